@@ -1,0 +1,83 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY.
+ * CPU restatement (plain C) of the TendermintX skip/step value-level witness path.  It is the checker the
+ * HIP path is compared against (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg) and is never
+ * linked, imported or executed by the product library (tendermintx_amd/csrc).
+ *
+ * The reference is Rust with un-vendored dependencies and cannot be built here (no cargo/rustc): see
+ * DESIGN.md "Oracle".  Pinning: reference fixtures + the five CI known-answer tables + RFC 8032 vectors,
+ * via tests/golden and oracle/py (pure-Python big-int model).
+ */
+#ifndef TMXO_H
+#define TMXO_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMXO_KIND_SKIP 0
+#define TMXO_KIND_STEP 1
+#define TMXO_REC_VALIDATOR 256
+#define TMXO_REC_HASHFIELD 48
+#define TMXO_REC_HEADER 1136
+#define TMXO_REC_PROOF 2336
+#define TMXO_FLAG_SIGNED 1
+#define TMXO_FLAG_PRESENT 2
+
+typedef struct {
+  uint8_t header[32];   /* Level-0 output: target_header / next_header */
+  uint32_t all_ok;
+  uint32_t fail_mask;   /* bit i = check i failed (order: DESIGN.md "checks") */
+  int32_t first_bad_sig;
+  uint32_t gt_target;   /* 2/3 verdict on the target set */
+  uint32_t gt_trusted;  /* 1/3 verdict on the trusted set (skip only) */
+  uint32_t dist_ok;     /* both skip-distance bounds hold (skip only) */
+  uint32_t reserved[2];
+} tmxo_report;
+
+/* Level-1 EdDSA values of one lane, all canonical little-endian */
+typedef struct {
+  uint8_t digest[64];
+  uint8_t h[32];
+  uint8_t pt[10][32]; /* A.x A.y R.x R.y sB.x sB.y hA.x hA.y sum.x sum.y */
+  uint32_t ok;
+  uint32_t decode_ok;
+} tmxo_eddsa_trace;
+
+void tmxo_sha256(const uint8_t* msg, size_t len, uint8_t out[32]);
+void tmxo_sha512(const uint8_t* msg, size_t len, uint8_t out[64]);
+void tmxo_sha512_3(const uint8_t* p0, size_t l0, const uint8_t* p1, size_t l1, const uint8_t* p2, size_t l2, uint8_t out[64]);
+
+void tmxo_eddsa_trace_lane(const uint8_t pk[32], const uint8_t sig[64], const uint8_t* msg, size_t len, tmxo_eddsa_trace* out);
+void tmxo_ed25519_pubkey(const uint8_t seed[32], uint8_t pk[32]);
+void tmxo_ed25519_sign(const uint8_t seed[32], const uint8_t* msg, size_t len, uint8_t sig[64]);
+void tmxo_sc_reduce512(const uint8_t in[64], uint8_t out[32]);
+void tmxo_dummy(uint8_t pk[32], uint8_t sig[64]);
+
+void tmxo_varint9(uint64_t v, uint8_t out[9]);
+void tmxo_marshal_validator(const uint8_t pk[32], uint64_t power, uint8_t out[46]);
+void tmxo_leaf_hash(const uint8_t* b, size_t len, uint8_t out[32]);
+void tmxo_inner_hash(const uint8_t l[32], const uint8_t r[32], uint8_t out[32]);
+/* RFC-6962 root over n already-hashed leaves (n >= 1) */
+void tmxo_rfc6962_root(const uint8_t* leaf_hashes, size_t n, uint8_t out[32]);
+/* fixed-shape in-circuit tree: writes all layer nodes (tree_nodes(n) x 32 B), returns root */
+size_t tmxo_tree_nodes(size_t n);
+void tmxo_fixed_shape_tree(const uint8_t* leaf_hashes, size_t n, size_t nb_enabled, uint8_t* nodes_out, uint8_t root[32]);
+/* threshold: returns gt; fills totals; *no_overflow cleared on any wrap */
+int tmxo_tally(const uint64_t* powers, size_t n, size_t nb, const uint8_t* in_group, uint64_t num, uint64_t den,
+               uint64_t* tot_prefix, uint64_t* acc_prefix, uint64_t scal[4], int* no_overflow);
+
+size_t tmxo_elem_count(int kind, size_t n);
+/* one proof; out must hold tmxo_elem_count(kind, n) elements.  trusted_recs ignored for step. returns 0 / <0 */
+int tmxo_witness(int kind, const uint8_t* proof_rec, const uint8_t* target_recs, const uint8_t* trusted_recs, uint32_t n,
+                 const uint8_t* chain_id, uint32_t chain_id_len, uint64_t skip_max, uint64_t* out, tmxo_report* rep);
+/* batch of independent proofs split over n_threads host threads (pthreads); out may be NULL (compute only) */
+int tmxo_witness_batch(int kind, uint32_t n_proofs, const uint8_t* proof_recs, const uint8_t* target_recs,
+                       const uint8_t* trusted_recs, uint32_t n, const uint8_t* chain_id, uint32_t chain_id_len,
+                       uint64_t skip_max, uint64_t* out, tmxo_report* reps, uint32_t n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,376 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY (CPU restatement; never linked into the product library).
+ *
+ * Value-level witness of the skip / step circuits: hint elements (H) + every derived Level-1 value (D),
+ * appended sequentially as Goldilocks elements (all values < 2^32, hence canonical).
+ *
+ * Reference map (file:line under /root/reference):
+ *   H order, skip     circuits/variables.rs:91-105, circuits/skip.rs:85-100
+ *   H order, step     circuits/variables.rs:108-120, circuits/step.rs:73-87
+ *   verify_skip       circuits/builder/verify.rs:528-563      verify_step      verify.rs:469-506
+ *   verify_header     verify.rs:224-334                        trusted match    verify.rs:361-437
+ *   marshal / leaf / set hash   circuits/builder/validator.rs:185-252, shared.rs:67-156
+ *   sig-data checks   validator.rs:80-183                      tally            circuits/builder/voting.rs:31-109
+ *   chain id / height verify.rs:180-222, shared.rs:169-207     header proofs    circuits/input/tendermint_utils.rs:214-393
+ * Layout of D and of the check bits: DESIGN.md "Witness layout".
+ */
+#include "tmxo.h"
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ encodings + Merkle */
+void tmxo_varint9(uint64_t v, uint8_t out[9]) {
+  /* shared.rs:67-156: nine septets; continuation bit iff index < last non-zero septet; trailing zeros */
+  int last = 0;
+  for (int i = 0; i < 9; i++) if ((v >> (7 * i)) & 0x7f) last = i;
+  for (int i = 0; i < 9; i++) out[i] = (uint8_t)(((v >> (7 * i)) & 0x7f) | (i < last ? 0x80 : 0));
+}
+void tmxo_marshal_validator(const uint8_t pk[32], uint64_t power, uint8_t out[46]) {
+  /* validator.rs:185-207: 0a 22 0a 20 pk 10 varint9 */
+  out[0] = 0x0a; out[1] = 0x22; out[2] = 0x0a; out[3] = 0x20;
+  memcpy(out + 4, pk, 32);
+  out[36] = 0x10;
+  tmxo_varint9(power, out + 37);
+}
+void tmxo_leaf_hash(const uint8_t* b, size_t len, uint8_t out[32]) {
+  uint8_t buf[1 + 128];
+  buf[0] = 0x00; memcpy(buf + 1, b, len);
+  tmxo_sha256(buf, len + 1, out);
+}
+void tmxo_inner_hash(const uint8_t l[32], const uint8_t r[32], uint8_t out[32]) {
+  uint8_t buf[65];
+  buf[0] = 0x01; memcpy(buf + 1, l, 32); memcpy(buf + 33, r, 32);
+  tmxo_sha256(buf, 65, out);
+}
+static size_t split_point(size_t n) { /* tendermint_utils.rs:338-349 */
+  size_t k = 1;
+  while (k * 2 < n) k *= 2;
+  return k;
+}
+void tmxo_rfc6962_root(const uint8_t* lh, size_t n, uint8_t out[32]) {
+  if (n == 1) { memcpy(out, lh, 32); return; }
+  size_t k = split_point(n);
+  uint8_t l[32], r[32];
+  tmxo_rfc6962_root(lh, k, l); tmxo_rfc6962_root(lh + 32 * k, n - k, r);
+  tmxo_inner_hash(l, r, out);
+}
+/* aunts (leaf->root) of leaf `index` among n hashed leaves; returns depth */
+static int rfc6962_aunts(const uint8_t* lh, size_t n, size_t index, uint8_t aunts[][32]) {
+  if (n == 1) return 0;
+  size_t k = split_point(n);
+  int d;
+  if (index < k) { d = rfc6962_aunts(lh, k, index, aunts); tmxo_rfc6962_root(lh + 32 * k, n - k, aunts[d]); }
+  else { d = rfc6962_aunts(lh + 32 * k, n - k, index - k, aunts); tmxo_rfc6962_root(lh, k, aunts[d]); }
+  return d + 1;
+}
+size_t tmxo_tree_nodes(size_t n) { size_t c = 0; while (n > 1) { n = (n + 1) / 2; c += n; } return c; }
+
+void tmxo_fixed_shape_tree(const uint8_t* leaf_hashes, size_t n, size_t nb, uint8_t* nodes_out, uint8_t root[32]) {
+  /* get_root_from_hashed_leaves value semantics (call: validator.rs:248-251): see oracle/py/tm_encoding.py */
+  uint8_t* cur = (uint8_t*)malloc(32 * n); uint8_t* en = (uint8_t*)malloc(n);
+  memcpy(cur, leaf_hashes, 32 * n);
+  for (size_t i = 0; i < n; i++) en[i] = i < nb;
+  size_t sz = n;
+  while (sz > 1) {
+    size_t nx = (sz + 1) / 2;
+    for (size_t i = 0; i < nx; i++) {
+      uint8_t nd[32];
+      if (2 * i + 1 < sz && en[2 * i] && en[2 * i + 1]) tmxo_inner_hash(cur + 64 * i, cur + 64 * i + 32, nd);
+      else memcpy(nd, cur + 64 * i, 32);
+      en[i] = en[2 * i];
+      memcpy(cur + 32 * i, nd, 32);
+      if (nodes_out) { memcpy(nodes_out, nd, 32); nodes_out += 32; }
+    }
+    sz = nx;
+  }
+  memcpy(root, cur, 32);
+  free(cur); free(en);
+}
+
+int tmxo_tally(const uint64_t* powers, size_t n, size_t nb, const uint8_t* in_group, uint64_t num, uint64_t den,
+               uint64_t* tot_prefix, uint64_t* acc_prefix, uint64_t scal[4], int* no_overflow) {
+  uint64_t total = 0, acc = 0;
+  int enabled = 1;
+  for (size_t i = 0; i < n; i++) {          /* voting.rs:31-63 */
+    if (i == nb) enabled = 0;
+    uint64_t t2 = total + (enabled ? powers[i] : 0);
+    if (t2 < total) *no_overflow = 0;
+    total = t2;
+    if (tot_prefix) tot_prefix[i] = total;
+  }
+  for (size_t i = 0; i < n; i++) {          /* voting.rs:79-89 */
+    uint64_t a2 = acc + (in_group[i] ? powers[i] : 0);
+    if (a2 < acc) *no_overflow = 0;
+    acc = a2;
+    if (acc_prefix) acc_prefix[i] = acc;
+  }
+  uint64_t sa = acc * den, st = total * num; /* voting.rs:91-105: wrapping mul checked by division */
+  if (sa / den != acc) *no_overflow = 0;
+  if (st / num != total) *no_overflow = 0;
+  scal[0] = total; scal[1] = acc; scal[2] = sa; scal[3] = st;
+  return sa > st;                            /* voting.rs:108 */
+}
+
+/* ------------------------------------------------------------------ element stream */
+typedef struct { uint64_t* p; size_t n; } es;
+static void e_byte(es* e, uint8_t b) { for (int k = 7; k >= 0; k--) { if (e->p) e->p[e->n] = (b >> k) & 1; e->n++; } }
+static void e_bytes(es* e, const uint8_t* b, size_t len) { for (size_t i = 0; i < len; i++) e_byte(e, b[i]); }
+static void e_u32(es* e, uint64_t v) { if (e->p) e->p[e->n] = v & 0xffffffffu; e->n++; }
+static void e_u64(es* e, uint64_t v) { e_u32(e, v); e_u32(e, v >> 32); }
+static void e_u256le(es* e, const uint8_t b[32]) {
+  for (int k = 0; k < 8; k++) e_u32(e, (uint64_t)b[4 * k] | ((uint64_t)b[4 * k + 1] << 8) | ((uint64_t)b[4 * k + 2] << 16) | ((uint64_t)b[4 * k + 3] << 24));
+}
+static void e_bool(es* e, int b) { e_u32(e, b ? 1 : 0); }
+
+static uint64_t rd64(const uint8_t* p) { uint64_t v = 0; for (int k = 7; k >= 0; k--) v = (v << 8) | p[k]; return v; }
+static uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+typedef struct {
+  uint8_t len[14];
+  const uint8_t* leaf[14];
+  uint8_t lh[14][32];
+  uint8_t root[32];
+} hdr;
+
+static void hdr_load(hdr* h, const uint8_t* rec) {
+  for (int i = 0; i < 14; i++) { h->len[i] = rec[i]; h->leaf[i] = rec + 16 + 80 * i; tmxo_leaf_hash(h->leaf[i], h->len[i], h->lh[i]); }
+  tmxo_rfc6962_root(&h->lh[0][0], 14, h->root);
+}
+/* walk a depth-4 proof (tendermint_utils.rs:214-224; path bits LSB-first per shared.rs:45-65) */
+static void proof_walk(const uint8_t leaf_hash[32], int index, uint8_t aunts[4][32], uint8_t nodes[4][32]) {
+  uint8_t cur[32]; memcpy(cur, leaf_hash, 32);
+  for (int k = 0; k < 4; k++) {
+    if ((index >> k) & 1) tmxo_inner_hash(aunts[k], cur, nodes[k]); else tmxo_inner_hash(cur, aunts[k], nodes[k]);
+    memcpy(cur, nodes[k], 32);
+  }
+}
+static void emit_proof_d(es* e, const uint8_t lh[32], uint8_t nodes[4][32]) { e_bytes(e, lh, 32); for (int k = 0; k < 4; k++) e_bytes(e, nodes[k], 32); }
+
+static uint64_t height_from_leaf(const uint8_t* leaf, int len) {
+  uint64_t x = 0; int s = 0;
+  for (int i = 1; i < len; i++) { x |= (uint64_t)(leaf[i] & 0x7f) << s; s += 7; }
+  return x;
+}
+
+#define DT 1235
+#define DR 630
+#define PROOF_D 1280
+size_t tmxo_elem_count(int kind, size_t n) {
+  if (kind == TMXO_KIND_SKIP) return 1776 * n + 5320 + n * DT + n * DR + 2 * tmxo_tree_nodes(n) * 256 + (4 * PROOF_D + 88) + 33;
+  return 1517 * n + 6919 + n * DT + tmxo_tree_nodes(n) * 256 + (5 * PROOF_D + 88) + 24;
+}
+
+int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8_t* rrec, uint32_t n,
+                 const uint8_t* chain_id, uint32_t chain_id_len, uint64_t skip_max, uint64_t* out, tmxo_report* rep) {
+  if (n == 0 || n > 4096) return -1;
+  es E = {out, 0};
+  uint64_t block_a = rd64(prec), block_b = rd64(prec + 8), round = rd64(prec + 48);
+  const uint8_t* pub_hash = prec + 16;
+  uint32_t nb = rd32(prec + 56), nbt = rd32(prec + 60);
+  hdr ha, hb;
+  hdr_load(&ha, prec + 64); hdr_load(&hb, prec + 64 + TMXO_REC_HEADER);
+  const uint8_t* header = ha.root;
+  uint64_t height_a = height_from_leaf(ha.leaf[2], ha.len[2]);
+  uint8_t dummy_pk[32], dummy_sig[64], zero_msg[32] = {0};
+  tmxo_dummy(dummy_pk, dummy_sig);
+
+  uint8_t a_cid[4][32], a_h[4][32], a_v[4][32], a_tv[4][32], a_lb[4][32], a_nv[4][32];
+  rfc6962_aunts(&ha.lh[0][0], 14, 1, a_cid); rfc6962_aunts(&ha.lh[0][0], 14, 2, a_h); rfc6962_aunts(&ha.lh[0][0], 14, 7, a_v);
+  uint8_t leaf34[34], leaf72[72], leafb[34];
+
+  /* ---------------- H */
+  e_bytes(&E, header, 32);
+  for (uint32_t i = 0; i < n; i++) {
+    const uint8_t* v = trec + (size_t)TMXO_REC_VALIDATOR * i;
+    e_bytes(&E, v, 32); e_bytes(&E, v + 32, 32); e_u256le(&E, v + 64); e_bytes(&E, v + 96, 124);
+    e_u32(&E, (uint64_t)v[220] | ((uint64_t)v[221] << 8)); e_u64(&E, rd64(v + 224)); e_u32(&E, v[222]); e_bool(&E, v[223] & TMXO_FLAG_SIGNED);
+  }
+  e_u32(&E, nb); e_u64(&E, round);
+  for (int k = 0; k < 4; k++) e_bytes(&E, a_cid[k], 32);
+  e_u32(&E, ha.len[1]);
+  { uint8_t cid52[52] = {0}; memcpy(cid52, ha.leaf[1], ha.len[1] < 52 ? ha.len[1] : 52); e_bytes(&E, cid52, 52); }
+  for (int k = 0; k < 4; k++) e_bytes(&E, a_h[k], 32);
+  e_u32(&E, ha.len[2]); e_u64(&E, height_a);
+  memset(leaf34, 0, 34); memcpy(leaf34, ha.leaf[7], ha.len[7] < 34 ? ha.len[7] : 34);
+  for (int k = 0; k < 4; k++) e_bytes(&E, a_v[k], 32);
+  e_bytes(&E, leaf34, 34);
+  if (kind == TMXO_KIND_SKIP) {
+    rfc6962_aunts(&hb.lh[0][0], 14, 7, a_tv);
+    memset(leafb, 0, 34); memcpy(leafb, hb.leaf[7], hb.len[7] < 34 ? hb.len[7] : 34);
+    e_u32(&E, nbt);
+    for (int k = 0; k < 4; k++) e_bytes(&E, a_tv[k], 32);
+    e_bytes(&E, leafb, 34);
+    for (uint32_t j = 0; j < n; j++) { const uint8_t* t = rrec + (size_t)TMXO_REC_HASHFIELD * j; e_bytes(&E, t, 32); e_u64(&E, rd64(t + 32)); e_u32(&E, t[40]); }
+  } else {
+    rfc6962_aunts(&ha.lh[0][0], 14, 4, a_lb); rfc6962_aunts(&hb.lh[0][0], 14, 8, a_nv);
+    memset(leaf72, 0, 72); memcpy(leaf72, ha.leaf[4], ha.len[4] < 72 ? ha.len[4] : 72);
+    memset(leafb, 0, 34); memcpy(leafb, hb.leaf[8], hb.len[8] < 34 ? hb.len[8] : 34);
+    for (int k = 0; k < 4; k++) e_bytes(&E, a_lb[k], 32);
+    e_bytes(&E, leaf72, 72);
+    for (int k = 0; k < 4; k++) e_bytes(&E, a_nv[k], 32);
+    e_bytes(&E, leafb, 34);
+  }
+
+  /* ---------------- D */
+  uint64_t expected_height = block_b;
+  uint64_t* powers = (uint64_t*)malloc(8 * n); uint8_t* signedv = (uint8_t*)malloc(n);
+  uint64_t* totp = (uint64_t*)malloc(8 * n); uint64_t* accp = (uint64_t*)malloc(8 * n);
+  uint8_t* leaves = (uint8_t*)malloc(32 * n); uint8_t* nodes = (uint8_t*)malloc(32 * (tmxo_tree_nodes(n) + 1));
+  int no_overflow = 1, varint_ok = 1;
+  for (uint32_t i = 0; i < n; i++) { const uint8_t* v = trec + (size_t)TMXO_REC_VALIDATOR * i; powers[i] = rd64(v + 224); signedv[i] = v[223] & TMXO_FLAG_SIGNED; if (powers[i] >> 63) varint_ok = 0; }
+  uint64_t scal_t[4], scal_r[4] = {0, 0, 0, 0};
+  int gt_t = tmxo_tally(powers, n, nb, signedv, 2, 3, totp, accp, scal_t, &no_overflow), gt_r = 0;
+  int all_eddsa = 1, all_sigdata = 1; int32_t first_bad = -1;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint8_t* v = trec + (size_t)TMXO_REC_VALIDATOR * i;
+    uint8_t m[46], lh[32];
+    tmxo_marshal_validator(v, powers[i], m);
+    tmxo_leaf_hash(m, v[222], lh);                       /* validator.rs:209-229: 1 + vlen bytes */
+    memcpy(leaves + 32 * i, lh, 32);
+    tmxo_eddsa_trace tr;
+    size_t mlen = (size_t)v[220] | ((size_t)v[221] << 8);
+    if (signedv[i]) tmxo_eddsa_trace_lane(v, v + 32, v + 96, mlen, &tr);
+    else tmxo_eddsa_trace_lane(dummy_pk, dummy_sig, zero_msg, 32, &tr);   /* conditional substitution (verify.rs:248-259) */
+    const uint8_t* msg = v + 96;
+    int enabled = i < nb;
+    int off = round == 0 ? 16 : 25;
+    int hash_in_msg = memcmp(msg + off, header, 32) == 0;                   /* validator.rs:155-183 */
+    int is_precommit = msg[1] == 8 && msg[2] == 2;                          /* validator.rs:100-109 */
+    int height_ok = rd64(msg + 4) == expected_height;                       /* validator.rs:111-123 */
+    int round_ok = round == 0 ? 1 : (rd64(msg + 13) == round);              /* validator.rs:125-141 */
+    int valid = signedv[i] && enabled && hash_in_msg && is_precommit && height_ok && round_ok;
+    int sigdata_ok = (signedv[i] != 0) == valid;                            /* validator.rs:143-152 */
+    e_bytes(&E, m, 46); e_bytes(&E, lh, 32); e_bytes(&E, tr.digest, 64); e_u256le(&E, tr.h);
+    for (int k = 0; k < 10; k++) e_u256le(&E, tr.pt[k]);
+    e_bool(&E, tr.ok); e_bool(&E, enabled); e_bool(&E, hash_in_msg); e_bool(&E, is_precommit); e_bool(&E, height_ok);
+    e_bool(&E, round_ok); e_bool(&E, sigdata_ok);
+    e_u64(&E, totp[i]); e_u64(&E, accp[i]);
+    if (!tr.ok) { all_eddsa = 0; if (first_bad < 0) first_bad = (int32_t)i; }
+    if (!sigdata_ok) all_sigdata = 0;
+  }
+  uint8_t root_t[32], root_r[32];
+  tmxo_fixed_shape_tree(leaves, n, nb, nodes, root_t);
+  size_t tn = tmxo_tree_nodes(n);
+  uint8_t* nodes_r = NULL;
+  if (kind == TMXO_KIND_SKIP) {
+    uint8_t* matched = (uint8_t*)malloc(n); uint64_t* rp = (uint64_t*)malloc(8 * n);
+    uint8_t* rleaves = (uint8_t*)malloc(32 * n); uint8_t* rm = (uint8_t*)malloc(46 * n);
+    nodes_r = (uint8_t*)malloc(32 * (tn + 1));
+    for (uint32_t j = 0; j < n; j++) {
+      const uint8_t* t = rrec + (size_t)TMXO_REC_HASHFIELD * j;
+      rp[j] = rd64(t + 32); if (rp[j] >> 63) varint_ok = 0;
+      matched[j] = 0;
+      for (uint32_t i = 0; i < n; i++)                                  /* verify.rs:398-418 */
+        if (signedv[i] && memcmp(trec + (size_t)TMXO_REC_VALIDATOR * i, t, 32) == 0) matched[j] = 1;
+      tmxo_marshal_validator(t, rp[j], rm + 46 * j);
+      tmxo_leaf_hash(rm + 46 * j, t[40], rleaves + 32 * j);
+    }
+    gt_r = tmxo_tally(rp, n, nbt, matched, 1, 3, totp, accp, scal_r, &no_overflow);
+    for (uint32_t j = 0; j < n; j++) {
+      e_bytes(&E, rm + 46 * j, 46); e_bytes(&E, rleaves + 32 * j, 32); e_bool(&E, j < nbt); e_bool(&E, matched[j]);
+      e_u64(&E, totp[j]); e_u64(&E, accp[j]);
+    }
+    tmxo_fixed_shape_tree(rleaves, n, nbt, nodes_r, root_r);
+    free(matched); free(rp); free(rleaves); free(rm);
+  }
+  e_bytes(&E, nodes, 32 * tn);
+  if (kind == TMXO_KIND_SKIP) e_bytes(&E, nodes_r, 32 * tn);
+
+  uint8_t n_cid[4][32], n_h[4][32], n_v[4][32], n_x[4][32], n_y[4][32], hl[11], hlh[32], vlh[32], xlh[32], ylh[32];
+  proof_walk(ha.lh[1], 1, a_cid, n_cid);                                  /* verify.rs:189-209 */
+  hl[0] = 0x00; hl[1] = 0x08; tmxo_varint9(height_a, hl + 2);             /* shared.rs:158-167 */
+  tmxo_leaf_hash(hl + 1, ha.len[2], hlh);                                  /* shared.rs:183-194: 1 + enc_len bytes */
+  proof_walk(hlh, 2, a_h, n_h);
+  tmxo_leaf_hash(leaf34, 34, vlh); proof_walk(vlh, 7, a_v, n_v);
+  emit_proof_d(&E, ha.lh[1], n_cid);
+  e_bytes(&E, hl, 11); emit_proof_d(&E, hlh, n_h);
+  emit_proof_d(&E, vlh, n_v);
+  uint8_t cid52[52] = {0}; memcpy(cid52, ha.leaf[1], ha.len[1] < 52 ? ha.len[1] : 52);
+  int chain_ok = chain_id_len <= 50 && memcmp(cid52 + 2, chain_id, chain_id_len) == 0;   /* verify.rs:211-221 */
+  int checks[16]; int nchk = 0; int all_ok = 1;
+  if (kind == TMXO_KIND_SKIP) {
+    tmxo_leaf_hash(leafb, 34, xlh); proof_walk(xlh, 7, a_tv, n_x);
+    emit_proof_d(&E, xlh, n_x);
+    for (int k = 0; k < 4; k++) e_u64(&E, scal_t[k]);
+    e_bool(&E, gt_t);
+    for (int k = 0; k < 4; k++) e_u64(&E, scal_r[k]);
+    e_bool(&E, gt_r);
+    int dist_gt = block_b > block_a + 1, dist_le = block_b <= block_a + skip_max;     /* verify.rs:508-526 */
+    e_bool(&E, dist_gt); e_bool(&E, dist_le);
+    checks[nchk++] = memcmp(n_x[3], pub_hash, 32) == 0;     /* verify.rs:374-379 */
+    checks[nchk++] = memcmp(root_r, leafb + 2, 32) == 0;    /* verify.rs:382-389 */
+    checks[nchk++] = memcmp(root_t, leaf34 + 2, 32) == 0;   /* verify.rs:279-280 */
+    checks[nchk++] = memcmp(n_v[3], header, 32) == 0;       /* verify.rs:283-286 */
+    checks[nchk++] = memcmp(n_cid[3], header, 32) == 0;     /* verify.rs:205-209 */
+    checks[nchk++] = chain_ok;
+    checks[nchk++] = memcmp(n_h[3], header, 32) == 0;       /* shared.rs:197-203 */
+    checks[nchk++] = height_a == expected_height;           /* shared.rs:206 */
+    checks[nchk++] = all_sigdata; checks[nchk++] = all_eddsa; checks[nchk++] = no_overflow; checks[nchk++] = varint_ok;
+    for (int k = 0; k < nchk; k++) { e_bool(&E, checks[k]); all_ok = all_ok && checks[k]; }
+    all_ok = all_ok && gt_t && gt_r && dist_gt && dist_le;
+    e_bool(&E, all_ok);
+    if (rep) rep->dist_ok = (uint32_t)(dist_gt && dist_le);
+  } else {
+    tmxo_leaf_hash(leaf72, 72, xlh); proof_walk(xlh, 4, a_lb, n_x);
+    emit_proof_d(&E, xlh, n_x);
+    tmxo_leaf_hash(leafb, 34, ylh); proof_walk(ylh, 8, a_nv, n_y);
+    emit_proof_d(&E, ylh, n_y);
+    for (int k = 0; k < 4; k++) e_u64(&E, scal_t[k]);
+    e_bool(&E, gt_t);
+    checks[nchk++] = memcmp(root_t, leaf34 + 2, 32) == 0;
+    checks[nchk++] = memcmp(n_v[3], header, 32) == 0;
+    checks[nchk++] = memcmp(n_cid[3], header, 32) == 0;
+    checks[nchk++] = chain_ok;
+    checks[nchk++] = memcmp(n_h[3], header, 32) == 0;
+    checks[nchk++] = height_a == expected_height;
+    checks[nchk++] = all_sigdata; checks[nchk++] = all_eddsa; checks[nchk++] = no_overflow; checks[nchk++] = varint_ok;
+    checks[nchk++] = memcmp(n_x[3], header, 32) == 0;       /* verify.rs:144-147 */
+    checks[nchk++] = memcmp(leaf72 + 2, pub_hash, 32) == 0; /* verify.rs:150-153 */
+    checks[nchk++] = memcmp(n_y[3], pub_hash, 32) == 0;     /* verify.rs:166-170 */
+    checks[nchk++] = memcmp(leaf34 + 2, leafb + 2, 32) == 0;/* verify.rs:173-177 */
+    for (int k = 0; k < nchk; k++) { e_bool(&E, checks[k]); all_ok = all_ok && checks[k]; }
+    all_ok = all_ok && gt_t;
+    e_bool(&E, all_ok);
+    if (rep) rep->dist_ok = 0;
+  }
+  if (rep) {
+    memcpy(rep->header, header, 32);
+    rep->all_ok = (uint32_t)all_ok; rep->fail_mask = 0;
+    for (int k = 0; k < nchk; k++) if (!checks[k]) rep->fail_mask |= 1u << k;
+    rep->first_bad_sig = first_bad; rep->gt_target = (uint32_t)gt_t; rep->gt_trusted = (uint32_t)gt_r;
+    rep->reserved[0] = rep->reserved[1] = 0;
+  }
+  free(powers); free(signedv); free(totp); free(accp); free(leaves); free(nodes); free(nodes_r);
+  return E.n == tmxo_elem_count(kind, n) ? 0 : -2;
+}
+
+typedef struct {
+  int kind; uint32_t lo, hi, n; const uint8_t *p, *t, *r, *cid; uint32_t cid_len; uint64_t skip_max; uint64_t* out; tmxo_report* reps; int rc;
+} job;
+static void* worker(void* arg) {
+  job* j = (job*)arg;
+  size_t ec = tmxo_elem_count(j->kind, j->n);
+  for (uint32_t i = j->lo; i < j->hi; i++) {
+    int rc = tmxo_witness(j->kind, j->p + (size_t)TMXO_REC_PROOF * i, j->t + (size_t)TMXO_REC_VALIDATOR * j->n * i,
+                          j->r ? j->r + (size_t)TMXO_REC_HASHFIELD * j->n * i : NULL, j->n, j->cid, j->cid_len, j->skip_max,
+                          j->out ? j->out + ec * i : NULL, j->reps ? j->reps + i : NULL);
+    if (rc) j->rc = rc;
+  }
+  return NULL;
+}
+int tmxo_witness_batch(int kind, uint32_t n_proofs, const uint8_t* proof_recs, const uint8_t* target_recs,
+                       const uint8_t* trusted_recs, uint32_t n, const uint8_t* chain_id, uint32_t chain_id_len,
+                       uint64_t skip_max, uint64_t* out, tmxo_report* reps, uint32_t n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > n_proofs) n_threads = n_proofs ? n_proofs : 1;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads); job* jobs = (job*)malloc(sizeof(job) * n_threads);
+  int rc = 0;
+  for (uint32_t k = 0; k < n_threads; k++) {
+    jobs[k] = (job){kind, (uint32_t)((uint64_t)n_proofs * k / n_threads), (uint32_t)((uint64_t)n_proofs * (k + 1) / n_threads), n,
+                    proof_recs, target_recs, trusted_recs, chain_id, chain_id_len, skip_max, out, reps, 0};
+    if (n_threads == 1) worker(&jobs[k]); else pthread_create(&th[k], NULL, worker, &jobs[k]);
+  }
+  for (uint32_t k = 0; k < n_threads; k++) { if (n_threads > 1) pthread_join(th[k], NULL); if (jobs[k].rc) rc = jobs[k].rc; }
+  free(th); free(jobs);
+  return rc;
+}

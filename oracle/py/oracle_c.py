@@ -1,0 +1,155 @@
+"""ctypes binding of the C oracle (oracle/c/libtmx_oracle.so).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CDIR = os.path.join(os.path.dirname(_HERE), "c")
+_LIB = None
+
+
+class Report(C.Structure):
+    _fields_ = [("header", C.c_uint8 * 32), ("all_ok", C.c_uint32), ("fail_mask", C.c_uint32),
+                ("first_bad_sig", C.c_int32), ("gt_target", C.c_uint32), ("gt_trusted", C.c_uint32),
+                ("dist_ok", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+
+
+class EddsaTrace(C.Structure):
+    _fields_ = [("digest", C.c_uint8 * 64), ("h", C.c_uint8 * 32), ("pt", (C.c_uint8 * 32) * 10),
+                ("ok", C.c_uint32), ("decode_ok", C.c_uint32)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _CDIR])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_CDIR, "libtmx_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.tmxo_elem_count.restype = C.c_size_t
+        _LIB.tmxo_elem_count.argtypes = [C.c_int, C.c_size_t]
+        _LIB.tmxo_tree_nodes.restype = C.c_size_t
+        _LIB.tmxo_tree_nodes.argtypes = [C.c_size_t]
+    return _LIB
+
+
+def sha256(b):
+    out = (C.c_uint8 * 32)()
+    lib().tmxo_sha256(bytes(b), C.c_size_t(len(b)), out)
+    return bytes(out)
+
+
+def sha512(b):
+    out = (C.c_uint8 * 64)()
+    lib().tmxo_sha512(bytes(b), C.c_size_t(len(b)), out)
+    return bytes(out)
+
+
+def eddsa_trace(pk, sig, msg):
+    tr = EddsaTrace()
+    lib().tmxo_eddsa_trace_lane(bytes(pk), bytes(sig), bytes(msg), C.c_size_t(len(msg)), C.byref(tr))
+    return dict(digest=bytes(tr.digest), h=bytes(tr.h), pt=[bytes(tr.pt[k]) for k in range(10)], ok=bool(tr.ok),
+                decode_ok=bool(tr.decode_ok))
+
+
+def pubkey(seed):
+    out = (C.c_uint8 * 32)()
+    lib().tmxo_ed25519_pubkey(bytes(seed), out)
+    return bytes(out)
+
+
+def sign(seed, msg):
+    out = (C.c_uint8 * 64)()
+    lib().tmxo_ed25519_sign(bytes(seed), bytes(msg), C.c_size_t(len(msg)), out)
+    return bytes(out)
+
+
+def dummy():
+    pk, sig = (C.c_uint8 * 32)(), (C.c_uint8 * 64)()
+    lib().tmxo_dummy(pk, sig)
+    return bytes(pk), bytes(sig)
+
+
+def sc_reduce512(b):
+    out = (C.c_uint8 * 32)()
+    lib().tmxo_sc_reduce512(bytes(b), out)
+    return bytes(out)
+
+
+def varint9(v):
+    out = (C.c_uint8 * 9)()
+    lib().tmxo_varint9(C.c_uint64(v), out)
+    return bytes(out)
+
+
+def marshal_validator(pk, power):
+    out = (C.c_uint8 * 46)()
+    lib().tmxo_marshal_validator(bytes(pk), C.c_uint64(power), out)
+    return bytes(out)
+
+
+def rfc6962_root(leaf_hashes):
+    out = (C.c_uint8 * 32)()
+    lib().tmxo_rfc6962_root(b"".join(leaf_hashes), C.c_size_t(len(leaf_hashes)), out)
+    return bytes(out)
+
+
+def fixed_shape_tree(leaf_hashes, nb):
+    n = len(leaf_hashes)
+    tn = lib().tmxo_tree_nodes(n)
+    nodes = (C.c_uint8 * (32 * max(tn, 1)))()
+    root = (C.c_uint8 * 32)()
+    lib().tmxo_fixed_shape_tree(b"".join(leaf_hashes), C.c_size_t(n), C.c_size_t(nb), nodes, root)
+    return bytes(nodes)[:32 * tn], bytes(root)
+
+
+def tally(powers, nb, in_group, num, den):
+    n = len(powers)
+    pw = (C.c_uint64 * n)(*powers)
+    ig = (C.c_uint8 * n)(*[1 if x else 0 for x in in_group])
+    tp, ap, sc = (C.c_uint64 * n)(), (C.c_uint64 * n)(), (C.c_uint64 * 4)()
+    no = C.c_int(1)
+    gt = lib().tmxo_tally(pw, C.c_size_t(n), C.c_size_t(nb), ig, C.c_uint64(num), C.c_uint64(den), tp, ap, sc, C.byref(no))
+    return dict(gt=bool(gt), tot_prefix=list(tp), acc_prefix=list(ap), total=sc[0], acc=sc[1], scaled_acc=sc[2],
+                scaled_total=sc[3], no_overflow=bool(no.value))
+
+
+def elem_count(kind, n):
+    return lib().tmxo_elem_count(kind, n)
+
+
+def _rep(r):
+    return dict(header=bytes(r.header), all_ok=bool(r.all_ok), fail_mask=r.fail_mask, first_bad_sig=r.first_bad_sig,
+                gt_target=bool(r.gt_target), gt_trusted=bool(r.gt_trusted), dist_ok=bool(r.dist_ok))
+
+
+def witness(kind, proof_rec, target_recs, trusted_recs, chain_id, skip_max):
+    """One proof.  *_recs: bytes (concatenated records).  Returns (np.uint64 array, report dict)."""
+    n = len(target_recs) // 256
+    out = np.zeros(elem_count(kind, n), dtype=np.uint64)
+    rep = Report()
+    rc = lib().tmxo_witness(kind, bytes(proof_rec), bytes(target_recs), bytes(trusted_recs) if trusted_recs else None,
+                            C.c_uint32(n), bytes(chain_id), C.c_uint32(len(chain_id)), C.c_uint64(skip_max),
+                            out.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(rep))
+    if rc:
+        raise RuntimeError(f"tmxo_witness rc={rc}")
+    return out, _rep(rep)
+
+
+def witness_batch(kind, n_proofs, proof_recs, target_recs, trusted_recs, n, chain_id, skip_max, n_threads=1, want_out=True):
+    ec = elem_count(kind, n)
+    out = np.zeros(ec * n_proofs, dtype=np.uint64) if want_out else None
+    reps = (Report * n_proofs)()
+    rc = lib().tmxo_witness_batch(kind, C.c_uint32(n_proofs), bytes(proof_recs), bytes(target_recs),
+                                  bytes(trusted_recs) if trusted_recs else None, C.c_uint32(n), bytes(chain_id),
+                                  C.c_uint32(len(chain_id)), C.c_uint64(skip_max),
+                                  out.ctypes.data_as(C.POINTER(C.c_uint64)) if want_out else None, reps, C.c_uint32(n_threads))
+    if rc:
+        raise RuntimeError(f"tmxo_witness_batch rc={rc}")
+    return (out.reshape(n_proofs, ec) if want_out else None), [_rep(r) for r in reps]
