@@ -1,0 +1,193 @@
+/* libtmx -- MI355X-native witness generator for the TendermintX skip / step circuits.  C ABI.
+ *
+ * This is the drop-in boundary for ONE path of succinctlabs/tendermintx: the value-level witness that the
+ * off-chain-input hints produce and the gadget tree consumes.  Reference interfaces replaced:
+ *
+ *   SkipOffchainInputs::hint   reference circuits/skip.rs:64-102   (reads U64, Bytes32, U64; writes VerifySkipVariable<N>)
+ *   StepOffchainInputs::hint   reference circuits/step.rs:56-89    (reads U64, Bytes32;      writes VerifyStepVariable<N>)
+ *   InputDataFetcher::get_skip_inputs / get_step_inputs   reference circuits/input/mod.rs:425-523, 316-423
+ *   get_validator_data_from_block / validator_hash_field_from_block   reference circuits/input/conversion.rs:59-178
+ *   verify_skip / verify_step gadget values   reference circuits/builder/verify.rs:469-563 (+ validator.rs, voting.rs, shared.rs)
+ *
+ * The Rust host keeps `impl Circuit for SkipCircuit / StepCircuit` (skip.rs:113-143, step.rs:100-127) and
+ * bin/skip.rs / bin/step.rs unchanged; only the hint body calls into this library (INTEGRATION.md shows the
+ * FFI stub).  All compute below runs in hand-written HIP kernels for gfx950; there is no CPU fallback: every
+ * entry point fails with TMX_ERR_HIP if no device is usable.
+ *
+ * Conventions: every function returns 0 on success or a negative tmx_status; nothing throws across the ABI;
+ * the caller owns all buffers passed in; the library never keeps caller pointers after returning; a tmx_ctx is
+ * not thread-safe (use one per thread, they are independent: one HIP stream each).
+ */
+#ifndef TMX_H
+#define TMX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMX_KIND_SKIP 0
+#define TMX_KIND_STEP 1
+
+#define TMX_N_MAX_LIMIT 512 /* largest VALIDATOR_SET_SIZE_MAX a context accepts (BASELINE config 5) */
+
+/* reference circuits/consts.rs:9-29 */
+#define TMX_VALIDATOR_MESSAGE_BYTES_LENGTH_MAX 124
+#define TMX_VALIDATOR_BYTE_LENGTH_MAX 46
+#define TMX_PROTOBUF_CHAIN_ID_SIZE_BYTES 52
+#define TMX_HEADER_PROOF_DEPTH 4
+
+#define TMX_FLAG_SIGNED 1u  /* CommitSig::is_commit() -- conversion.rs:79 */
+#define TMX_FLAG_PRESENT 2u /* lane index < commit.signatures.len() -- conversion.rs:70 vs :118 */
+
+typedef enum {
+  TMX_OK = 0,
+  TMX_ERR_BAD_ARG = -1,
+  TMX_ERR_SET_TOO_LARGE = -2, /* reference input/mod.rs:439-444, 338-342: validator set larger than N */
+  TMX_ERR_HIP = -3,           /* no device / HIP runtime error (message in tmx_last_error) */
+  TMX_ERR_CAPACITY = -4,      /* output buffer or context batch capacity too small */
+  TMX_ERR_PARSE = -5,         /* malformed fixture / RPC JSON */
+  TMX_ERR_MSG_TOO_LONG = -6   /* sign-bytes longer than 124 B -- conversion.rs:52 `try_into().unwrap()` */
+} tmx_status;
+
+/* One lane of `target_block_validators` (ValidatorType, reference circuits/variables.rs:69-79) before
+ * field-element expansion.  256 B so that a wavefront's lanes read 16-B aligned, coalescable records. */
+typedef struct {
+  uint8_t pubkey[32];
+  uint8_t signature[64]; /* R || s, s little-endian (conversion.rs:43-46) */
+  uint8_t message[TMX_VALIDATOR_MESSAGE_BYTES_LENGTH_MAX]; /* sign-bytes, zero padded (conversion.rs:37-39) */
+  uint16_t message_byte_length;
+  uint8_t validator_byte_length;
+  uint8_t flags; /* TMX_FLAG_* */
+  uint64_t voting_power;
+  uint8_t pad[24];
+} tmx_validator_rec;
+
+/* One lane of `trusted_header_validator_hash_fields` (ValidatorHashField, variables.rs:82-88). */
+typedef struct {
+  uint8_t pubkey[32];
+  uint64_t voting_power;
+  uint8_t validator_byte_length;
+  uint8_t flags;
+  uint8_t pad[6];
+} tmx_hashfield_rec;
+
+/* The 14 protobuf-encoded header fields (reference circuits/input/tendermint_utils.rs:374-393), each < 80 B. */
+typedef struct {
+  uint8_t leaf_len[14];
+  uint8_t pad[2];
+  uint8_t leaf[14][80];
+} tmx_header_rec;
+
+/* Per-proof fixed inputs.  skip: block_a = trusted_block, block_b = target_block, hash = trusted_header_hash,
+ * header_a = target header, header_b = trusted header, nb_a / nb_b = target / trusted validator counts.
+ * step: block_a = prev_block_number, block_b = prev + 1, hash = prev_header_hash, header_a = next header,
+ * header_b = prev header, nb_a = next validator count, nb_b = 0. */
+typedef struct {
+  uint64_t block_a;
+  uint64_t block_b;
+  uint8_t hash[32];
+  uint64_t round; /* commit.round of header_a's block */
+  uint32_t nb_a;
+  uint32_t nb_b;
+  tmx_header_rec header_a;
+  tmx_header_rec header_b;
+} tmx_proof_rec;
+
+/* Level-0 output + verdicts, one per proof.  fail_mask bit order: DESIGN.md "checks". */
+typedef struct {
+  uint8_t header[32]; /* target_header (skip.rs:132) / next_header (step.rs:116) */
+  uint32_t all_ok;
+  uint32_t fail_mask;
+  int32_t first_bad_sig; /* first lane whose EdDSA equation fails (conversion.rs:48-49 panic site), or -1 */
+  uint32_t gt_target;    /* signed power * 3 > total * 2   (verify.rs:289-303) */
+  uint32_t gt_trusted;   /* matched power * 3 > total * 1  (verify.rs:428-436), skip only */
+  uint32_t dist_ok;      /* verify_skip_distance (verify.rs:508-526), skip only */
+  uint32_t reserved[2];
+} tmx_report;
+
+typedef struct {
+  uint32_t n_max;        /* VALIDATOR_SET_SIZE_MAX (const generic of SkipCircuit / StepCircuit), 1..512 */
+  uint32_t chain_id_len; /* CHAIN_ID_SIZE_BYTES */
+  uint8_t chain_id[TMX_PROTOBUF_CHAIN_ID_SIZE_BYTES]; /* TendermintConfig::CHAIN_ID_BYTES (config.rs:6) */
+  uint64_t skip_max;     /* TendermintConfig::SKIP_MAX (config.rs:7) */
+  int32_t device;        /* HIP device ordinal */
+  uint32_t max_batch;    /* proofs per call this context preallocates scratch for (>= 1) */
+} tmx_config;
+
+typedef struct tmx_ctx tmx_ctx;
+
+/* names of the kernels timed by tmx_last_kernel_ms, in launch order */
+#define TMX_N_KERNELS 3
+#define TMX_K_EDDSA 0     /* per-validator Ed25519: SHA-512, decode, s*B, h*A, R+hA, affine */
+#define TMX_K_PROOF 1     /* marshal + SHA-256 leaves + Merkle trees + header proofs + NxN match + tallies */
+#define TMX_K_SERIALIZE 2 /* Goldilocks element fill */
+
+uint32_t tmx_version(void);
+const char* tmx_status_str(int32_t status);
+
+int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out);
+void tmx_ctx_destroy(tmx_ctx* ctx);
+const char* tmx_last_error(const tmx_ctx* ctx);
+
+/* number of Goldilocks elements of one witness, and the (even) row stride used in batched output */
+uint64_t tmx_elem_count(int32_t kind, uint32_t n_max);
+uint64_t tmx_elem_stride(int32_t kind, uint32_t n_max);
+/* offset and length of the hint section H (= VerifySkipVariable<N> / VerifyStepVariable<N> elements) in a row */
+uint64_t tmx_hint_elem_count(int32_t kind, uint32_t n_max);
+
+/* ---- host-buffer entry points: what the Rust hint binds.  out_elems receives tmx_elem_count() elements. */
+int32_t tmx_skip_witness(tmx_ctx* ctx, const tmx_proof_rec* proof, const tmx_validator_rec* target /*[n_max]*/,
+                         const tmx_hashfield_rec* trusted /*[n_max]*/, uint64_t* out_elems, uint64_t cap_elems,
+                         tmx_report* report);
+int32_t tmx_step_witness(tmx_ctx* ctx, const tmx_proof_rec* proof, const tmx_validator_rec* target /*[n_max]*/,
+                         uint64_t* out_elems, uint64_t cap_elems, tmx_report* report);
+/* n_proofs independent proofs; rows of tmx_elem_stride() elements; out_elems may be NULL (reports only) */
+int32_t tmx_witness_batch(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const tmx_proof_rec* proofs,
+                          const tmx_validator_rec* targets /*[n_proofs][n_max]*/,
+                          const tmx_hashfield_rec* trusteds /*[n_proofs][n_max], NULL for step*/, uint64_t* out_elems,
+                          uint64_t cap_elems, tmx_report* reports);
+
+/* ---- device-resident entry point: inputs already in HBM, outputs stay in HBM.  All pointers are device
+ * pointers of the context's device; `hip_stream` is a hipStream_t (NULL = the context's own stream).  Asynchronous:
+ * returns after enqueueing; order against it with the stream. */
+int32_t tmx_witness_batch_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
+                                 const void* d_trusteds, void* d_out_elems, void* d_reports, void* hip_stream);
+/* HIP-event times (ms) of the kernels of the LAST tmx_witness_batch_device / host call; blocks until they finished */
+int32_t tmx_last_kernel_ms(tmx_ctx* ctx, float ms[TMX_N_KERNELS]);
+int32_t tmx_sync(tmx_ctx* ctx);
+
+/* ---- per-lane Level-1 EdDSA values only (unit-test / profiling hook of the dominant kernel).
+ * d_out: 448 B per lane = digest[64] | h[32] | A.x A.y R.x R.y sB.x sB.y hA.x hA.y sum.x sum.y [10][32] | ok u32 |
+ * decode_ok u32 | pad.  Host variant copies in/out. */
+int32_t tmx_eddsa_lanes(tmx_ctx* ctx, uint32_t n_lanes, const tmx_validator_rec* lanes, uint8_t* out /*[n_lanes][448]*/);
+
+/* ---- input codec: the reference's on-disk fixture / CometBFT RPC JSON -> packed records
+ * (InputDataFetcher fixture mode, reference circuits/input/mod.rs:188-282; conversion.rs:59-178;
+ *  tendermint_utils.rs:374-441).  Pure host code, no hashing: the trusted header hash is NOT computed here. */
+int32_t tmx_skip_inputs_from_json(const char* trusted_commit_json, const char* trusted_validators_json,
+                                  const char* target_commit_json, const char* target_validators_json, uint32_t n_max,
+                                  uint64_t trusted_block, const uint8_t trusted_header_hash[32], uint64_t target_block,
+                                  tmx_proof_rec* proof, tmx_validator_rec* target, tmx_hashfield_rec* trusted);
+int32_t tmx_step_inputs_from_json(const char* prev_commit_json, const char* next_commit_json, const char* next_validators_json,
+                                  uint32_t n_max, uint64_t prev_block, const uint8_t prev_header_hash[32],
+                                  tmx_proof_rec* proof, tmx_validator_rec* target);
+
+/* ---- public I/O packing: abi.encodePacked(uint64,bytes32,uint64) / (uint64,bytes32)
+ * (reference contracts/src/TendermintX.sol:104-108, circuits/skip.rs:120-122, circuits/step.rs:107-108) */
+void tmx_pack_skip_input(uint64_t trusted_block, const uint8_t trusted_header_hash[32], uint64_t target_block, uint8_t out[48]);
+void tmx_unpack_skip_input(const uint8_t in[48], uint64_t* trusted_block, uint8_t trusted_header_hash[32], uint64_t* target_block);
+void tmx_pack_step_input(uint64_t prev_block, const uint8_t prev_header_hash[32], uint8_t out[40]);
+void tmx_unpack_step_input(const uint8_t in[40], uint64_t* prev_block, uint8_t prev_header_hash[32]);
+
+/* ---- synthetic workload generator (bench / tests; not part of the reference): fills device buffers with
+ * n_proofs well-formed skip (or step) inputs whose signatures are produced on the GPU (RFC 8032 signing).
+ * nb_validators real validators per set (<= n_max); signed_permille of them sign; round_ is the commit round. */
+int32_t tmx_synth_batch_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, uint64_t seed, uint32_t nb_validators,
+                               uint32_t signed_permille, uint64_t round_, void* d_proofs, void* d_targets, void* d_trusteds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -39,26 +39,38 @@ static void fe_sub(fe o, const fe a, const fe b) {
 }
 static void fe_neg(fe o, const fe a) { fe z; fe_set(z, 0); fe_sub(o, z, a); }
 
-static void fe_mul(fe o, const fe a, const fe b) {
-  u128 t[5];
-  uint64_t b19[5];
-  for (int i = 0; i < 5; i++) b19[i] = 19 * b[i];
-  for (int k = 0; k < 5; k++) {
-    u128 acc = 0;
-    for (int i = 0; i < 5; i++) {
-      int j = k - i;
-      acc += (j >= 0) ? (u128)a[i] * b[j] : (u128)a[i] * b19[j + 5];
-    }
-    t[k] = acc;
-  }
-  uint64_t r[5];
-  u128 c = 0;
-  for (int k = 0; k < 5; k++) { t[k] += c; r[k] = (uint64_t)t[k] & M51; c = t[k] >> 51; }
-  r[0] += 19 * (uint64_t)c;
-  fe_copy(o, r);
-  fe_carry(o);
+static void fe_reduce_wide(fe o, u128 t0, u128 t1, u128 t2, u128 t3, u128 t4) {
+  uint64_t r0, r1, r2, r3, r4, c;
+  t1 += (uint64_t)(t0 >> 51); r0 = (uint64_t)t0 & M51;
+  t2 += (uint64_t)(t1 >> 51); r1 = (uint64_t)t1 & M51;
+  t3 += (uint64_t)(t2 >> 51); r2 = (uint64_t)t2 & M51;
+  t4 += (uint64_t)(t3 >> 51); r3 = (uint64_t)t3 & M51;
+  c = (uint64_t)(t4 >> 51); r4 = (uint64_t)t4 & M51;
+  r0 += 19 * c; c = r0 >> 51; r0 &= M51; r1 += c;
+  c = r1 >> 51; r1 &= M51; r2 += c;
+  o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3; o[4] = r4;
 }
-static void fe_sq(fe o, const fe a) { fe_mul(o, a, a); }
+static void fe_mul(fe o, const fe a, const fe b) {
+  uint64_t a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4];
+  uint64_t b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4];
+  uint64_t b1_19 = 19 * b1, b2_19 = 19 * b2, b3_19 = 19 * b3, b4_19 = 19 * b4;
+  u128 t0 = (u128)a0 * b0 + (u128)a1 * b4_19 + (u128)a2 * b3_19 + (u128)a3 * b2_19 + (u128)a4 * b1_19;
+  u128 t1 = (u128)a0 * b1 + (u128)a1 * b0 + (u128)a2 * b4_19 + (u128)a3 * b3_19 + (u128)a4 * b2_19;
+  u128 t2 = (u128)a0 * b2 + (u128)a1 * b1 + (u128)a2 * b0 + (u128)a3 * b4_19 + (u128)a4 * b3_19;
+  u128 t3 = (u128)a0 * b3 + (u128)a1 * b2 + (u128)a2 * b1 + (u128)a3 * b0 + (u128)a4 * b4_19;
+  u128 t4 = (u128)a0 * b4 + (u128)a1 * b3 + (u128)a2 * b2 + (u128)a3 * b1 + (u128)a4 * b0;
+  fe_reduce_wide(o, t0, t1, t2, t3, t4);
+}
+static void fe_sq(fe o, const fe a) {
+  uint64_t a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4];
+  uint64_t d0 = 2 * a0, d1 = 2 * a1, d2 = 2 * a2, a3_19 = 19 * a3, a4_19 = 19 * a4;
+  u128 t0 = (u128)a0 * a0 + (u128)d1 * a4_19 + (u128)d2 * a3_19;
+  u128 t1 = (u128)d0 * a1 + (u128)d2 * a4_19 + (u128)a3 * a3_19;
+  u128 t2 = (u128)d0 * a2 + (u128)a1 * a1 + (u128)(2 * a3) * a4_19;
+  u128 t3 = (u128)d0 * a3 + (u128)d1 * a2 + (u128)a4 * a4_19;
+  u128 t4 = (u128)d0 * a4 + (u128)d1 * a3 + (u128)a2 * a2;
+  fe_reduce_wide(o, t0, t1, t2, t3, t4);
+}
 static void fe_sqn(fe o, const fe a, int n) { fe_sq(o, a); for (int i = 1; i < n; i++) fe_sq(o, o); }
 
 static void fe_frombytes(fe o, const uint8_t s[32]) {
@@ -214,6 +226,19 @@ static void ge_affine_bytes(const ge* p, uint8_t x[32], uint8_t y[32]) {
   fe_mul(t, p->X, zi); fe_tobytes(x, t);
   fe_mul(t, p->Y, zi); fe_tobytes(y, t);
 }
+/* affine bytes of k points with one inversion (Montgomery's trick) */
+static void ge_affine_bytes_batch(const ge* const* ps, int k, uint8_t (*xy)[32]) {
+  fe pre[8], inv, t;
+  fe_copy(pre[0], ps[0]->Z);
+  for (int i = 1; i < k; i++) fe_mul(pre[i], pre[i - 1], ps[i]->Z);
+  fe_invert(inv, pre[k - 1]);
+  for (int i = k - 1; i >= 0; i--) {
+    fe zi;
+    if (i) { fe_mul(zi, inv, pre[i - 1]); fe_mul(inv, inv, ps[i]->Z); } else fe_copy(zi, inv);
+    fe_mul(t, ps[i]->X, zi); fe_tobytes(xy[2 * i], t);
+    fe_mul(t, ps[i]->Y, zi); fe_tobytes(xy[2 * i + 1], t);
+  }
+}
 
 /* ---------------------------------------------------------------- scalars mod l */
 static const uint64_t L64[4] = {0x5812631a5cf5d3edULL, 0x14def9dea2f79cd6ULL, 0, 0x1000000000000000ULL};
@@ -284,11 +309,8 @@ void tmxo_eddsa_trace_lane(const uint8_t pk[32], const uint8_t sig[64], const ui
   ge_scalarmult_base(&sB, sig + 32);
   ge_scalarmult(&hA, out->h, &A);
   ge_add(&sum, &R, &hA);
-  ge_affine_bytes(&A, out->pt[0], out->pt[1]);
-  ge_affine_bytes(&R, out->pt[2], out->pt[3]);
-  ge_affine_bytes(&sB, out->pt[4], out->pt[5]);
-  ge_affine_bytes(&hA, out->pt[6], out->pt[7]);
-  ge_affine_bytes(&sum, out->pt[8], out->pt[9]);
+  const ge* ps[5] = {&A, &R, &sB, &hA, &sum};
+  ge_affine_bytes_batch(ps, 5, out->pt);
   out->ok = (memcmp(out->pt[4], out->pt[8], 64) == 0) && sc_is_canonical(sig + 32);
 }
 

@@ -1,0 +1,153 @@
+"""ctypes binding of libtmx.so (include/tmx.h).  Fails loudly when the library or a HIP runtime is missing:
+there is no CPU fallback in this package."""
+import ctypes as C
+import ctypes.util
+import importlib.util
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtmx.so")
+
+KIND_SKIP, KIND_STEP = 0, 1
+FLAG_SIGNED, FLAG_PRESENT = 1, 2
+N_KERNELS = 3
+KERNEL_NAMES = ("k_eddsa", "k_proof", "k_serialize")
+ED_STRIDE = 448
+
+
+class ValidatorRec(C.Structure):
+    _fields_ = [("pubkey", C.c_uint8 * 32), ("signature", C.c_uint8 * 64), ("message", C.c_uint8 * 124),
+                ("message_byte_length", C.c_uint16), ("validator_byte_length", C.c_uint8), ("flags", C.c_uint8),
+                ("voting_power", C.c_uint64), ("pad", C.c_uint8 * 24)]
+
+
+class HashFieldRec(C.Structure):
+    _fields_ = [("pubkey", C.c_uint8 * 32), ("voting_power", C.c_uint64), ("validator_byte_length", C.c_uint8),
+                ("flags", C.c_uint8), ("pad", C.c_uint8 * 6)]
+
+
+class HeaderRec(C.Structure):
+    _fields_ = [("leaf_len", C.c_uint8 * 14), ("pad", C.c_uint8 * 2), ("leaf", (C.c_uint8 * 80) * 14)]
+
+
+class ProofRec(C.Structure):
+    _fields_ = [("block_a", C.c_uint64), ("block_b", C.c_uint64), ("hash", C.c_uint8 * 32), ("round", C.c_uint64),
+                ("nb_a", C.c_uint32), ("nb_b", C.c_uint32), ("header_a", HeaderRec), ("header_b", HeaderRec)]
+
+
+class Report(C.Structure):
+    _fields_ = [("header", C.c_uint8 * 32), ("all_ok", C.c_uint32), ("fail_mask", C.c_uint32),
+                ("first_bad_sig", C.c_int32), ("gt_target", C.c_uint32), ("gt_trusted", C.c_uint32),
+                ("dist_ok", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+
+    def as_dict(self):
+        return dict(header=bytes(self.header), all_ok=bool(self.all_ok), fail_mask=self.fail_mask,
+                    first_bad_sig=self.first_bad_sig, gt_target=bool(self.gt_target),
+                    gt_trusted=bool(self.gt_trusted), dist_ok=bool(self.dist_ok))
+
+
+class Config(C.Structure):
+    _fields_ = [("n_max", C.c_uint32), ("chain_id_len", C.c_uint32), ("chain_id", C.c_uint8 * 52),
+                ("skip_max", C.c_uint64), ("device", C.c_int32), ("max_batch", C.c_uint32)]
+
+
+assert C.sizeof(ValidatorRec) == 256 and C.sizeof(HashFieldRec) == 48 and C.sizeof(ProofRec) == 2336
+assert C.sizeof(Report) == 64
+
+_lib = None
+_hip = None
+
+
+class TmxError(RuntimeError):
+    def __init__(self, status, msg=""):
+        self.status = status
+        super().__init__(f"libtmx status {status}: {msg}")
+
+
+def _hip_runtime_candidates():
+    # One HIP runtime per process: if PyTorch is (or will be) in this process, libtmx must run on PyTorch's bundled
+    # libamdhip64 so that device pointers, streams and events are shared.
+    cands = []
+    spec = importlib.util.find_spec("torch") if "torch" in sys.modules or os.environ.get("TMX_HIP_FROM_TORCH", "1") == "1" else None
+    if spec and spec.origin:
+        cands.append(os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so"))
+    cands.append("/opt/rocm/lib/libamdhip64.so")
+    found = ctypes.util.find_library("amdhip64")
+    if found:
+        cands.append(found)
+    return cands
+
+
+def load_hip_runtime():
+    global _hip
+    if _hip is not None:
+        return _hip
+    errors = []
+    for path in _hip_runtime_candidates():
+        if os.path.sep in path and not os.path.exists(path):
+            continue
+        try:
+            _hip = C.CDLL(path, mode=C.RTLD_GLOBAL)
+            return _hip
+        except OSError as e:  # keep looking, report all at the end
+            errors.append(f"{path}: {e}")
+    raise ImportError("tendermintx_amd needs a HIP runtime (libamdhip64.so); tried: " + "; ".join(errors or ["<none found>"]))
+
+
+def lib():
+    """The loaded libtmx.so.  Raises ImportError (never falls back to a CPU path) if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(make -C tendermintx_amd/csrc); tendermintx_amd has no CPU fallback")
+    load_hip_runtime()
+    L = C.CDLL(LIB_PATH)
+    L.tmx_version.restype = C.c_uint32
+    L.tmx_status_str.restype = C.c_char_p
+    L.tmx_status_str.argtypes = [C.c_int32]
+    L.tmx_last_error.restype = C.c_char_p
+    L.tmx_last_error.argtypes = [C.c_void_p]
+    L.tmx_ctx_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    L.tmx_ctx_destroy.argtypes = [C.c_void_p]
+    L.tmx_ctx_destroy.restype = None
+    for f in (L.tmx_elem_count, L.tmx_elem_stride, L.tmx_hint_elem_count):
+        f.restype = C.c_uint64
+        f.argtypes = [C.c_int32, C.c_uint32]
+    L.tmx_witness_batch.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_uint64, C.c_void_p]
+    L.tmx_witness_batch_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tmx_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.tmx_sync.argtypes = [C.c_void_p]
+    L.tmx_eddsa_lanes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.tmx_skip_inputs_from_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64,
+                                            C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tmx_step_inputs_from_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64, C.c_char_p,
+                                            C.c_void_p, C.c_void_p]
+    L.tmx_pack_skip_input.argtypes = [C.c_uint64, C.c_char_p, C.c_uint64, C.c_char_p]
+    L.tmx_pack_skip_input.restype = None
+    L.tmx_unpack_skip_input.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.c_char_p, C.POINTER(C.c_uint64)]
+    L.tmx_unpack_skip_input.restype = None
+    L.tmx_pack_step_input.argtypes = [C.c_uint64, C.c_char_p, C.c_char_p]
+    L.tmx_pack_step_input.restype = None
+    L.tmx_unpack_step_input.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.c_char_p]
+    L.tmx_unpack_step_input.restype = None
+    if hasattr(L, "tmx_synth_batch_device"):
+        L.tmx_synth_batch_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
+                                             C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib = L
+    return L
+
+
+def check(status, ctx=None):
+    if status != 0:
+        L = lib()
+        msg = L.tmx_status_str(status).decode()
+        if ctx:
+            detail = L.tmx_last_error(ctx).decode()
+            if detail:
+                msg += " -- " + detail
+        raise TmxError(status, msg)

@@ -1,0 +1,98 @@
+"""Context + array-level entry points over the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KIND_SKIP, KIND_STEP, Config, Report, check
+
+
+class Context:
+    """One tmx_ctx: a HIP stream, device scratch for `max_batch` proofs and the serializer programs for a fixed
+    (VALIDATOR_SET_SIZE_MAX, chain id, SKIP_MAX) -- the const generics / TendermintConfig of the reference's
+    SkipCircuit<N, CHAIN_ID_SIZE_BYTES, C> (reference circuits/skip.rs:104-111, circuits/config.rs:3-8)."""
+
+    def __init__(self, n_max, chain_id=b"celestia", skip_max=100800, device=0, max_batch=1):
+        self._L = _lib.lib()
+        self.n_max, self.chain_id, self.skip_max, self.max_batch = int(n_max), bytes(chain_id), int(skip_max), int(max_batch)
+        cfg = Config()
+        cfg.n_max = self.n_max
+        cfg.chain_id_len = len(self.chain_id)
+        for i, b in enumerate(self.chain_id[:52]):
+            cfg.chain_id[i] = b
+        cfg.skip_max = self.skip_max
+        cfg.device = device
+        cfg.max_batch = self.max_batch
+        h = C.c_void_p()
+        st = self._L.tmx_ctx_create(C.byref(cfg), C.byref(h))
+        self._h = h
+        if st != 0:
+            try:
+                check(st, h if h else None)
+            finally:
+                if h:
+                    self._L.tmx_ctx_destroy(h)
+                    self._h = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tmx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def elem_count(self, kind):
+        return int(self._L.tmx_elem_count(kind, self.n_max))
+
+    def elem_stride(self, kind):
+        return int(self._L.tmx_elem_stride(kind, self.n_max))
+
+    def hint_elem_count(self, kind):
+        return int(self._L.tmx_hint_elem_count(kind, self.n_max))
+
+    # ---- host-buffer path
+    def witness_batch(self, kind, proofs, targets, trusteds=None, want_elems=True):
+        """proofs: bytes (n x 2336); targets: bytes (n x n_max x 256); trusteds: bytes (n x n_max x 48) for skip.
+        Returns (np.uint64 [n, elem_count] or None, [report dict])."""
+        n = len(proofs) // 2336
+        assert len(proofs) == n * 2336 and len(targets) == n * self.n_max * 256
+        if kind == KIND_SKIP:
+            assert trusteds is not None and len(trusteds) == n * self.n_max * 48
+        count, stride = self.elem_count(kind), self.elem_stride(kind)
+        out = np.zeros(n * stride, dtype=np.uint64) if want_elems else None
+        reps = (Report * n)()
+        st = self._L.tmx_witness_batch(self._h, kind, n, bytes(proofs), bytes(targets), bytes(trusteds) if trusteds else None,
+                                       out.ctypes.data if want_elems else None, out.size if want_elems else 0, reps)
+        check(st, self._h)
+        elems = out.reshape(n, stride)[:, :count] if want_elems else None
+        return elems, [r.as_dict() for r in reps]
+
+    def eddsa_lanes(self, lanes):
+        n = len(lanes) // 256
+        out = np.zeros(n * _lib.ED_STRIDE, dtype=np.uint8)
+        check(self._L.tmx_eddsa_lanes(self._h, n, bytes(lanes), out.ctypes.data), self._h)
+        return out.reshape(n, _lib.ED_STRIDE)
+
+    # ---- device-resident path (raw device pointers, e.g. torch tensors' data_ptr())
+    def witness_batch_device(self, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports, stream=None):
+        check(self._L.tmx_witness_batch_device(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports, stream),
+              self._h)
+
+    def synth_batch_device(self, kind, n_proofs, seed, nb_validators, signed_permille, round_, d_proofs, d_targets, d_trusteds):
+        check(self._L.tmx_synth_batch_device(self._h, kind, n_proofs, seed, nb_validators, signed_permille, round_, d_proofs,
+                                             d_targets, d_trusteds), self._h)
+
+    def last_kernel_ms(self):
+        ms = (C.c_float * _lib.N_KERNELS)()
+        check(self._L.tmx_last_kernel_ms(self._h, ms), self._h)
+        return dict(zip(_lib.KERNEL_NAMES, (float(x) for x in ms)))
+
+    def sync(self):
+        check(self._L.tmx_sync(self._h), self._h)

@@ -1,0 +1,429 @@
+// libtmx C ABI (include/tmx.h): context, device scratch, serializer program, launch sequence.
+//
+// Host side of the drop-in boundary: what SkipOffchainInputs::hint / StepOffchainInputs::hint
+// (reference circuits/skip.rs:64-102, circuits/step.rs:56-89) do after the RPC/fixture fetch, expressed as
+//   records -> [k_eddsa] -> [k_proof] -> [k_serialize] -> Goldilocks elements (+ tmx_report)
+// on one HIP stream.  No CPU compute path exists here: without a usable HIP device every call fails.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "tmx.h"
+
+using namespace tmx;
+
+static_assert(sizeof(tmx_validator_rec) == VR_STRIDE, "validator record layout");
+static_assert(sizeof(tmx_hashfield_rec) == HR_STRIDE, "hash-field record layout");
+static_assert(sizeof(tmx_header_rec) == HDR_SIZE, "header record layout");
+static_assert(sizeof(tmx_proof_rec) == PR_STRIDE, "proof record layout");
+static_assert(sizeof(tmx_report) == 64, "report layout");
+static_assert(offsetof(tmx_validator_rec, message_byte_length) == VR_OFF_MLEN, "mlen offset");
+static_assert(offsetof(tmx_validator_rec, voting_power) == VR_OFF_POWER, "power offset");
+static_assert(offsetof(tmx_hashfield_rec, validator_byte_length) == HR_OFF_VLEN, "vlen offset");
+static_assert(offsetof(tmx_proof_rec, header_b) == PR_OFF_HDR_B, "header_b offset");
+static_assert(TMX_N_MAX_LIMIT == TMX_N_LIMIT, "n_max limit");
+
+// ------------------------------------------------------------------------------------------------ element layout
+// Declarative description of the witness row: hint section H in the field order of VerifySkipVariable<N> /
+// VerifyStepVariable<N> (reference circuits/variables.rs:91-120) with the element widths of the plonky2x
+// variable types (ByteVariable = 8 big-endian bits, U32/Variable/Bool = 1, U64 = 2 LE limbs, U256 = 8 LE limbs),
+// followed by the derived section D (DESIGN.md "Witness layout").
+namespace {
+
+struct LutBuilder {
+  std::vector<uint32_t> v;
+  void bytes(uint32_t src, uint32_t off, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++)
+      for (uint32_t k = 0; k < 8; k++) v.push_back(lut_entry(src, CODE_BIT0 + k, off + i));
+  }
+  void u8(uint32_t src, uint32_t off) { v.push_back(lut_entry(src, CODE_U8, off)); }
+  void u16(uint32_t src, uint32_t off) { v.push_back(lut_entry(src, CODE_U16, off)); }
+  void u32(uint32_t src, uint32_t off) { v.push_back(lut_entry(src, CODE_U32, off)); }
+  void u64(uint32_t src, uint32_t off) { u32(src, off); u32(src, off + 4); }
+  void u256(uint32_t src, uint32_t off) { for (uint32_t k = 0; k < 8; k++) u32(src, off + 4 * k); }
+  void flag0(uint32_t src, uint32_t off) { v.push_back(lut_entry(src, CODE_FLAG0, off)); }
+};
+
+uint32_t tree_nodes(uint32_t n) {
+  uint32_t c = 0;
+  while (n > 1) { n = (n + 1) / 2; c += n; }
+  return c;
+}
+
+// MerkleInclusionProofVariable<4, LEAF>: proof[4] (Bytes32 each) then leaf bytes  (variables.rs:58-62)
+void emit_inclusion_proof(LutBuilder& L, int q, uint32_t leaf_src_off, uint32_t leaf_size) {
+  L.bytes(SRC_PF, PF_OFF_AUNTS + 128 * q, 128);
+  L.bytes(SRC_PF, leaf_src_off, leaf_size);
+}
+// derived: leaf hash + the four path nodes of proof q
+void emit_proof_d(LutBuilder& L, int q) { L.bytes(SRC_PF, PF_OFF_PROOFD + 160 * q, 160); }
+
+struct Program {
+  SerializeProgram sp;
+  std::vector<uint32_t> lut;
+  uint32_t hint_elems;
+};
+
+Program build_program(int kind, uint32_t n) {
+  Program P;
+  std::memset(&P.sp, 0, sizeof P.sp);
+  LutBuilder L;
+  const bool skip = kind == TMX_KIND_SKIP;
+  const uint32_t tn = tree_nodes(n);
+  uint32_t elem = 0;
+  auto add_section = [&](uint32_t lane_elems, uint32_t n_lanes, uint32_t lut_off, uint32_t kind_) {
+    Section& s = P.sp.sec[P.sp.n_sections++];
+    s.elem_start = elem; s.lane_elems = lane_elems; s.n_lanes = n_lanes; s.lut_off = lut_off; s.kind = kind_;
+    elem += lane_elems * n_lanes;
+  };
+  uint32_t mark;
+
+  // H.1 target_header / next_header : Bytes32
+  mark = (uint32_t)L.v.size();
+  L.bytes(SRC_PF, PF_OFF_HEADER, 32);
+  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT);
+
+  // H.2 validators[N] : ValidatorVariable (variables.rs:69-79) = pubkey, signature{r, s}, message[124],
+  //     message_byte_length, voting_power, validator_byte_length, signed
+  mark = (uint32_t)L.v.size();
+  L.bytes(SRC_TARGET, VR_OFF_PK, 32);
+  L.bytes(SRC_TARGET, VR_OFF_SIG, 32);
+  L.u256(SRC_TARGET, VR_OFF_SIG + 32);
+  L.bytes(SRC_TARGET, VR_OFF_MSG, 124);
+  L.u16(SRC_TARGET, VR_OFF_MLEN);
+  L.u64(SRC_TARGET, VR_OFF_POWER);
+  L.u8(SRC_TARGET, VR_OFF_VLEN);
+  L.flag0(SRC_TARGET, VR_OFF_FLAGS);
+  add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT);
+
+  // H.3 nb_validators, round, ChainIdProofVariable, HeightProofVariable, validators-hash proof, then
+  //     skip: trusted nb + trusted validators-hash proof ; step: last_block_id proof + prev next_validators_hash proof
+  mark = (uint32_t)L.v.size();
+  L.u32(SRC_PROOF, PR_OFF_NB_A);
+  L.u64(SRC_PROOF, PR_OFF_ROUND);
+  L.bytes(SRC_PF, PF_OFF_AUNTS + 128 * 0, 128);   // chain_id_proof.proof
+  L.u32(SRC_PF, PF_OFF_CIDLEN);                   // enc_chain_id_byte_length
+  L.bytes(SRC_PF, PF_OFF_CID52, 52);              // chain_id
+  L.bytes(SRC_PF, PF_OFF_AUNTS + 128 * 1, 128);   // height_proof.proof
+  L.u32(SRC_PF, PF_OFF_HLEN);                     // enc_height_byte_length
+  L.u64(SRC_PF, PF_OFF_HEIGHT);                   // height
+  emit_inclusion_proof(L, 2, PF_OFF_LEAFV, 34);
+  if (skip) {
+    L.u32(SRC_PROOF, PR_OFF_NB_B);
+    emit_inclusion_proof(L, 3, PF_OFF_LEAFX, 34);
+  } else {
+    emit_inclusion_proof(L, 3, PF_OFF_LEAFX, 72);
+    emit_inclusion_proof(L, 4, PF_OFF_LEAFY, 34);
+  }
+  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT);
+
+  // H.4 skip: trusted_header_validator_hash_fields[N] : ValidatorHashFieldVariable (variables.rs:82-88)
+  if (skip) {
+    mark = (uint32_t)L.v.size();
+    L.bytes(SRC_TRUSTED, HR_OFF_PK, 32);
+    L.u64(SRC_TRUSTED, HR_OFF_POWER);
+    L.u8(SRC_TRUSTED, HR_OFF_VLEN);
+    add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT);
+  }
+  P.hint_elems = elem;
+
+  // D.1 per target lane
+  mark = (uint32_t)L.v.size();
+  L.bytes(SRC_LT, LN_OFF_MARSHAL, 46);
+  L.bytes(SRC_LT, LN_OFF_LEAF, 32);
+  L.bytes(SRC_ED, ED_OFF_DIGEST, 64);
+  L.u256(SRC_ED, ED_OFF_H);
+  for (int p = 0; p < 10; p++) L.u256(SRC_ED, ED_OFF_PTS + 32 * p);
+  L.u32(SRC_ED, ED_OFF_OK);
+  for (int f = 0; f < 6; f++) L.u8(SRC_LT, LN_OFF_FLAGS + f);
+  L.u64(SRC_LT, LN_OFF_TOT);
+  L.u64(SRC_LT, LN_OFF_ACC);
+  add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT);
+
+  // D.2 per trusted lane
+  if (skip) {
+    mark = (uint32_t)L.v.size();
+    L.bytes(SRC_LR, LN_OFF_MARSHAL, 46);
+    L.bytes(SRC_LR, LN_OFF_LEAF, 32);
+    L.u8(SRC_LR, LN_OFF_FLAGS);
+    L.u8(SRC_LR, LN_OFF_FLAGS + 1);
+    L.u64(SRC_LR, LN_OFF_TOT);
+    L.u64(SRC_LR, LN_OFF_ACC);
+    add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT);
+  }
+  // D.3 / D.4 tree nodes
+  if (tn) {
+    add_section(tn * 256, 1, 0, SEC_LINEAR_T);
+    if (skip) add_section(tn * 256, 1, 0, SEC_LINEAR_R);
+  }
+  // D.5 header proofs, tallies, checks, verdict
+  mark = (uint32_t)L.v.size();
+  emit_proof_d(L, 0);
+  L.bytes(SRC_PF, PF_OFF_HLEAF, 11);
+  emit_proof_d(L, 1);
+  emit_proof_d(L, 2);
+  emit_proof_d(L, 3);
+  if (!skip) emit_proof_d(L, 4);
+  for (int k = 0; k < 4; k++) L.u64(SRC_PF, PF_OFF_TALLY_T + 8 * k);
+  L.u32(SRC_PF, PF_OFF_VERDICTS);
+  if (skip) {
+    for (int k = 0; k < 4; k++) L.u64(SRC_PF, PF_OFF_TALLY_R + 8 * k);
+    L.u32(SRC_PF, PF_OFF_VERDICTS + 4);
+    L.u32(SRC_PF, PF_OFF_VERDICTS + 8);
+    L.u32(SRC_PF, PF_OFF_VERDICTS + 12);
+  }
+  const int n_checks = skip ? 12 : 14;
+  for (int k = 0; k < n_checks; k++) L.u32(SRC_PF, PF_OFF_CHECKS + 4 * k);
+  L.u32(SRC_PF, PF_OFF_ALLOK);
+  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT);
+
+  P.sp.elem_count = elem;
+  P.sp.elem_stride = (elem + 1) & ~1u;
+  P.sp.n = n;
+  P.sp.tree_nodes = tn;
+  P.lut = std::move(L.v);
+  return P;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ context
+struct tmx_ctx {
+  tmx_config cfg;
+  std::string err;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[TMX_N_KERNELS + 1] = {};
+  bool ev_valid = false;
+  Program prog[2];
+  void* d_lut[2] = {nullptr, nullptr};
+  void* d_table = nullptr;
+  // scratch sized for cfg.max_batch proofs
+  void *d_ed = nullptr, *d_lt = nullptr, *d_lr = nullptr, *d_pf = nullptr, *d_nodes_t = nullptr, *d_nodes_r = nullptr, *d_reports = nullptr;
+  // staging for the host-buffer entry points
+  void *d_in_proofs = nullptr, *d_in_targets = nullptr, *d_in_trusteds = nullptr, *d_out = nullptr;
+  uint64_t d_out_elems = 0;
+};
+
+static int32_t fail(tmx_ctx* c, int32_t st, const std::string& msg) {
+  if (c) c->err = msg;
+  return st;
+}
+#define HIPCK(c, call)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e_ = (call);                                                                               \
+    if (e_ != hipSuccess) return fail(c, TMX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" {
+
+uint32_t tmx_version(void) { return 0x000100; }
+
+const char* tmx_status_str(int32_t s) {
+  switch (s) {
+    case TMX_OK: return "ok";
+    case TMX_ERR_BAD_ARG: return "bad argument";
+    case TMX_ERR_SET_TOO_LARGE: return "validator set larger than VALIDATOR_SET_SIZE_MAX";
+    case TMX_ERR_HIP: return "HIP error (no usable MI355X device?)";
+    case TMX_ERR_CAPACITY: return "capacity too small";
+    case TMX_ERR_PARSE: return "malformed JSON";
+    case TMX_ERR_MSG_TOO_LONG: return "sign-bytes longer than 124 bytes";
+    default: return "unknown";
+  }
+}
+
+uint64_t tmx_elem_count(int32_t kind, uint32_t n) {
+  if ((kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP) || n == 0 || n > TMX_N_MAX_LIMIT) return 0;
+  const uint64_t tn = tree_nodes(n);
+  if (kind == TMX_KIND_SKIP) return 1776ull * n + 5320 + 1235ull * n + 630ull * n + 2 * tn * 256 + (4 * 1280 + 88) + 33;
+  return 1517ull * n + 6919 + 1235ull * n + tn * 256 + (5 * 1280 + 88) + 24;
+}
+uint64_t tmx_elem_stride(int32_t kind, uint32_t n) { return (tmx_elem_count(kind, n) + 1) & ~1ull; }
+uint64_t tmx_hint_elem_count(int32_t kind, uint32_t n) {
+  if (n == 0 || n > TMX_N_MAX_LIMIT) return 0;
+  return kind == TMX_KIND_SKIP ? 1776ull * n + 5320 : 1517ull * n + 6919;
+}
+
+const char* tmx_last_error(const tmx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+void tmx_ctx_destroy(tmx_ctx* c) {
+  if (!c) return;
+  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_table, c->d_ed, c->d_lt, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
+                  c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  for (auto& e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
+  if (!cfg || !out) return TMX_ERR_BAD_ARG;
+  *out = nullptr;
+  if (cfg->n_max == 0 || cfg->n_max > TMX_N_MAX_LIMIT || cfg->chain_id_len > 50 || cfg->max_batch == 0) return TMX_ERR_BAD_ARG;
+  tmx_ctx* c = new tmx_ctx();
+  c->cfg = *cfg;
+  *out = c;  // returned even on HIP failure so that tmx_last_error is readable; caller destroys it
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return fail(c, TMX_ERR_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(c, TMX_ERR_BAD_ARG, "device ordinal out of range");
+  HIPCK(c, hipSetDevice(cfg->device));
+  HIPCK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (auto& ev : c->ev) HIPCK(c, hipEventCreate(&ev));
+  const uint32_t n = cfg->n_max;
+  const size_t B = cfg->max_batch, lanes = B * n;
+  for (int k = 0; k < 2; k++) {
+    c->prog[k] = build_program(k, n);
+    if (c->prog[k].sp.elem_count != tmx_elem_count(k, n)) return fail(c, TMX_ERR_BAD_ARG, "internal: layout size mismatch");
+    HIPCK(c, hipMalloc(&c->d_lut[k], c->prog[k].lut.size() * 4));
+    HIPCK(c, hipMemcpyAsync(c->d_lut[k], c->prog[k].lut.data(), c->prog[k].lut.size() * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCK(c, hipMalloc(&c->d_table, base_table_bytes()));
+  HIPCK(c, hipMalloc(&c->d_ed, lanes * ED_STRIDE));
+  HIPCK(c, hipMalloc(&c->d_lt, lanes * LANE_STRIDE));
+  HIPCK(c, hipMalloc(&c->d_lr, lanes * LANE_STRIDE));
+  HIPCK(c, hipMalloc(&c->d_pf, B * PF_STRIDE));
+  const size_t tn = tree_nodes(n);
+  HIPCK(c, hipMalloc(&c->d_nodes_t, B * (tn + 1) * 32));
+  HIPCK(c, hipMalloc(&c->d_nodes_r, B * (tn + 1) * 32));
+  HIPCK(c, hipMalloc(&c->d_reports, B * sizeof(tmx_report)));
+  int rc = launch_init_base(c->d_table, c->stream);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_init_base launch: ") + hipGetErrorString((hipError_t)rc));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  return TMX_OK;
+}
+
+int32_t tmx_sync(tmx_ctx* c) {
+  if (!c) return TMX_ERR_BAD_ARG;
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  return TMX_OK;
+}
+
+int32_t tmx_witness_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
+                                 const void* d_trusteds, void* d_out_elems, void* d_reports, void* hip_stream) {
+  if (!c || (kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP) || !d_proofs || !d_targets) return TMX_ERR_BAD_ARG;
+  if (kind == TMX_KIND_SKIP && !d_trusteds) return fail(c, TMX_ERR_BAD_ARG, "skip needs the trusted hash fields");
+  if (n_proofs > c->cfg.max_batch) return fail(c, TMX_ERR_CAPACITY, "n_proofs exceeds the context's max_batch");
+  if (n_proofs == 0) return TMX_OK;
+  hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->stream;
+  const uint32_t n = c->cfg.n_max;
+  ProofParams P;
+  std::memset(&P, 0, sizeof P);
+  P.kind = (uint32_t)kind; P.n = n; P.tree_nodes = tree_nodes(n); P.chain_id_len = c->cfg.chain_id_len; P.skip_max = c->cfg.skip_max;
+  std::memcpy(P.chain_id, c->cfg.chain_id, sizeof P.chain_id);
+  void* reports = d_reports ? d_reports : c->d_reports;
+
+  HIPCK(c, hipEventRecord(c->ev[0], s));
+  int rc = launch_eddsa(n_proofs * n, d_targets, c->d_ed, c->d_table, s);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_eddsa launch: ") + hipGetErrorString((hipError_t)rc));
+  HIPCK(c, hipEventRecord(c->ev[1], s));
+  rc = launch_proof(P, n_proofs, d_proofs, d_targets, d_trusteds, c->d_ed, c->d_lt, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r, reports, s);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_proof launch: ") + hipGetErrorString((hipError_t)rc));
+  HIPCK(c, hipEventRecord(c->ev[2], s));
+  if (d_out_elems) {
+    SerializeSources src;
+    std::memset(&src, 0, sizeof src);
+    src.base[SRC_PROOF] = (const uint8_t*)d_proofs; src.base[SRC_TARGET] = (const uint8_t*)d_targets;
+    src.base[SRC_TRUSTED] = (const uint8_t*)d_trusteds; src.base[SRC_ED] = (const uint8_t*)c->d_ed;
+    src.base[SRC_LT] = (const uint8_t*)c->d_lt; src.base[SRC_LR] = (const uint8_t*)c->d_lr; src.base[SRC_PF] = (const uint8_t*)c->d_pf;
+    src.nodes_t = (const uint8_t*)c->d_nodes_t; src.nodes_r = (const uint8_t*)c->d_nodes_r;
+    rc = launch_serialize(c->prog[kind].sp, src, c->d_lut[kind], n_proofs, d_out_elems, s);
+    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_serialize launch: ") + hipGetErrorString((hipError_t)rc));
+  }
+  HIPCK(c, hipEventRecord(c->ev[3], s));
+  c->ev_valid = true;
+  return TMX_OK;
+}
+
+int32_t tmx_last_kernel_ms(tmx_ctx* c, float ms[TMX_N_KERNELS]) {
+  if (!c || !ms) return TMX_ERR_BAD_ARG;
+  if (!c->ev_valid) return fail(c, TMX_ERR_BAD_ARG, "no batch has been enqueued yet");
+  HIPCK(c, hipEventSynchronize(c->ev[TMX_N_KERNELS]));
+  for (int k = 0; k < TMX_N_KERNELS; k++) HIPCK(c, hipEventElapsedTime(&ms[k], c->ev[k], c->ev[k + 1]));
+  return TMX_OK;
+}
+
+static int32_t ensure_staging(tmx_ctx* c) {
+  if (c->d_in_proofs) return TMX_OK;
+  const size_t B = c->cfg.max_batch, lanes = B * c->cfg.n_max;
+  HIPCK(c, hipMalloc(&c->d_in_proofs, B * sizeof(tmx_proof_rec)));
+  HIPCK(c, hipMalloc(&c->d_in_targets, lanes * sizeof(tmx_validator_rec)));
+  HIPCK(c, hipMalloc(&c->d_in_trusteds, lanes * sizeof(tmx_hashfield_rec)));
+  uint64_t stride = tmx_elem_stride(TMX_KIND_SKIP, c->cfg.n_max), st2 = tmx_elem_stride(TMX_KIND_STEP, c->cfg.n_max);
+  c->d_out_elems = (stride > st2 ? stride : st2) * B;
+  HIPCK(c, hipMalloc(&c->d_out, c->d_out_elems * 8));
+  return TMX_OK;
+}
+
+int32_t tmx_witness_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const tmx_proof_rec* proofs, const tmx_validator_rec* targets,
+                          const tmx_hashfield_rec* trusteds, uint64_t* out_elems, uint64_t cap_elems, tmx_report* reports) {
+  if (!c || !proofs || !targets || (kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP)) return TMX_ERR_BAD_ARG;
+  if (kind == TMX_KIND_SKIP && !trusteds) return fail(c, TMX_ERR_BAD_ARG, "skip needs the trusted hash fields");
+  if (n_proofs == 0) return TMX_OK;
+  if (n_proofs > c->cfg.max_batch) return fail(c, TMX_ERR_CAPACITY, "n_proofs exceeds the context's max_batch");
+  const uint32_t n = c->cfg.n_max;
+  const uint64_t stride = tmx_elem_stride(kind, n), count = tmx_elem_count(kind, n);
+  if (out_elems && cap_elems < (uint64_t)(n_proofs - 1) * stride + count) return fail(c, TMX_ERR_CAPACITY, "out_elems too small");
+  for (uint32_t p = 0; p < n_proofs; p++)  // reference input/mod.rs:439-444, 338-342
+    if (proofs[p].nb_a > n || proofs[p].nb_b > n) return fail(c, TMX_ERR_SET_TOO_LARGE, "validator set larger than VALIDATOR_SET_SIZE_MAX");
+  int32_t st = ensure_staging(c);
+  if (st) return st;
+  const size_t lanes = (size_t)n_proofs * n;
+  HIPCK(c, hipMemcpyAsync(c->d_in_proofs, proofs, (size_t)n_proofs * sizeof(tmx_proof_rec), hipMemcpyHostToDevice, c->stream));
+  HIPCK(c, hipMemcpyAsync(c->d_in_targets, targets, lanes * sizeof(tmx_validator_rec), hipMemcpyHostToDevice, c->stream));
+  if (kind == TMX_KIND_SKIP)
+    HIPCK(c, hipMemcpyAsync(c->d_in_trusteds, trusteds, lanes * sizeof(tmx_hashfield_rec), hipMemcpyHostToDevice, c->stream));
+  st = tmx_witness_batch_device(c, kind, n_proofs, c->d_in_proofs, c->d_in_targets, kind == TMX_KIND_SKIP ? c->d_in_trusteds : nullptr,
+                                out_elems ? c->d_out : nullptr, c->d_reports, nullptr);
+  if (st) return st;
+  if (out_elems) {
+    // rows are stride apart on the device; the last row is copied without its pad element
+    const size_t bytes = ((size_t)(n_proofs - 1) * stride + count) * 8;
+    HIPCK(c, hipMemcpyAsync(out_elems, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+  }
+  if (reports) HIPCK(c, hipMemcpyAsync(reports, c->d_reports, (size_t)n_proofs * sizeof(tmx_report), hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  return TMX_OK;
+}
+
+int32_t tmx_skip_witness(tmx_ctx* c, const tmx_proof_rec* proof, const tmx_validator_rec* target, const tmx_hashfield_rec* trusted,
+                         uint64_t* out_elems, uint64_t cap_elems, tmx_report* report) {
+  return tmx_witness_batch(c, TMX_KIND_SKIP, 1, proof, target, trusted, out_elems, cap_elems, report);
+}
+int32_t tmx_step_witness(tmx_ctx* c, const tmx_proof_rec* proof, const tmx_validator_rec* target, uint64_t* out_elems, uint64_t cap_elems,
+                         tmx_report* report) {
+  return tmx_witness_batch(c, TMX_KIND_STEP, 1, proof, target, nullptr, out_elems, cap_elems, report);
+}
+
+int32_t tmx_eddsa_lanes(tmx_ctx* c, uint32_t n_lanes, const tmx_validator_rec* lanes, uint8_t* out) {
+  if (!c || !lanes || !out) return TMX_ERR_BAD_ARG;
+  if (n_lanes == 0) return TMX_OK;
+  if ((uint64_t)n_lanes > (uint64_t)c->cfg.max_batch * c->cfg.n_max) return fail(c, TMX_ERR_CAPACITY, "n_lanes exceeds max_batch * n_max");
+  int32_t st = ensure_staging(c);
+  if (st) return st;
+  HIPCK(c, hipMemcpyAsync(c->d_in_targets, lanes, (size_t)n_lanes * sizeof(tmx_validator_rec), hipMemcpyHostToDevice, c->stream));
+  int rc = launch_eddsa(n_lanes, c->d_in_targets, c->d_ed, c->d_table, c->stream);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_eddsa launch: ") + hipGetErrorString((hipError_t)rc));
+  HIPCK(c, hipMemcpyAsync(out, c->d_ed, (size_t)n_lanes * ED_STRIDE, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  return TMX_OK;
+}
+
+// ---- public I/O packing (big-endian, abi.encodePacked): TendermintX.sol:104-108, skip.rs:120-122, step.rs:107-108
+static void be64(uint64_t v, uint8_t* o) { for (int i = 0; i < 8; i++) o[i] = (uint8_t)(v >> (56 - 8 * i)); }
+static uint64_t rd_be64(const uint8_t* p) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | p[i]; return v; }
+void tmx_pack_skip_input(uint64_t trusted_block, const uint8_t h[32], uint64_t target_block, uint8_t out[48]) {
+  be64(trusted_block, out); std::memcpy(out + 8, h, 32); be64(target_block, out + 40);
+}
+void tmx_unpack_skip_input(const uint8_t in[48], uint64_t* trusted_block, uint8_t h[32], uint64_t* target_block) {
+  *trusted_block = rd_be64(in); std::memcpy(h, in + 8, 32); *target_block = rd_be64(in + 40);
+}
+void tmx_pack_step_input(uint64_t prev_block, const uint8_t h[32], uint8_t out[40]) { be64(prev_block, out); std::memcpy(out + 8, h, 32); }
+void tmx_unpack_step_input(const uint8_t in[40], uint64_t* prev_block, uint8_t h[32]) { *prev_block = rd_be64(in); std::memcpy(h, in + 8, 32); }
+
+}  // extern "C"

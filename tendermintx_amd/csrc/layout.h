@@ -1,0 +1,79 @@
+// Device-side buffer layouts shared by the kernels (kernels.hip) and the host API (api.cpp).
+// Host structs of the C ABI are in include/tmx.h; everything here is internal to libtmx.
+#pragma once
+#include <stdint.h>
+
+namespace tmx {
+
+constexpr uint32_t TMX_N_LIMIT = 512;  // largest VALIDATOR_SET_SIZE_MAX (LDS sizing of k_proof)
+
+// ---- compact per-lane / per-proof result buffers written by k_eddsa / k_proof, read by k_serialize
+constexpr uint32_t ED_STRIDE = 448;  // digest[64] h[32] pts[10][32] ok u32 decode_ok u32 pad
+constexpr uint32_t ED_OFF_DIGEST = 0, ED_OFF_H = 64, ED_OFF_PTS = 96, ED_OFF_OK = 416, ED_OFF_DECODE_OK = 420;
+
+constexpr uint32_t LANE_STRIDE = 112;  // derived per-lane record (target and trusted sets alike)
+constexpr uint32_t LN_OFF_MARSHAL = 0, LN_OFF_LEAF = 48, LN_OFF_FLAGS = 80, LN_OFF_TOT = 88, LN_OFF_ACC = 96;
+// target flags bytes: [0] enabled [1] hash_in_msg [2] is_precommit [3] height_ok [4] round_ok [5] sigdata_ok
+// trusted flags bytes: [0] enabled [1] matched
+
+constexpr uint32_t PF_STRIDE = 1920;  // per-proof derived record
+constexpr uint32_t PF_OFF_HEADER = 0;
+constexpr uint32_t PF_OFF_AUNTS = 32;     // 5 x [4][32]: chain-id, height, validators-hash, X, Y
+constexpr uint32_t PF_OFF_PROOFD = 672;   // 5 x (leaf_hash[32] + nodes[4][32]) same order
+constexpr uint32_t PF_OFF_HLEAF = 1472;   // 00 08 varint9(height)  (11 B)
+constexpr uint32_t PF_OFF_TALLY_T = 1488; // u64 total, acc, scaled_acc, scaled_total
+constexpr uint32_t PF_OFF_TALLY_R = 1520;
+constexpr uint32_t PF_OFF_VERDICTS = 1552;  // u32 gt_t, gt_r, dist_gt, dist_le
+constexpr uint32_t PF_OFF_CHECKS = 1568;    // u32 x 16
+constexpr uint32_t PF_OFF_ALLOK = 1632;     // u32
+constexpr uint32_t PF_OFF_HEIGHT = 1640;    // u64 header_a height
+constexpr uint32_t PF_OFF_CIDLEN = 1648;    // u32 enc chain id length
+constexpr uint32_t PF_OFF_HLEN = 1652;      // u32 enc height length
+constexpr uint32_t PF_OFF_CID52 = 1664;     // chain-id leaf zero-padded to 52
+constexpr uint32_t PF_OFF_LEAFV = 1728;     // header_a leaf 7 padded to 34
+constexpr uint32_t PF_OFF_LEAFX = 1776;     // skip: header_b leaf 7 (34) ; step: header_a leaf 4 (72)
+constexpr uint32_t PF_OFF_LEAFY = 1856;     // step: header_b leaf 8 (34)
+
+// ---- input record offsets (include/tmx.h structs, as raw bytes)
+constexpr uint32_t VR_STRIDE = 256, VR_OFF_PK = 0, VR_OFF_SIG = 32, VR_OFF_MSG = 96, VR_OFF_MLEN = 220, VR_OFF_VLEN = 222,
+                   VR_OFF_FLAGS = 223, VR_OFF_POWER = 224;
+constexpr uint32_t HR_STRIDE = 48, HR_OFF_PK = 0, HR_OFF_POWER = 32, HR_OFF_VLEN = 40, HR_OFF_FLAGS = 41;
+constexpr uint32_t HDR_SIZE = 1136, PR_STRIDE = 2336, PR_OFF_BLOCK_A = 0, PR_OFF_BLOCK_B = 8, PR_OFF_HASH = 16, PR_OFF_ROUND = 48,
+                   PR_OFF_NB_A = 56, PR_OFF_NB_B = 60, PR_OFF_HDR_A = 64, PR_OFF_HDR_B = 64 + HDR_SIZE;
+
+// ---- serializer program: the element stream is a list of sections; fixed and per-lane sections are driven by
+// look-up tables with one u32 per element:  src[31:29] | code[28:24] | byte offset[23:0]
+enum : uint32_t { SRC_PROOF = 0, SRC_TARGET = 1, SRC_TRUSTED = 2, SRC_ED = 3, SRC_LT = 4, SRC_LR = 5, SRC_PF = 6, SRC_COUNT = 7 };
+enum : uint32_t { CODE_BIT0 = 0 /* ..7: BE bit k of the byte */, CODE_U8 = 8, CODE_U16 = 9, CODE_U32 = 10, CODE_FLAG0 = 11 /* byte&1 */ };
+constexpr uint32_t lut_entry(uint32_t src, uint32_t code, uint32_t off) { return (src << 29) | (code << 24) | off; }
+
+enum : uint32_t { SEC_LUT = 0, SEC_LINEAR_T = 1, SEC_LINEAR_R = 2 };
+struct Section {
+  uint32_t elem_start;  // first element of the section within a proof row
+  uint32_t lane_elems;  // elements per lane (whole section if n_lanes == 1)
+  uint32_t n_lanes;     // 1 for fixed sections
+  uint32_t lut_off;     // index into the LUT array (SEC_LUT)
+  uint32_t kind;
+};
+constexpr int MAX_SECTIONS = 10;
+struct SerializeProgram {
+  Section sec[MAX_SECTIONS];
+  uint32_t n_sections;
+  uint32_t elem_count;   // elements per proof
+  uint32_t elem_stride;  // row stride (even)
+  uint32_t n;            // lanes per proof
+  uint32_t tree_nodes;   // nodes per validator tree
+};
+struct SerializeSources {
+  const uint8_t* base[SRC_COUNT];
+  const uint8_t* nodes_t;
+  const uint8_t* nodes_r;
+};
+
+struct ProofParams {
+  uint32_t kind, n, tree_nodes, chain_id_len;
+  uint64_t skip_max;
+  uint8_t chain_id[52];
+};
+
+}  // namespace tmx
