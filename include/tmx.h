@@ -156,6 +156,9 @@ int32_t tmx_witness_batch_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, 
                                  const void* d_trusteds, void* d_out_elems, void* d_reports, void* hip_stream);
 /* HIP-event times (ms) of the kernels of the LAST tmx_witness_batch_device / host call; blocks until they finished */
 int32_t tmx_last_kernel_ms(tmx_ctx* ctx, float ms[TMX_N_KERNELS]);
+/* mean over the last `last_k` enqueued batches (each batch keeps its own event set, ring of 128): lets a caller time
+ * a whole region without synchronising inside it */
+int32_t tmx_kernel_ms_mean(tmx_ctx* ctx, uint32_t last_k, float ms[TMX_N_KERNELS]);
 int32_t tmx_sync(tmx_ctx* ctx);
 
 /* ---- per-lane Level-1 EdDSA values only (unit-test / profiling hook of the dominant kernel).
@@ -180,12 +183,6 @@ void tmx_pack_skip_input(uint64_t trusted_block, const uint8_t trusted_header_ha
 void tmx_unpack_skip_input(const uint8_t in[48], uint64_t* trusted_block, uint8_t trusted_header_hash[32], uint64_t* target_block);
 void tmx_pack_step_input(uint64_t prev_block, const uint8_t prev_header_hash[32], uint8_t out[40]);
 void tmx_unpack_step_input(const uint8_t in[40], uint64_t* prev_block, uint8_t prev_header_hash[32]);
-
-/* ---- synthetic workload generator (bench / tests; not part of the reference): fills device buffers with
- * n_proofs well-formed skip (or step) inputs whose signatures are produced on the GPU (RFC 8032 signing).
- * nb_validators real validators per set (<= n_max); signed_permille of them sign; round_ is the commit round. */
-int32_t tmx_synth_batch_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, uint64_t seed, uint32_t nb_validators,
-                               uint32_t signed_permille, uint64_t round_, void* d_proofs, void* d_targets, void* d_trusteds);
 
 #ifdef __cplusplus
 }

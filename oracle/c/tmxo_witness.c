@@ -133,7 +133,8 @@ typedef struct {
 } hdr;
 
 static void hdr_load(hdr* h, const uint8_t* rec) {
-  for (int i = 0; i < 14; i++) { h->len[i] = rec[i]; h->leaf[i] = rec + 16 + 80 * i; tmxo_leaf_hash(h->leaf[i], h->len[i], h->lh[i]); }
+  /* len[] keeps the raw length byte (it is a hint element); hashing and copies use at most the 79 bytes a slot can hold */
+  for (int i = 0; i < 14; i++) { h->len[i] = rec[i]; h->leaf[i] = rec + 16 + 80 * i; tmxo_leaf_hash(h->leaf[i], rec[i] > 79 ? 79 : rec[i], h->lh[i]); }
   tmxo_rfc6962_root(&h->lh[0][0], 14, h->root);
 }
 /* walk a depth-4 proof (tendermint_utils.rs:214-224; path bits LSB-first per shared.rs:45-65) */
@@ -147,8 +148,9 @@ static void proof_walk(const uint8_t leaf_hash[32], int index, uint8_t aunts[4][
 static void emit_proof_d(es* e, const uint8_t lh[32], uint8_t nodes[4][32]) { e_bytes(e, lh, 32); for (int k = 0; k < 4; k++) e_bytes(e, nodes[k], 32); }
 
 static uint64_t height_from_leaf(const uint8_t* leaf, int len) {
+  /* inverse of `08 varint(height)`; a varint has at most 10 bytes, anything longer is ignored */
   uint64_t x = 0; int s = 0;
-  for (int i = 1; i < len; i++) { x |= (uint64_t)(leaf[i] & 0x7f) << s; s += 7; }
+  for (int i = 1; i < len && i <= 10; i++) { x |= (uint64_t)(leaf[i] & 0x7f) << s; s += 7; }
   return x;
 }
 
@@ -225,10 +227,11 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
     const uint8_t* v = trec + (size_t)TMXO_REC_VALIDATOR * i;
     uint8_t m[46], lh[32];
     tmxo_marshal_validator(v, powers[i], m);
-    tmxo_leaf_hash(m, v[222], lh);                       /* validator.rs:209-229: 1 + vlen bytes */
+    tmxo_leaf_hash(m, v[222] > 46 ? 46 : v[222], lh);    /* validator.rs:209-229: 1 + vlen bytes (vlen <= 46 by type) */
     memcpy(leaves + 32 * i, lh, 32);
     tmxo_eddsa_trace tr;
     size_t mlen = (size_t)v[220] | ((size_t)v[221] << 8);
+    if (mlen > 124) mlen = 124;                              /* message buffer is 124 bytes (consts.rs:29) */
     if (signedv[i]) tmxo_eddsa_trace_lane(v, v + 32, v + 96, mlen, &tr);
     else tmxo_eddsa_trace_lane(dummy_pk, dummy_sig, zero_msg, 32, &tr);   /* conditional substitution (verify.rs:248-259) */
     const uint8_t* msg = v + 96;
@@ -263,7 +266,7 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
       for (uint32_t i = 0; i < n; i++)                                  /* verify.rs:398-418 */
         if (signedv[i] && memcmp(trec + (size_t)TMXO_REC_VALIDATOR * i, t, 32) == 0) matched[j] = 1;
       tmxo_marshal_validator(t, rp[j], rm + 46 * j);
-      tmxo_leaf_hash(rm + 46 * j, t[40], rleaves + 32 * j);
+      tmxo_leaf_hash(rm + 46 * j, t[40] > 46 ? 46 : t[40], rleaves + 32 * j);
     }
     gt_r = tmxo_tally(rp, n, nbt, matched, 1, 3, totp, accp, scal_r, &no_overflow);
     for (uint32_t j = 0; j < n; j++) {
@@ -276,10 +279,10 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
   e_bytes(&E, nodes, 32 * tn);
   if (kind == TMXO_KIND_SKIP) e_bytes(&E, nodes_r, 32 * tn);
 
-  uint8_t n_cid[4][32], n_h[4][32], n_v[4][32], n_x[4][32], n_y[4][32], hl[11], hlh[32], vlh[32], xlh[32], ylh[32];
+  uint8_t n_cid[4][32], n_h[4][32], n_v[4][32], n_x[4][32], n_y[4][32], hl[96] = {0}, hlh[32], vlh[32], xlh[32], ylh[32];
   proof_walk(ha.lh[1], 1, a_cid, n_cid);                                  /* verify.rs:189-209 */
   hl[0] = 0x00; hl[1] = 0x08; tmxo_varint9(height_a, hl + 2);             /* shared.rs:158-167 */
-  tmxo_leaf_hash(hl + 1, ha.len[2], hlh);                                  /* shared.rs:183-194: 1 + enc_len bytes */
+  tmxo_leaf_hash(hl + 1, ha.len[2] > 79 ? 79 : ha.len[2], hlh);                                  /* shared.rs:183-194: 1 + enc_len bytes */
   proof_walk(hlh, 2, a_h, n_h);
   tmxo_leaf_hash(leaf34, 34, vlh); proof_walk(vlh, 7, a_v, n_v);
   emit_proof_d(&E, ha.lh[1], n_cid);

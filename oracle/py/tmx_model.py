@@ -291,7 +291,7 @@ def eddsa_lane(v):
     """curta_eddsa_verify_sigs_conditional value semantics (called at verify.rs:248-259): !signed lanes are
     evaluated on the dummy (pubkey, signature, 32-byte zero message)."""
     if v["flags"] & FLAG_SIGNED:
-        return ed.verify_trace(v["pubkey"], v["sig"], v["msg"][:v["msg_len"]])
+        return ed.verify_trace(v["pubkey"], v["sig"], v["msg"][:min(v["msg_len"], MSG_MAX)])
     return ed.verify_trace(ed.DUMMY_PUBLIC_KEY, ed.DUMMY_SIGNATURE, ed.DUMMY_MSG)
 
 
@@ -325,14 +325,11 @@ def _emit_chain_height_h(E, leaves, proofs, height_value):
 
 def _height_from_leaf(leaf):
     """Inverse of `08 varint(height)`; the reference reads header.height.value() (input/mod.rs:481)."""
-    if not leaf:
-        return 0
-    assert leaf[0] == 0x08
     x, s = 0, 0
-    for b in leaf[1:]:
+    for b in leaf[1:11]:
         x |= (b & 0x7F) << s
         s += 7
-    return x
+    return x & U64
 
 
 def _valset_derived(lanes):
@@ -341,7 +338,7 @@ def _valset_derived(lanes):
     for v in lanes:
         assert v["power"] < (1 << 63)
         m = b"\x0a\x22\x0a\x20" + v["pubkey"] + b"\x10" + tm.varint9(v["power"])
-        out.append((m, tm.leaf_hash(m[:v["vlen"]])))
+        out.append((m, tm.leaf_hash(m[:min(v["vlen"], VAL_BYTES_MAX)])))
     return out
 
 
@@ -446,7 +443,7 @@ def witness(kind, proof_rec, target_recs, trusted_recs, chain_id, skip_max):
     cid_leaf_hash = tm.leaf_hash(leaves_a[1])                      # verify.rs:189-202
     cid_nodes = proof_walk(cid_leaf_hash, 1, proofs_a[1])
     hl = b"\x00\x08" + tm.varint9(height_a)                        # shared.rs:158-167, 180-181
-    h_leaf_hash = tm.leaf_hash(hl[1:1 + len(leaves_a[2])])         # SHA256 over 1+len bytes of `00 08 varint9`
+    h_leaf_hash = tm.leaf_hash(hl[1:].ljust(80, b"\0")[:len(leaves_a[2])])   # SHA256 over 1+len bytes of `00 08 varint9 00..`
     h_nodes = proof_walk(h_leaf_hash, 2, proofs_a[2])
     v_leaf_hash = tm.leaf_hash(leaves_a[7].ljust(34, b"\0"))
     v_nodes = proof_walk(v_leaf_hash, 7, proofs_a[7])

@@ -121,6 +121,7 @@ def lib():
     L.tmx_witness_batch_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]
     L.tmx_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.tmx_kernel_ms_mean.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
     L.tmx_sync.argtypes = [C.c_void_p]
     L.tmx_eddsa_lanes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.tmx_skip_inputs_from_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64,
@@ -135,9 +136,6 @@ def lib():
     L.tmx_pack_step_input.restype = None
     L.tmx_unpack_step_input.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.c_char_p]
     L.tmx_unpack_step_input.restype = None
-    if hasattr(L, "tmx_synth_batch_device"):
-        L.tmx_synth_batch_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
-                                             C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

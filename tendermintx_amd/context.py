@@ -85,13 +85,15 @@ class Context:
         check(self._L.tmx_witness_batch_device(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports, stream),
               self._h)
 
-    def synth_batch_device(self, kind, n_proofs, seed, nb_validators, signed_permille, round_, d_proofs, d_targets, d_trusteds):
-        check(self._L.tmx_synth_batch_device(self._h, kind, n_proofs, seed, nb_validators, signed_permille, round_, d_proofs,
-                                             d_targets, d_trusteds), self._h)
-
     def last_kernel_ms(self):
         ms = (C.c_float * _lib.N_KERNELS)()
         check(self._L.tmx_last_kernel_ms(self._h, ms), self._h)
+        return dict(zip(_lib.KERNEL_NAMES, (float(x) for x in ms)))
+
+    def kernel_ms_mean(self, last_k):
+        """Mean HIP-event duration per kernel over the last `last_k` enqueued batches (blocks until they finished)."""
+        ms = (C.c_float * _lib.N_KERNELS)()
+        check(self._L.tmx_kernel_ms_mean(self._h, last_k, ms), self._h)
         return dict(zip(_lib.KERNEL_NAMES, (float(x) for x in ms)))
 
     def sync(self):

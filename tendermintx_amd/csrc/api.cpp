@@ -196,8 +196,11 @@ struct tmx_ctx {
   tmx_config cfg;
   std::string err;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[TMX_N_KERNELS + 1] = {};
-  bool ev_valid = false;
+  // ring of HIP-event sets: one set (TMX_N_KERNELS + 1 events) per enqueued batch, so that kernel durations can be
+  // averaged over a whole timed region afterwards without synchronising inside it
+  static constexpr int EV_RING = 128;
+  hipEvent_t ev[EV_RING][TMX_N_KERNELS + 1] = {};
+  uint64_t n_calls = 0;
   Program prog[2];
   void* d_lut[2] = {nullptr, nullptr};
   void* d_table = nullptr;
@@ -255,8 +258,9 @@ void tmx_ctx_destroy(tmx_ctx* c) {
                   c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
-  for (auto& e : c->ev)
-    if (e) (void)hipEventDestroy(e);
+  for (auto& set : c->ev)
+    for (auto& e : set)
+      if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -274,7 +278,8 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   if (cfg->device < 0 || cfg->device >= ndev) return fail(c, TMX_ERR_BAD_ARG, "device ordinal out of range");
   HIPCK(c, hipSetDevice(cfg->device));
   HIPCK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  for (auto& ev : c->ev) HIPCK(c, hipEventCreate(&ev));
+  for (auto& set : c->ev)
+    for (auto& ev : set) HIPCK(c, hipEventCreate(&ev));
   const uint32_t n = cfg->n_max;
   const size_t B = cfg->max_batch, lanes = B * n;
   for (int k = 0; k < 2; k++) {
@@ -318,13 +323,14 @@ int32_t tmx_witness_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, co
   std::memcpy(P.chain_id, c->cfg.chain_id, sizeof P.chain_id);
   void* reports = d_reports ? d_reports : c->d_reports;
 
-  HIPCK(c, hipEventRecord(c->ev[0], s));
+  hipEvent_t* ev = c->ev[c->n_calls % tmx_ctx::EV_RING];
+  HIPCK(c, hipEventRecord(ev[0], s));
   int rc = launch_eddsa(n_proofs * n, d_targets, c->d_ed, c->d_table, s);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_eddsa launch: ") + hipGetErrorString((hipError_t)rc));
-  HIPCK(c, hipEventRecord(c->ev[1], s));
+  HIPCK(c, hipEventRecord(ev[1], s));
   rc = launch_proof(P, n_proofs, d_proofs, d_targets, d_trusteds, c->d_ed, c->d_lt, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r, reports, s);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_proof launch: ") + hipGetErrorString((hipError_t)rc));
-  HIPCK(c, hipEventRecord(c->ev[2], s));
+  HIPCK(c, hipEventRecord(ev[2], s));
   if (d_out_elems) {
     SerializeSources src;
     std::memset(&src, 0, sizeof src);
@@ -335,18 +341,30 @@ int32_t tmx_witness_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, co
     rc = launch_serialize(c->prog[kind].sp, src, c->d_lut[kind], n_proofs, d_out_elems, s);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_serialize launch: ") + hipGetErrorString((hipError_t)rc));
   }
-  HIPCK(c, hipEventRecord(c->ev[3], s));
-  c->ev_valid = true;
+  HIPCK(c, hipEventRecord(ev[3], s));
+  c->n_calls++;
   return TMX_OK;
 }
 
-int32_t tmx_last_kernel_ms(tmx_ctx* c, float ms[TMX_N_KERNELS]) {
-  if (!c || !ms) return TMX_ERR_BAD_ARG;
-  if (!c->ev_valid) return fail(c, TMX_ERR_BAD_ARG, "no batch has been enqueued yet");
-  HIPCK(c, hipEventSynchronize(c->ev[TMX_N_KERNELS]));
-  for (int k = 0; k < TMX_N_KERNELS; k++) HIPCK(c, hipEventElapsedTime(&ms[k], c->ev[k], c->ev[k + 1]));
+int32_t tmx_kernel_ms_mean(tmx_ctx* c, uint32_t last_k, float ms[TMX_N_KERNELS]) {
+  if (!c || !ms || last_k == 0) return TMX_ERR_BAD_ARG;
+  if (c->n_calls == 0) return fail(c, TMX_ERR_BAD_ARG, "no batch has been enqueued yet");
+  if (last_k > tmx_ctx::EV_RING) last_k = tmx_ctx::EV_RING;
+  if (last_k > c->n_calls) last_k = (uint32_t)c->n_calls;
+  double acc[TMX_N_KERNELS] = {0};
+  for (uint32_t j = 0; j < last_k; j++) {
+    hipEvent_t* ev = c->ev[(c->n_calls - 1 - j) % tmx_ctx::EV_RING];
+    HIPCK(c, hipEventSynchronize(ev[TMX_N_KERNELS]));
+    for (int k = 0; k < TMX_N_KERNELS; k++) {
+      float t = 0;
+      HIPCK(c, hipEventElapsedTime(&t, ev[k], ev[k + 1]));
+      acc[k] += t;
+    }
+  }
+  for (int k = 0; k < TMX_N_KERNELS; k++) ms[k] = (float)(acc[k] / last_k);
   return TMX_OK;
 }
+int32_t tmx_last_kernel_ms(tmx_ctx* c, float ms[TMX_N_KERNELS]) { return tmx_kernel_ms_mean(c, 1, ms); }
 
 static int32_t ensure_staging(tmx_ctx* c) {
   if (c->d_in_proofs) return TMX_OK;

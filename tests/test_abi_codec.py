@@ -1,0 +1,137 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every symbol include/tmx.h declares, its host codec turns the
+reference's fixture JSON into exactly the records the oracle-side Python codec produces, and it refuses to compute
+without a GPU (no CPU fallback).  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import tmx_model as m
+from conftest import GOLDEN, ROOT
+
+FX = os.path.join(GOLDEN, "fixtures", "mocha-4")
+
+
+def test_exports_every_declared_symbol(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "tmx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(tmx_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 20
+    for n in sorted(names):
+        assert hasattr(built_lib, n), f"libtmx.so does not export {n}"
+
+
+def test_no_hip_runtime_dt_needed():
+    """libtmx.so must not pin a HIP runtime: the process (PyTorch or a C/Rust host) provides it -- INTEGRATION.md"""
+    import subprocess
+    out = subprocess.check_output(["objdump", "-p", os.path.join(ROOT, "tendermintx_amd", "libtmx.so")]).decode()
+    assert "libamdhip64" not in out
+
+
+def test_elem_counts_match_reference_formulas(built_lib, oracle):
+    for n in (1, 2, 4, 32, 100, 128, 512):
+        assert built_lib.tmx_hint_elem_count(0, n) == 1776 * n + 5320      # VerifySkipVariable<N>, SURVEY App. B
+        assert built_lib.tmx_hint_elem_count(1, n) == 1517 * n + 6919      # VerifyStepVariable<N>
+        for kind in (0, 1):
+            assert built_lib.tmx_elem_count(kind, n) == oracle.elem_count(kind, n) == m.elem_count(kind, n)
+            assert built_lib.tmx_elem_stride(kind, n) % 2 == 0
+    assert built_lib.tmx_elem_count(0, 0) == 0 and built_lib.tmx_elem_count(0, 513) == 0 and built_lib.tmx_elem_count(2, 4) == 0
+
+
+def test_public_input_packing(built_lib, kat):
+    """abi.encodePacked(uint64, bytes32, uint64): reference skip.rs:197-199, step.rs:178-180, TendermintX.sol:104-108"""
+    for inp, _ in kat["public_io"]["skip"]:
+        raw = bytes.fromhex(inp)
+        a, h, b = C.c_uint64(), C.create_string_buffer(32), C.c_uint64()
+        built_lib.tmx_unpack_skip_input(raw, C.byref(a), h, C.byref(b))
+        assert a.value == int.from_bytes(raw[:8], "big") and h.raw == raw[8:40] and b.value == int.from_bytes(raw[40:], "big")
+        out = C.create_string_buffer(48)
+        built_lib.tmx_pack_skip_input(a.value, h.raw, b.value, out)
+        assert out.raw == raw
+    for inp, _ in kat["public_io"]["step"]:
+        raw = bytes.fromhex(inp)
+        a, h = C.c_uint64(), C.create_string_buffer(32)
+        built_lib.tmx_unpack_step_input(raw, C.byref(a), h)
+        out = C.create_string_buffer(40)
+        built_lib.tmx_pack_step_input(a.value, h.raw, out)
+        assert out.raw == raw
+
+
+def test_codec_skip_equals_python_codec(built_lib, cases):
+    """tmx_skip_inputs_from_json (C++) == oracle/py fixture codec == committed golden records, incl. the 100-validator set
+    with absent (flag 1) and nil (flag 3) votes."""
+    from tendermintx_amd.circuits import InputDataFetcher
+    f, pf = InputDataFetcher(FX), m.FixtureFetcher(FX)
+    for name, a, b, n in [("skip_3000_3100_n4", 3000, 3100, 4), ("skip_10000_10500_n4", 10000, 10500, 4),
+                          ("skip_10000_10500_n32", 10000, 10500, 32), ("skip_157001_157001_n128", 157001, 157001, 128),
+                          ("skip_10500_157001_n128", 10500, 157001, 128)]:
+        pr, tg, tr = m.skip_inputs_from_fixtures(pf, a, b, n)
+        p2, t2, r2 = f.get_skip_inputs(n, a, m.unpack_proof(pr)["hash"], b)
+        assert p2 == pr and t2 == b"".join(tg) and r2 == b"".join(tr), name
+        c = cases[name]
+        assert p2.hex() == c["proof"] and t2.hex() == c["target"] and r2.hex() == c["trusted"], name
+
+
+def test_codec_step_equals_python_codec(built_lib, cases):
+    from tendermintx_amd.circuits import InputDataFetcher
+    f, pf = InputDataFetcher(FX), m.FixtureFetcher(FX)
+    for name, prev, n in [("step_3000_n4", 3000, 4), ("step_10000_n2", 10000, 2), ("step_10500_n4", 10500, 4), ("step_10500_n100", 10500, 100)]:
+        pr, tg = m.step_inputs_from_fixtures(pf, prev, n)
+        p2, t2 = f.get_step_inputs(n, prev, m.unpack_proof(pr)["hash"])
+        assert p2 == pr and t2 == b"".join(tg), name
+        assert p2.hex() == cases[name]["proof"] and t2.hex() == cases[name]["target"], name
+
+
+def test_codec_error_behaviour(built_lib):
+    """reference input/mod.rs:439-444 / 338-342 assert when the validator set exceeds VALIDATOR_SET_SIZE_MAX"""
+    from tendermintx_amd.circuits import InputDataFetcher
+    f = InputDataFetcher(FX)
+    with pytest.raises(AssertionError, match="larger than the VALIDATOR_SET_SIZE_MAX"):
+        f.get_skip_inputs(2, 10000, bytes(32), 10500)       # target set has 3 validators
+    with pytest.raises(AssertionError, match="larger than the VALIDATOR_SET_SIZE_MAX"):
+        f.get_step_inputs(2, 10500, bytes(32))
+    from tendermintx_amd._lib import HashFieldRec, ProofRec, ValidatorRec
+    p, t, r = ProofRec(), (ValidatorRec * 4)(), (HashFieldRec * 4)()
+    assert built_lib.tmx_skip_inputs_from_json(b"{not json", b"{}", b"{}", b"{}", 4, 1, bytes(32), 3, C.byref(p), t, r) == -5
+    assert built_lib.tmx_skip_inputs_from_json(None, b"{}", b"{}", b"{}", 4, 1, bytes(32), 3, C.byref(p), t, r) == -1
+
+
+def test_round_nonzero_sign_bytes(built_lib):
+    """The reference has no fixture with round != 0 (TODO at verify.rs:612): the codec must place LE64(round) at [13..21] and
+    the block hash at [25..57] (validator.rs:133, 168)."""
+    import json
+    commit = json.load(open(os.path.join(FX, "10500", "commit.json")))
+    commit["result"]["signed_header"]["commit"]["round"] = 5
+    vals = open(os.path.join(FX, "10500", "validators_1.json"), "rb").read()
+    from tendermintx_amd._lib import ProofRec, ValidatorRec
+    p, t = ProofRec(), (ValidatorRec * 4)()
+    prev = open(os.path.join(FX, "10500", "commit.json"), "rb").read()
+    assert built_lib.tmx_step_inputs_from_json(prev, json.dumps(commit).encode(), vals, 4, 10499, bytes(32), C.byref(p), t) == 0
+    msg = bytes(t[0].message)
+    assert p.round == 5 and msg[12] == 0x19 and int.from_bytes(msg[13:21], "little") == 5
+    assert msg[25:57].hex().upper() == commit["result"]["signed_header"]["commit"]["block_id"]["hash"]
+    assert t[0].message_byte_length == 109 + 9
+
+
+def test_no_cpu_fallback(built_lib):
+    """Without a usable HIP device every compute entry point fails loudly (TMX_ERR_HIP); with one, this test is vacuous."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from tendermintx_amd import Context, TmxError
+    with pytest.raises(TmxError) as e:
+        Context(4)
+    assert e.value.status == -3
+
+
+def test_product_never_touches_the_oracle():
+    """The product package and its native sources must not import, link or execute anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tendermintx_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".hpp", ".h")) or fn == "Makefile":
+                text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "oracle_c" not in text and "tmxo_" not in text and "libtmx_oracle" not in text, fn
+    import subprocess
+    syms = subprocess.check_output(["nm", "-D", os.path.join(ROOT, "tendermintx_amd", "libtmx.so")]).decode()
+    assert "tmxo_" not in syms

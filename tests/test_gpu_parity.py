@@ -1,0 +1,362 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same inputs
+(bit-exact: all values are integers / bytes), against the committed goldens, and -- at BASELINE.json's full sizes --
+through size-independent properties.  Written to read like the reference's own tests (circuits/skip.rs:157-296,
+circuits/step.rs:141-268): same fixtures, same public inputs, same names."""
+import hashlib
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+FX = os.path.join(GOLDEN, "fixtures", "mocha-4")
+MOCHA = b"mocha-4"
+
+
+@pytest.fixture(scope="module")
+def tmx(built_lib):
+    import tendermintx_amd
+    return tendermintx_amd
+
+
+def _case_inputs(c):
+    return (bytes.fromhex(c["proof"]), bytes.fromhex(c["target"]), bytes.fromhex(c["trusted"]) if c["trusted"] else None)
+
+
+def _check_vs_oracle(tmx, oracle, kind, n, proofs, targets, trusteds, chain_id, skip_max=100800, ctx=None, threads=8):
+    P = len(proofs) // 2336
+    own = ctx is None
+    ctx = ctx or tmx.Context(n, chain_id, skip_max, max_batch=P)
+    try:
+        elems, reps = ctx.witness_batch(kind, proofs, targets, trusteds)
+    finally:
+        if own:
+            ctx.close()
+    want, oreps = oracle.witness_batch(kind, P, proofs, targets, trusteds, n, chain_id, skip_max, n_threads=threads)
+    if not np.array_equal(elems, want):
+        bad = np.argwhere(elems != want)
+        raise AssertionError(f"GPU != oracle at (proof, element) {bad[:10].tolist()} ({len(bad)} differences)")
+    assert reps == oreps
+    return elems, reps
+
+
+# ------------------------------------------------------------------------------------------------ goldens
+def test_golden_cases_bit_exact(tmx, oracle, cases):
+    for name, c in sorted(cases.items()):
+        proof, target, trusted = _case_inputs(c)
+        elems, reps = _check_vs_oracle(tmx, oracle, c["kind"], c["n"], proof, target, trusted, c["chain_id"].encode(), c["skip_max"])
+        assert hashlib.sha256(np.ascontiguousarray(elems[0]).tobytes()).hexdigest() == c["elems_sha256"], name
+        r = reps[0]
+        assert r["header"].hex() == c["header"] and r["all_ok"] == c["all_ok"] and r["fail_mask"] == c["fail_mask"], name
+        assert r["first_bad_sig"] == c["first_bad_sig"] and r["gt_target"] == c["gt_target"], name
+        path = os.path.join(GOLDEN, f"elems_{name}.npz")
+        if os.path.exists(path):
+            assert np.array_equal(np.load(path)["elems"], elems[0]), name
+
+
+# ------------------------------------------------------------------------------------------------ the reference's own tests
+def _skip_template(tmx, n, trusted_header_hex, trusted_block, target_block, expect_hex):
+    """test_skip_template (skip.rs:219-250) at the value level: target_header out, all constraints satisfied."""
+    circ = tmx.SkipCircuit(n, tmx.MOCHA_4_CHAIN_ID_BYTES, tmx.SKIP_MAX, fetcher=tmx.InputDataFetcher(FX))
+    try:
+        elems, rep = circ.hint(trusted_block, bytes.fromhex(trusted_header_hex), target_block)
+        assert rep["all_ok"] and rep["header"].hex().upper() == expect_hex.upper()
+        assert len(elems) == circ.ctx.elem_count(0)
+        # the first 256 elements are target_header as 32 x 8 big-endian bits (Bytes32Variable)
+        bits = elems[:256].reshape(32, 8)
+        assert bytes(int("".join(str(int(b)) for b in row), 2) for row in bits) == rep["header"]
+    finally:
+        circ.close()
+
+
+def test_skip_circuit_with_input_bytes(tmx, kat):
+    """skip.rs:188-217: block 3000 with requested block 3100, N = 4"""
+    circ = tmx.SkipCircuit(4, tmx.MOCHA_4_CHAIN_ID_BYTES, fetcher=tmx.InputDataFetcher(FX))
+    inp, out = kat["public_io"]["skip"][0]
+    assert circ.prove_public(bytes.fromhex(inp)).hex() == out
+    circ.close()
+
+
+def test_skip_small(tmx):
+    """skip.rs:252-265"""
+    _skip_template(tmx, 4, "A0123D5E4B8B8888A61F931EE2252D83568B97C223E0ECA9795B29B8BD8CBA2D", 10000, 10500,
+                   "E2BA1B86926925A69C2FCC32E5178E7E6653D386C956BB975142FA73211A9444")
+
+
+def test_skip_medium(tmx):
+    """skip.rs:267-282"""
+    _skip_template(tmx, 32, "A0123D5E4B8B8888A61F931EE2252D83568B97C223E0ECA9795B29B8BD8CBA2D", 10000, 10500,
+                   "E2BA1B86926925A69C2FCC32E5178E7E6653D386C956BB975142FA73211A9444")
+
+
+def test_skip_wrong_trusted_hash_panics(tmx):
+    """input/mod.rs:450-455: a wrong trusted header hash fails the sanity assert"""
+    circ = tmx.SkipCircuit(4, tmx.MOCHA_4_CHAIN_ID_BYTES, fetcher=tmx.InputDataFetcher(FX))
+    with pytest.raises(AssertionError, match="Trusted header hash doesn't pass sanity check"):
+        circ.hint(10000, bytes(32), 10500)
+    circ.close()
+
+
+def _step_template(tmx, n, block_height, header_hex, expect_hex):
+    """test_step_template (step.rs:200-228)"""
+    circ = tmx.StepCircuit(n, tmx.MOCHA_4_CHAIN_ID_BYTES, fetcher=tmx.InputDataFetcher(FX))
+    try:
+        _, rep = circ.hint(block_height, bytes.fromhex(header_hex))
+        assert rep["all_ok"] and rep["header"].hex().upper() == expect_hex.upper()
+    finally:
+        circ.close()
+
+
+def test_step_circuit_with_input_bytes(tmx, kat):
+    """step.rs:170-198"""
+    circ = tmx.StepCircuit(4, tmx.MOCHA_4_CHAIN_ID_BYTES, fetcher=tmx.InputDataFetcher(FX))
+    inp, out = kat["public_io"]["step"][0]
+    assert circ.prove_public(bytes.fromhex(inp)).hex() == out
+    circ.close()
+
+
+def test_step_small(tmx):
+    """step.rs:230-241"""
+    _step_template(tmx, 2, 10000, "A0123D5E4B8B8888A61F931EE2252D83568B97C223E0ECA9795B29B8BD8CBA2D",
+                   "F2A340CC2AEF6FE163254B326A52334B45793EB11417029F9548418F88B38E26")
+
+
+def test_step_with_dummy(tmx):
+    """step.rs:243-254: validator 2 of block 10501 voted nil -> dummy-signature lane"""
+    _step_template(tmx, 4, 10500, "E2BA1B86926925A69C2FCC32E5178E7E6653D386C956BB975142FA73211A9444",
+                   "CD3E0F3E47FDAC9ABE1C98CF6BE241BC23A8779E67DF068832F7F43E2DB7B05B")
+
+
+def test_step_large(tmx):
+    """step.rs:256-267: N = 100 (the reference's VALIDATOR_SET_SIZE_MAX, not a power of two)"""
+    _step_template(tmx, 100, 10500, "E2BA1B86926925A69C2FCC32E5178E7E6653D386C956BB975142FA73211A9444",
+                   "CD3E0F3E47FDAC9ABE1C98CF6BE241BC23A8779E67DF068832F7F43E2DB7B05B")
+
+
+def test_step_wrong_prev_hash_panics(tmx):
+    circ = tmx.StepCircuit(4, tmx.MOCHA_4_CHAIN_ID_BYTES, fetcher=tmx.InputDataFetcher(FX))
+    with pytest.raises(AssertionError, match="Prev header hash doesn't pass sanity check"):
+        circ.hint(10500, bytes(32))
+    circ.close()
+
+
+# ------------------------------------------------------------------------------------------------ EdDSA lanes
+def _lane(pk, sig, msg, signed=True, power=1, vlen=38):
+    return struct.pack("<32s64s124sHBBQ24x", pk, sig, msg.ljust(124, b"\0"), len(msg), vlen, 3 if signed else 2, power)
+
+
+def _ed_record(tr):
+    return tr["digest"] + tr["h"] + b"".join(tr["pt"]) + struct.pack("<II", int(tr["ok"]), int(tr["decode_ok"])) + bytes(24)
+
+
+def test_eddsa_lanes_vs_oracle(tmx, oracle, kat):
+    rng = np.random.default_rng(11)
+    lanes, want = [], []
+
+    def add(pk, sig, msg, signed=True):
+        lanes.append(_lane(pk, sig, msg, signed))
+        if signed:
+            want.append(_ed_record(oracle.eddsa_trace(pk, sig, msg)))
+        else:
+            dpk, dsig = oracle.dummy()
+            want.append(_ed_record(oracle.eddsa_trace(dpk, dsig, bytes(32))))
+
+    for seed, pk, msg, sig in kat["rfc8032"]:
+        add(bytes.fromhex(pk), bytes.fromhex(sig), bytes.fromhex(msg))
+    ell = 2**252 + 27742317777372353535851937790883648493
+    for i in range(40):
+        seed = rng.integers(0, 256, 32, dtype=np.uint8).tobytes()
+        msg = rng.integers(0, 256, int(rng.integers(0, 125)), dtype=np.uint8).tobytes()
+        pk, sig = oracle.pubkey(seed), oracle.sign(seed, msg)
+        add(pk, sig, msg)
+        mode = i % 8
+        b = bytearray(sig)
+        if mode == 0:
+            b[int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))      # corrupt R
+            add(pk, bytes(b), msg)
+        elif mode == 1:
+            b[32 + int(rng.integers(0, 31))] ^= 1 << int(rng.integers(0, 8))  # corrupt s
+            add(pk, bytes(b), msg)
+        elif mode == 2:
+            s = int.from_bytes(sig[32:], "little") + ell                      # non-canonical s (same point s*B)
+            add(pk, sig[:32] + s.to_bytes(32, "little"), msg)
+        elif mode == 3:
+            add(pk, sig[:32] + b"\xff" * 32, msg)                             # s = 2^256 - 1 (recoding carry-out path)
+        elif mode == 4:
+            add((2).to_bytes(32, "little"), sig, msg)                         # undecodable public key
+        elif mode == 5:
+            add(pk, (2**255 - 19 + 1).to_bytes(32, "little") + sig[32:], msg)  # non-canonical y = p + 1 for R
+        elif mode == 6:
+            add(pk, sig, msg + b"x" if len(msg) < 124 else msg[:-1])          # wrong message
+        else:
+            add(pk, sig, msg, signed=False)                                   # unsigned lane -> dummy triple
+    add(bytes(32), bytes(64), b"")                                            # y = 0
+    add(b"\x01" + bytes(31), b"\x01" + bytes(63), b"")                        # identity point, s = 0
+    add(b"\x01" + bytes(30) + b"\x80", bytes(64), b"")                        # x = 0 with sign bit set: rejected
+    with tmx.Context(64, max_batch=4) as ctx:
+        got = ctx.eddsa_lanes(b"".join(lanes))
+    for i, w in enumerate(want):
+        assert bytes(got[i]) == w, f"lane {i}"
+
+
+# ------------------------------------------------------------------------------------------------ synthetic + adversarial
+@pytest.mark.parametrize("kind,n,nb,permille", [(0, 4, 4, 1000), (0, 32, 32, 900), (0, 32, 21, 1000), (1, 32, 32, 900),
+                                                 (0, 100, 77, 850), (1, 128, 100, 900), (0, 128, 128, 1000)])
+def test_synthetic_batches(tmx, oracle, kind, n, nb, permille):
+    from tendermintx_amd.synth import Workload
+    wl = Workload(kind, n, 5, nb, chain_id=b"celestia", seed=1000 + n + nb, signed_permille=permille, rounds=(0, 3, 0, 2**40 + 7, 1))
+    _, reps = _check_vs_oracle(tmx, oracle, kind, n, wl.proofs, wl.targets, wl.trusteds, b"celestia")
+    assert all(r["all_ok"] for r in reps)
+
+
+def test_adversarial_mutations(tmx, oracle):
+    """Random corruption of every input field: verdicts may flip, parity with the oracle must not."""
+    from tendermintx_amd.synth import Workload
+    n, P = 32, 24
+    rng = np.random.default_rng(5)
+    for kind in (0, 1):
+        wl = Workload(kind, n, P, 29, chain_id=b"celestia", seed=77 + kind, signed_permille=950, rounds=(0, 0, 4))
+        proofs, targets = bytearray(wl.proofs), bytearray(wl.targets)
+        trusteds = bytearray(wl.trusteds) if kind == 0 else None
+        for p in range(1, P):  # proof 0 stays pristine
+            mode = p % 12
+            t0 = p * n * 256
+            lane = t0 + int(rng.integers(0, 29)) * 256
+            if mode == 0:
+                targets[lane + int(rng.integers(0, 32))] ^= 0x04                    # pubkey
+            elif mode == 1:
+                targets[lane + 32 + int(rng.integers(0, 64))] ^= 0x20               # signature
+            elif mode == 2:
+                targets[lane + 96 + int(rng.integers(0, 100))] ^= 0x01              # message byte
+            elif mode == 3:
+                targets[lane + 224:lane + 232] = struct.pack("<Q", 2**63 + 5)       # power with bit 63
+            elif mode == 4:
+                targets[lane + 224:lane + 232] = struct.pack("<Q", 2**63 - 1)       # sums wrap
+                targets[lane + 256 + 224:lane + 256 + 232] = struct.pack("<Q", 2**63 - 1)
+                targets[lane + 512 + 224:lane + 512 + 232] = struct.pack("<Q", 2**63 - 1)
+            elif mode == 5:
+                targets[lane + 222] = int(rng.integers(30, 60))                     # validator_byte_length (incl. > 46)
+            elif mode == 6:
+                targets[lane + 220:lane + 222] = struct.pack("<H", int(rng.integers(0, 300)))  # message length (incl. > 124)
+            elif mode == 7:
+                targets[lane + 223] ^= 1                                            # signed flag flipped
+            elif mode == 8:
+                proofs[p * 2336 + 56:p * 2336 + 60] = struct.pack("<I", int(rng.integers(0, 40)))  # nb (incl. > N)
+            elif mode == 9:
+                hb = p * 2336 + 64 + int(rng.integers(0, 2)) * 1136
+                li = int(rng.integers(0, 14))
+                proofs[hb + 16 + 80 * li + int(rng.integers(0, 30))] ^= 0x80        # a header field byte
+            elif mode == 10:
+                hb = p * 2336 + 64
+                proofs[hb + int(rng.integers(0, 14))] = int(rng.integers(0, 120))   # a header field length (incl. > 79)
+            else:
+                proofs[p * 2336 + 16 + int(rng.integers(0, 32))] ^= 0x10            # public trusted / prev hash
+                if trusteds is not None:
+                    j = p * n * 48 + int(rng.integers(0, 29)) * 48
+                    trusteds[j:j + 32] = targets[t0:t0 + 32]                         # duplicate pubkey into the trusted set
+        elems, reps = _check_vs_oracle(tmx, oracle, kind, n, bytes(proofs), bytes(targets), bytes(trusteds) if trusteds else None,
+                                       b"celestia")
+        assert reps[0]["all_ok"] and sum(1 for r in reps if not r["all_ok"]) >= P // 2
+
+
+def test_threshold_edges(tmx, oracle):
+    """exactly 2/3 is not enough (strict >, voting.rs:108); one more unit is"""
+    from tendermintx_amd.synth import Workload
+    n = 4
+    wl = Workload(1, n, 1, 3, chain_id=b"celestia", seed=9, signed_permille=1000, rounds=(0,))
+    for powers, signed, expect in [((10, 10, 10), (1, 1, 0), False), ((10, 10, 9), (1, 1, 0), True), ((1, 1, 1), (1, 1, 1), True)]:
+        t = bytearray(wl.targets)
+        for i in range(3):
+            t[i * 256 + 224:i * 256 + 232] = struct.pack("<Q", powers[i])
+            if not signed[i]:
+                t[i * 256 + 223] &= 0xFE
+        _, reps = _check_vs_oracle(tmx, oracle, 1, n, wl.proofs, bytes(t), None, b"celestia")
+        assert reps[0]["gt_target"] == expect
+
+
+# ------------------------------------------------------------------------------------------------ batch / device paths, properties
+def test_batch_equals_individual_and_is_idempotent(tmx, oracle):
+    from tendermintx_amd.synth import Workload
+    n, P = 32, 37
+    wl = Workload(0, n, P, 30, chain_id=b"celestia", seed=4242, signed_permille=900)
+    with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+        a, ra = ctx.witness_batch(0, wl.proofs, wl.targets, wl.trusteds)
+        b, rb = ctx.witness_batch(0, wl.proofs, wl.targets, wl.trusteds)
+        assert np.array_equal(a, b) and ra == rb                              # idempotent
+        for p in (0, 17, 36):
+            e, r = ctx.witness_batch(0, wl.proofs[p * 2336:(p + 1) * 2336], wl.targets[p * n * 256:(p + 1) * n * 256],
+                                     wl.trusteds[p * n * 48:(p + 1) * n * 48])
+            assert np.array_equal(e[0], a[p]) and r[0] == ra[p]
+        # permuting the proofs of a batch permutes the rows
+        perm = np.random.default_rng(0).permutation(P)
+        pp = b"".join(wl.proofs[p * 2336:(p + 1) * 2336] for p in perm)
+        tt = b"".join(wl.targets[p * n * 256:(p + 1) * n * 256] for p in perm)
+        rr = b"".join(wl.trusteds[p * n * 48:(p + 1) * n * 48] for p in perm)
+        c, _ = ctx.witness_batch(0, pp, tt, rr)
+        assert np.array_equal(c, a[perm])
+        with pytest.raises(tmx.TmxError):
+            ctx.witness_batch(0, wl.proofs + wl.proofs[:2336], wl.targets + wl.targets[:n * 256], wl.trusteds + wl.trusteds[:n * 48])
+
+
+def test_device_resident_path_with_torch(tmx, oracle):
+    """tmx_witness_batch_device on PyTorch-owned HBM buffers and PyTorch's current stream (one HIP runtime per process)"""
+    import torch
+    from tendermintx_amd.synth import Workload
+    n, P = 128, 16
+    wl = Workload(0, n, P, 128, chain_id=b"celestia", seed=31337, signed_permille=900)
+    dev = torch.device("cuda", 0)
+    d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) for b in (wl.proofs, wl.targets, wl.trusteds)]
+    with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+        stride, count = ctx.elem_stride(0), ctx.elem_count(0)
+        out = torch.full((P, stride), -1, dtype=torch.int64, device=dev)
+        rep = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
+        s = torch.cuda.Stream(dev)
+        with torch.cuda.stream(s):
+            ctx.witness_batch_device(0, P, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), out.data_ptr(), rep.data_ptr(), s.cuda_stream)
+        s.synchronize()
+        ms = ctx.kernel_ms_mean(1)
+        assert all(v > 0 for v in ms.values())
+    got = out[:, :count].cpu().numpy().view(np.uint64)
+    want, oreps = oracle.witness_batch(0, P, wl.proofs, wl.targets, wl.trusteds, n, b"celestia", 100800, n_threads=8)
+    assert np.array_equal(got, want)
+    assert int(out[:, count:].abs().sum().item()) == 0                       # row padding is zero-filled
+    assert bytes(rep.cpu().numpy()[:32]) == oreps[0]["header"]
+
+
+def test_full_size_n128_batch256(tmx, oracle):
+    """BASELINE configs[2]/[3]: N = 128, 256 proofs: every row bit-exact vs the (multi-threaded) oracle, all proofs verify,
+    checksum-of-checksums stable across two runs."""
+    from tendermintx_amd.synth import Workload
+    n, P = 128, 256
+    wl = Workload(0, n, P, 128, chain_id=b"celestia", seed=0x544D58, signed_permille=1000)
+    with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+        elems, reps = _check_vs_oracle(tmx, oracle, 0, n, wl.proofs, wl.targets, wl.trusteds, b"celestia", ctx=ctx, threads=os.cpu_count() or 8)
+        again, _ = ctx.witness_batch(0, wl.proofs, wl.targets, wl.trusteds)
+    assert all(r["all_ok"] for r in reps)
+    h1 = hashlib.sha256(b"".join(hashlib.sha256(np.ascontiguousarray(r).tobytes()).digest() for r in elems)).hexdigest()
+    h2 = hashlib.sha256(b"".join(hashlib.sha256(np.ascontiguousarray(r).tobytes()).digest() for r in again)).hexdigest()
+    assert h1 == h2
+
+
+def test_stress_n512(tmx, oracle):
+    """BASELINE configs[4]: VALIDATOR_SET_SIZE_MAX = 512, full and partially filled sets"""
+    from tendermintx_amd.synth import Workload
+    for nb in (512, 300):
+        wl = Workload(0, 512, 3, nb, chain_id=b"celestia", seed=512 + nb, signed_permille=900)
+        _, reps = _check_vs_oracle(tmx, oracle, 0, 512, wl.proofs, wl.targets, wl.trusteds, b"celestia")
+        assert all(r["all_ok"] for r in reps)
+
+
+def test_set_too_large_and_capacity_errors(tmx):
+    from tendermintx_amd.synth import Workload
+    wl = Workload(0, 4, 1, 4, seed=1)
+    bad = bytearray(wl.proofs)
+    bad[56:60] = struct.pack("<I", 5)  # nb_a > N through the host entry point -> TMX_ERR_SET_TOO_LARGE (mod.rs:439-444)
+    with tmx.Context(4, b"celestia") as ctx:
+        with pytest.raises(tmx.TmxError) as e:
+            ctx.witness_batch(0, bytes(bad), wl.targets, wl.trusteds)
+        assert e.value.status == -2
