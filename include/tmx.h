@@ -154,6 +154,12 @@ int32_t tmx_witness_batch(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const t
  * returns after enqueueing; order against it with the stream. */
 int32_t tmx_witness_batch_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
                                  const void* d_trusteds, void* d_out_elems, void* d_reports, void* hip_stream);
+/* The two halves of the call above, for the validator-sharded single-proof mode (BASELINE config 5): each GPU runs
+ * k_eddsa on its slice of lanes, the 448-B lane records are exchanged (one RCCL all-gather), then k_proof + k_serialize
+ * run on the reassembled records.  d_ed_out / d_ed: TMX ED records, 448 B per lane (layout at tmx_eddsa_lanes). */
+int32_t tmx_eddsa_lanes_device(tmx_ctx* ctx, uint32_t n_lanes, const void* d_lanes, void* d_ed_out, void* hip_stream);
+int32_t tmx_finish_batch_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
+                                const void* d_trusteds, const void* d_ed, void* d_out_elems, void* d_reports, void* hip_stream);
 /* HIP-event times (ms) of the kernels of the LAST tmx_witness_batch_device / host call; blocks until they finished */
 int32_t tmx_last_kernel_ms(tmx_ctx* ctx, float ms[TMX_N_KERNELS]);
 /* mean over the last `last_k` enqueued batches (each batch keeps its own event set, ring of 128): lets a caller time

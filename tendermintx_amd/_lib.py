@@ -120,6 +120,9 @@ def lib():
                                     C.c_uint64, C.c_void_p]
     L.tmx_witness_batch_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tmx_eddsa_lanes_device.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tmx_finish_batch_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
     L.tmx_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.tmx_kernel_ms_mean.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
     L.tmx_sync.argtypes = [C.c_void_p]

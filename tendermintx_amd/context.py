@@ -85,6 +85,13 @@ class Context:
         check(self._L.tmx_witness_batch_device(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports, stream),
               self._h)
 
+    def eddsa_lanes_device(self, n_lanes, d_lanes, d_ed_out, stream=None):
+        check(self._L.tmx_eddsa_lanes_device(self._h, n_lanes, d_lanes, d_ed_out, stream), self._h)
+
+    def finish_batch_device(self, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_ed, d_out, d_reports, stream=None):
+        check(self._L.tmx_finish_batch_device(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_ed, d_out, d_reports, stream),
+              self._h)
+
     def last_kernel_ms(self):
         ms = (C.c_float * _lib.N_KERNELS)()
         check(self._L.tmx_last_kernel_ms(self._h, ms), self._h)

@@ -309,33 +309,23 @@ int32_t tmx_sync(tmx_ctx* c) {
   return TMX_OK;
 }
 
-int32_t tmx_witness_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
-                                 const void* d_trusteds, void* d_out_elems, void* d_reports, void* hip_stream) {
-  if (!c || (kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP) || !d_proofs || !d_targets) return TMX_ERR_BAD_ARG;
-  if (kind == TMX_KIND_SKIP && !d_trusteds) return fail(c, TMX_ERR_BAD_ARG, "skip needs the trusted hash fields");
-  if (n_proofs > c->cfg.max_batch) return fail(c, TMX_ERR_CAPACITY, "n_proofs exceeds the context's max_batch");
-  if (n_proofs == 0) return TMX_OK;
-  hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->stream;
+// k_proof + k_serialize over caller-visible EdDSA lane records (d_ed); ev[1..3] are recorded here
+static int32_t finish_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets, const void* d_trusteds,
+                            const void* d_ed, void* d_out_elems, void* d_reports, hipStream_t s, hipEvent_t* ev) {
   const uint32_t n = c->cfg.n_max;
   ProofParams P;
   std::memset(&P, 0, sizeof P);
   P.kind = (uint32_t)kind; P.n = n; P.tree_nodes = tree_nodes(n); P.chain_id_len = c->cfg.chain_id_len; P.skip_max = c->cfg.skip_max;
   std::memcpy(P.chain_id, c->cfg.chain_id, sizeof P.chain_id);
   void* reports = d_reports ? d_reports : c->d_reports;
-
-  hipEvent_t* ev = c->ev[c->n_calls % tmx_ctx::EV_RING];
-  HIPCK(c, hipEventRecord(ev[0], s));
-  int rc = launch_eddsa(n_proofs * n, d_targets, c->d_ed, c->d_table, s);
-  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_eddsa launch: ") + hipGetErrorString((hipError_t)rc));
-  HIPCK(c, hipEventRecord(ev[1], s));
-  rc = launch_proof(P, n_proofs, d_proofs, d_targets, d_trusteds, c->d_ed, c->d_lt, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r, reports, s);
+  int rc = launch_proof(P, n_proofs, d_proofs, d_targets, d_trusteds, d_ed, c->d_lt, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r, reports, s);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_proof launch: ") + hipGetErrorString((hipError_t)rc));
   HIPCK(c, hipEventRecord(ev[2], s));
   if (d_out_elems) {
     SerializeSources src;
     std::memset(&src, 0, sizeof src);
     src.base[SRC_PROOF] = (const uint8_t*)d_proofs; src.base[SRC_TARGET] = (const uint8_t*)d_targets;
-    src.base[SRC_TRUSTED] = (const uint8_t*)d_trusteds; src.base[SRC_ED] = (const uint8_t*)c->d_ed;
+    src.base[SRC_TRUSTED] = (const uint8_t*)d_trusteds; src.base[SRC_ED] = (const uint8_t*)d_ed;
     src.base[SRC_LT] = (const uint8_t*)c->d_lt; src.base[SRC_LR] = (const uint8_t*)c->d_lr; src.base[SRC_PF] = (const uint8_t*)c->d_pf;
     src.nodes_t = (const uint8_t*)c->d_nodes_t; src.nodes_r = (const uint8_t*)c->d_nodes_r;
     rc = launch_serialize(c->prog[kind].sp, src, c->d_lut[kind], n_proofs, d_out_elems, s);
@@ -344,6 +334,49 @@ int32_t tmx_witness_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, co
   HIPCK(c, hipEventRecord(ev[3], s));
   c->n_calls++;
   return TMX_OK;
+}
+
+static int32_t check_batch_args(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets, const void* d_trusteds) {
+  if (!c || (kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP) || !d_proofs || !d_targets) return TMX_ERR_BAD_ARG;
+  if (kind == TMX_KIND_SKIP && !d_trusteds) return fail(c, TMX_ERR_BAD_ARG, "skip needs the trusted hash fields");
+  if (n_proofs > c->cfg.max_batch) return fail(c, TMX_ERR_CAPACITY, "n_proofs exceeds the context's max_batch");
+  return TMX_OK;
+}
+
+int32_t tmx_witness_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
+                                 const void* d_trusteds, void* d_out_elems, void* d_reports, void* hip_stream) {
+  int32_t st = check_batch_args(c, kind, n_proofs, d_proofs, d_targets, d_trusteds);
+  if (st) return st;
+  if (n_proofs == 0) return TMX_OK;
+  hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->stream;
+  hipEvent_t* ev = c->ev[c->n_calls % tmx_ctx::EV_RING];
+  HIPCK(c, hipEventRecord(ev[0], s));
+  int rc = launch_eddsa(n_proofs * c->cfg.n_max, d_targets, c->d_ed, c->d_table, s);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_eddsa launch: ") + hipGetErrorString((hipError_t)rc));
+  HIPCK(c, hipEventRecord(ev[1], s));
+  return finish_batch(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, c->d_ed, d_out_elems, d_reports, s, ev);
+}
+
+int32_t tmx_eddsa_lanes_device(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_ed_out, void* hip_stream) {
+  if (!c || !d_lanes || !d_ed_out) return TMX_ERR_BAD_ARG;
+  if (n_lanes == 0) return TMX_OK;
+  hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->stream;
+  int rc = launch_eddsa(n_lanes, d_lanes, d_ed_out, c->d_table, s);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_eddsa launch: ") + hipGetErrorString((hipError_t)rc));
+  return TMX_OK;
+}
+
+int32_t tmx_finish_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
+                                const void* d_trusteds, const void* d_ed, void* d_out_elems, void* d_reports, void* hip_stream) {
+  int32_t st = check_batch_args(c, kind, n_proofs, d_proofs, d_targets, d_trusteds);
+  if (st) return st;
+  if (!d_ed) return TMX_ERR_BAD_ARG;
+  if (n_proofs == 0) return TMX_OK;
+  hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->stream;
+  hipEvent_t* ev = c->ev[c->n_calls % tmx_ctx::EV_RING];
+  HIPCK(c, hipEventRecord(ev[0], s));
+  HIPCK(c, hipEventRecord(ev[1], s));
+  return finish_batch(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_ed, d_out_elems, d_reports, s, ev);
 }
 
 int32_t tmx_kernel_ms_mean(tmx_ctx* c, uint32_t last_k, float ms[TMX_N_KERNELS]) {

@@ -360,3 +360,30 @@ def test_set_too_large_and_capacity_errors(tmx):
         with pytest.raises(tmx.TmxError) as e:
             ctx.witness_batch(0, bytes(bad), wl.targets, wl.trusteds)
         assert e.value.status == -2
+
+
+def test_validator_sharded_single_proof(tmx, oracle):
+    """BASELINE config 5 path (lanes sharded, one all-gather of the EdDSA lane records, replicated finish) on the ranks
+    available here (world_size 1 over RCCL); the 2-rank exchange logic is covered on CPU by tests/test_sharding_gloo.py."""
+    import torch
+    import torch.distributed as dist
+    from tendermintx_amd import sharding
+    from tendermintx_amd.synth import Workload
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n = 512
+        wl = Workload(0, n, 1, 400, chain_id=b"celestia", seed=2024, signed_permille=900)
+        d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) for b in (wl.proofs, wl.targets, wl.trusteds)]
+        with tmx.Context(n, b"celestia", max_batch=1) as ctx:
+            elems, rep = sharding.validator_sharded_skip(ctx, 0, d[0], d[1], d[2])
+            torch.cuda.synchronize(dev)
+            got = elems.cpu().numpy().view(np.uint64)
+        want, orep = oracle.witness(0, wl.proofs, wl.targets, wl.trusteds, b"celestia", 100800)
+        assert np.array_equal(got, want) and orep["all_ok"]
+        assert bytes(rep.cpu().numpy()[:32]) == orep["header"]
+    finally:
+        dist.destroy_process_group()
