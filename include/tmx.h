@@ -150,8 +150,9 @@ int32_t tmx_witness_batch(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const t
                           uint64_t cap_elems, tmx_report* reports);
 
 /* ---- device-resident entry point: inputs already in HBM, outputs stay in HBM.  All pointers are device
- * pointers of the context's device; `hip_stream` is a hipStream_t (NULL = the context's own stream).  Asynchronous:
- * returns after enqueueing; order against it with the stream. */
+ * pointers of the context's device; `hip_stream` is the hipStream_t to enqueue on, used exactly as passed (NULL = the HIP
+ * default stream; tmx_ctx_stream() = the context's own stream).  Asynchronous: returns after enqueueing. */
+void* tmx_ctx_stream(tmx_ctx* ctx);
 int32_t tmx_witness_batch_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
                                  const void* d_trusteds, void* d_out_elems, void* d_reports, void* hip_stream);
 /* The two halves of the call above, for the validator-sharded single-proof mode (BASELINE config 5): each GPU runs

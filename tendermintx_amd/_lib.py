@@ -7,7 +7,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtmx.so")
+LIB_PATH = os.environ.get("TMX_LIB") or os.path.join(_HERE, "libtmx.so")
 
 KIND_SKIP, KIND_STEP = 0, 1
 FLAG_SIGNED, FLAG_PRESENT = 1, 2
@@ -125,6 +125,8 @@ def lib():
                                           C.c_void_p, C.c_void_p, C.c_void_p]
     L.tmx_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.tmx_kernel_ms_mean.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
+    L.tmx_ctx_stream.restype = C.c_void_p
+    L.tmx_ctx_stream.argtypes = [C.c_void_p]
     L.tmx_sync.argtypes = [C.c_void_p]
     L.tmx_eddsa_lanes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.tmx_skip_inputs_from_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64,

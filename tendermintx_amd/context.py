@@ -81,15 +81,20 @@ class Context:
         return out.reshape(n, _lib.ED_STRIDE)
 
     # ---- device-resident path (raw device pointers, e.g. torch tensors' data_ptr())
+    def _stream(self, stream):
+        """stream=None -> the context's own stream; an int (e.g. torch.cuda.current_stream().cuda_stream, 0 = the HIP default
+        stream) is used exactly as given."""
+        return self._L.tmx_ctx_stream(self._h) if stream is None else (stream or None)
+
     def witness_batch_device(self, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports, stream=None):
-        check(self._L.tmx_witness_batch_device(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports, stream),
-              self._h)
+        check(self._L.tmx_witness_batch_device(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports,
+                                               self._stream(stream)), self._h)
 
     def eddsa_lanes_device(self, n_lanes, d_lanes, d_ed_out, stream=None):
-        check(self._L.tmx_eddsa_lanes_device(self._h, n_lanes, d_lanes, d_ed_out, stream), self._h)
+        check(self._L.tmx_eddsa_lanes_device(self._h, n_lanes, d_lanes, d_ed_out, self._stream(stream)), self._h)
 
     def finish_batch_device(self, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_ed, d_out, d_reports, stream=None):
-        check(self._L.tmx_finish_batch_device(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_ed, d_out, d_reports, stream),
+        check(self._L.tmx_finish_batch_device(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_ed, d_out, d_reports, self._stream(stream)),
               self._h)
 
     def last_kernel_ms(self):

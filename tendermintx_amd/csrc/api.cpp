@@ -7,6 +7,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -34,18 +35,18 @@ static_assert(TMX_N_MAX_LIMIT == TMX_N_LIMIT, "n_max limit");
 // followed by the derived section D (DESIGN.md "Witness layout").
 namespace {
 
-struct LutBuilder {
+struct LutBuilder {  // offsets are relative to the section's single source record
   std::vector<uint32_t> v;
-  void bytes(uint32_t src, uint32_t off, uint32_t n) {
+  void bytes(uint32_t off, uint32_t n) {
     for (uint32_t i = 0; i < n; i++)
-      for (uint32_t k = 0; k < 8; k++) v.push_back(lut_entry(src, CODE_BIT0 + k, off + i));
+      for (uint32_t k = 0; k < 8; k++) v.push_back(lut_entry(CODE_BIT0 + k, off + i));
   }
-  void u8(uint32_t src, uint32_t off) { v.push_back(lut_entry(src, CODE_U8, off)); }
-  void u16(uint32_t src, uint32_t off) { v.push_back(lut_entry(src, CODE_U16, off)); }
-  void u32(uint32_t src, uint32_t off) { v.push_back(lut_entry(src, CODE_U32, off)); }
-  void u64(uint32_t src, uint32_t off) { u32(src, off); u32(src, off + 4); }
-  void u256(uint32_t src, uint32_t off) { for (uint32_t k = 0; k < 8; k++) u32(src, off + 4 * k); }
-  void flag0(uint32_t src, uint32_t off) { v.push_back(lut_entry(src, CODE_FLAG0, off)); }
+  void u8(uint32_t off) { v.push_back(lut_entry(CODE_U8, off)); }
+  void u16(uint32_t off) { v.push_back(lut_entry(CODE_U16, off)); }
+  void u32(uint32_t off) { v.push_back(lut_entry(CODE_U32, off)); }
+  void u64(uint32_t off) { u32(off); u32(off + 4); }
+  void u256(uint32_t off) { for (uint32_t k = 0; k < 8; k++) u32(off + 4 * k); }
+  void flag0(uint32_t off) { v.push_back(lut_entry(CODE_FLAG0, off)); }
 };
 
 uint32_t tree_nodes(uint32_t n) {
@@ -56,15 +57,16 @@ uint32_t tree_nodes(uint32_t n) {
 
 // MerkleInclusionProofVariable<4, LEAF>: proof[4] (Bytes32 each) then leaf bytes  (variables.rs:58-62)
 void emit_inclusion_proof(LutBuilder& L, int q, uint32_t leaf_src_off, uint32_t leaf_size) {
-  L.bytes(SRC_PF, PF_OFF_AUNTS + 128 * q, 128);
-  L.bytes(SRC_PF, leaf_src_off, leaf_size);
+  L.bytes(PF_OFF_AUNTS + 128 * q, 128);
+  L.bytes(leaf_src_off, leaf_size);
 }
 // derived: leaf hash + the four path nodes of proof q
-void emit_proof_d(LutBuilder& L, int q) { L.bytes(SRC_PF, PF_OFF_PROOFD + 160 * q, 160); }
+void emit_proof_d(LutBuilder& L, int q) { L.bytes(PF_OFF_PROOFD + 160 * q, 160); }
 
 struct Program {
   SerializeProgram sp;
   std::vector<uint32_t> lut;
+  std::vector<uint8_t> wave_sec;  // per 128-element span of a row: its section, or 0xff if it straddles a boundary / the row end
   uint32_t hint_elems;
 };
 
@@ -75,117 +77,129 @@ Program build_program(int kind, uint32_t n) {
   const bool skip = kind == TMX_KIND_SKIP;
   const uint32_t tn = tree_nodes(n);
   uint32_t elem = 0;
-  auto add_section = [&](uint32_t lane_elems, uint32_t n_lanes, uint32_t lut_off, uint32_t kind_) {
+  auto add_section = [&](uint32_t lane_elems, uint32_t n_lanes, uint32_t lut_off, uint32_t kind_, uint32_t src) {
     Section& s = P.sp.sec[P.sp.n_sections++];
-    s.elem_start = elem; s.lane_elems = lane_elems; s.n_lanes = n_lanes; s.lut_off = lut_off; s.kind = kind_;
+    s.elem_start = elem; s.lane_elems = lane_elems; s.n_lanes = n_lanes; s.lut_off = lut_off; s.kind = kind_; s.src = src;
+    s.magic = (uint32_t)((0x100000000ull + lane_elems - 1) / lane_elems);  // lane = mulhi(rel, magic); rel * lane_elems < 2^32 here
+    s.pad = 0;
     elem += lane_elems * n_lanes;
   };
   uint32_t mark;
 
   // H.1 target_header / next_header : Bytes32
   mark = (uint32_t)L.v.size();
-  L.bytes(SRC_PF, PF_OFF_HEADER, 32);
-  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT);
+  L.bytes(PF_OFF_HEADER, 32);
+  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT, SRC_PF);
 
   // H.2 validators[N] : ValidatorVariable (variables.rs:69-79) = pubkey, signature{r, s}, message[124],
   //     message_byte_length, voting_power, validator_byte_length, signed
   mark = (uint32_t)L.v.size();
-  L.bytes(SRC_TARGET, VR_OFF_PK, 32);
-  L.bytes(SRC_TARGET, VR_OFF_SIG, 32);
-  L.u256(SRC_TARGET, VR_OFF_SIG + 32);
-  L.bytes(SRC_TARGET, VR_OFF_MSG, 124);
-  L.u16(SRC_TARGET, VR_OFF_MLEN);
-  L.u64(SRC_TARGET, VR_OFF_POWER);
-  L.u8(SRC_TARGET, VR_OFF_VLEN);
-  L.flag0(SRC_TARGET, VR_OFF_FLAGS);
-  add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT);
+  L.bytes(VR_OFF_PK, 32);
+  L.bytes(VR_OFF_SIG, 32);
+  L.u256(VR_OFF_SIG + 32);
+  L.bytes(VR_OFF_MSG, 124);
+  L.u16(VR_OFF_MLEN);
+  L.u64(VR_OFF_POWER);
+  L.u8(VR_OFF_VLEN);
+  L.flag0(VR_OFF_FLAGS);
+  add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_TARGET);
 
   // H.3 nb_validators, round, ChainIdProofVariable, HeightProofVariable, validators-hash proof, then
   //     skip: trusted nb + trusted validators-hash proof ; step: last_block_id proof + prev next_validators_hash proof
   mark = (uint32_t)L.v.size();
-  L.u32(SRC_PROOF, PR_OFF_NB_A);
-  L.u64(SRC_PROOF, PR_OFF_ROUND);
-  L.bytes(SRC_PF, PF_OFF_AUNTS + 128 * 0, 128);   // chain_id_proof.proof
-  L.u32(SRC_PF, PF_OFF_CIDLEN);                   // enc_chain_id_byte_length
-  L.bytes(SRC_PF, PF_OFF_CID52, 52);              // chain_id
-  L.bytes(SRC_PF, PF_OFF_AUNTS + 128 * 1, 128);   // height_proof.proof
-  L.u32(SRC_PF, PF_OFF_HLEN);                     // enc_height_byte_length
-  L.u64(SRC_PF, PF_OFF_HEIGHT);                   // height
+  L.u32(PF_OFF_NB_A);
+  L.u64(PF_OFF_ROUND);
+  L.bytes(PF_OFF_AUNTS + 128 * 0, 128);   // chain_id_proof.proof
+  L.u32(PF_OFF_CIDLEN);                   // enc_chain_id_byte_length
+  L.bytes(PF_OFF_CID52, 52);              // chain_id
+  L.bytes(PF_OFF_AUNTS + 128 * 1, 128);   // height_proof.proof
+  L.u32(PF_OFF_HLEN);                     // enc_height_byte_length
+  L.u64(PF_OFF_HEIGHT);                   // height
   emit_inclusion_proof(L, 2, PF_OFF_LEAFV, 34);
   if (skip) {
-    L.u32(SRC_PROOF, PR_OFF_NB_B);
+    L.u32(PF_OFF_NB_B);
     emit_inclusion_proof(L, 3, PF_OFF_LEAFX, 34);
   } else {
     emit_inclusion_proof(L, 3, PF_OFF_LEAFX, 72);
     emit_inclusion_proof(L, 4, PF_OFF_LEAFY, 34);
   }
-  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT);
+  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT, SRC_PF);
 
   // H.4 skip: trusted_header_validator_hash_fields[N] : ValidatorHashFieldVariable (variables.rs:82-88)
   if (skip) {
     mark = (uint32_t)L.v.size();
-    L.bytes(SRC_TRUSTED, HR_OFF_PK, 32);
-    L.u64(SRC_TRUSTED, HR_OFF_POWER);
-    L.u8(SRC_TRUSTED, HR_OFF_VLEN);
-    add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT);
+    L.bytes(HR_OFF_PK, 32);
+    L.u64(HR_OFF_POWER);
+    L.u8(HR_OFF_VLEN);
+    add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_TRUSTED);
   }
   P.hint_elems = elem;
 
   // D.1 per target lane
   mark = (uint32_t)L.v.size();
-  L.bytes(SRC_LT, LN_OFF_MARSHAL, 46);
-  L.bytes(SRC_LT, LN_OFF_LEAF, 32);
-  L.bytes(SRC_ED, ED_OFF_DIGEST, 64);
-  L.u256(SRC_ED, ED_OFF_H);
-  for (int p = 0; p < 10; p++) L.u256(SRC_ED, ED_OFF_PTS + 32 * p);
-  L.u32(SRC_ED, ED_OFF_OK);
-  for (int f = 0; f < 6; f++) L.u8(SRC_LT, LN_OFF_FLAGS + f);
-  L.u64(SRC_LT, LN_OFF_TOT);
-  L.u64(SRC_LT, LN_OFF_ACC);
-  add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT);
+  L.bytes(TL_OFF_LT + LN_OFF_MARSHAL, 46);
+  L.bytes(TL_OFF_LT + LN_OFF_LEAF, 32);
+  L.bytes(TL_OFF_ED + ED_OFF_DIGEST, 64);
+  L.u256(TL_OFF_ED + ED_OFF_H);
+  for (int p = 0; p < 10; p++) L.u256(TL_OFF_ED + ED_OFF_PTS + 32 * p);
+  L.u32(TL_OFF_ED + ED_OFF_OK);
+  for (int f = 0; f < 6; f++) L.u8(TL_OFF_LT + LN_OFF_FLAGS + f);
+  L.u64(TL_OFF_LT + LN_OFF_TOT);
+  L.u64(TL_OFF_LT + LN_OFF_ACC);
+  add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_TL);
 
   // D.2 per trusted lane
   if (skip) {
     mark = (uint32_t)L.v.size();
-    L.bytes(SRC_LR, LN_OFF_MARSHAL, 46);
-    L.bytes(SRC_LR, LN_OFF_LEAF, 32);
-    L.u8(SRC_LR, LN_OFF_FLAGS);
-    L.u8(SRC_LR, LN_OFF_FLAGS + 1);
-    L.u64(SRC_LR, LN_OFF_TOT);
-    L.u64(SRC_LR, LN_OFF_ACC);
-    add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT);
+    L.bytes(LN_OFF_MARSHAL, 46);
+    L.bytes(LN_OFF_LEAF, 32);
+    L.u8(LN_OFF_FLAGS);
+    L.u8(LN_OFF_FLAGS + 1);
+    L.u64(LN_OFF_TOT);
+    L.u64(LN_OFF_ACC);
+    add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_LR);
   }
   // D.3 / D.4 tree nodes
   if (tn) {
-    add_section(tn * 256, 1, 0, SEC_LINEAR_T);
-    if (skip) add_section(tn * 256, 1, 0, SEC_LINEAR_R);
+    add_section(tn * 256, 1, 0, SEC_LINEAR_T, SRC_PF);
+    if (skip) add_section(tn * 256, 1, 0, SEC_LINEAR_R, SRC_PF);
   }
   // D.5 header proofs, tallies, checks, verdict
   mark = (uint32_t)L.v.size();
   emit_proof_d(L, 0);
-  L.bytes(SRC_PF, PF_OFF_HLEAF, 11);
+  L.bytes(PF_OFF_HLEAF, 11);
   emit_proof_d(L, 1);
   emit_proof_d(L, 2);
   emit_proof_d(L, 3);
   if (!skip) emit_proof_d(L, 4);
-  for (int k = 0; k < 4; k++) L.u64(SRC_PF, PF_OFF_TALLY_T + 8 * k);
-  L.u32(SRC_PF, PF_OFF_VERDICTS);
+  for (int k = 0; k < 4; k++) L.u64(PF_OFF_TALLY_T + 8 * k);
+  L.u32(PF_OFF_VERDICTS);
   if (skip) {
-    for (int k = 0; k < 4; k++) L.u64(SRC_PF, PF_OFF_TALLY_R + 8 * k);
-    L.u32(SRC_PF, PF_OFF_VERDICTS + 4);
-    L.u32(SRC_PF, PF_OFF_VERDICTS + 8);
-    L.u32(SRC_PF, PF_OFF_VERDICTS + 12);
+    for (int k = 0; k < 4; k++) L.u64(PF_OFF_TALLY_R + 8 * k);
+    L.u32(PF_OFF_VERDICTS + 4);
+    L.u32(PF_OFF_VERDICTS + 8);
+    L.u32(PF_OFF_VERDICTS + 12);
   }
   const int n_checks = skip ? 12 : 14;
-  for (int k = 0; k < n_checks; k++) L.u32(SRC_PF, PF_OFF_CHECKS + 4 * k);
-  L.u32(SRC_PF, PF_OFF_ALLOK);
-  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT);
+  for (int k = 0; k < n_checks; k++) L.u32(PF_OFF_CHECKS + 4 * k);
+  L.u32(PF_OFF_ALLOK);
+  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT, SRC_PF);
 
   P.sp.elem_count = elem;
   P.sp.elem_stride = (elem + 1) & ~1u;
   P.sp.n = n;
   P.sp.tree_nodes = tn;
   P.lut = std::move(L.v);
+  for (uint32_t w = 0; w * 128 < P.sp.elem_stride; w++) {
+    const uint32_t first = w * 128, last = first + 127;
+    uint8_t sec = 0xff;
+    if (last < P.sp.elem_count)
+      for (uint32_t s = 0; s < P.sp.n_sections; s++) {
+        const uint32_t lo = P.sp.sec[s].elem_start, hi = lo + P.sp.sec[s].lane_elems * P.sp.sec[s].n_lanes;
+        if (first >= lo && last < hi) sec = (uint8_t)s;
+      }
+    P.wave_sec.push_back(sec);
+  }
   return P;
 }
 
@@ -203,9 +217,12 @@ struct tmx_ctx {
   uint64_t n_calls = 0;
   Program prog[2];
   void* d_lut[2] = {nullptr, nullptr};
+  void* d_wave_sec[2] = {nullptr, nullptr};
   void* d_table = nullptr;
+  void *d_qtable = nullptr, *d_pre = nullptr, *d_mulout = nullptr;
+  bool quad = true;  // TMX_EDDSA=mono selects the first-generation one-lane-per-thread kernel (kept for A/B runs)
   // scratch sized for cfg.max_batch proofs
-  void *d_ed = nullptr, *d_lt = nullptr, *d_lr = nullptr, *d_pf = nullptr, *d_nodes_t = nullptr, *d_nodes_r = nullptr, *d_reports = nullptr;
+  void *d_ed = nullptr, *d_tl = nullptr, *d_lr = nullptr, *d_pf = nullptr, *d_nodes_t = nullptr, *d_nodes_r = nullptr, *d_reports = nullptr;
   // staging for the host-buffer entry points
   void *d_in_proofs = nullptr, *d_in_targets = nullptr, *d_in_trusteds = nullptr, *d_out = nullptr;
   uint64_t d_out_elems = 0;
@@ -254,7 +271,7 @@ const char* tmx_last_error(const tmx_ctx* ctx) { return ctx ? ctx->err.c_str() :
 
 void tmx_ctx_destroy(tmx_ctx* c) {
   if (!c) return;
-  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_table, c->d_ed, c->d_lt, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
+  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
                   c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -287,10 +304,12 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     if (c->prog[k].sp.elem_count != tmx_elem_count(k, n)) return fail(c, TMX_ERR_BAD_ARG, "internal: layout size mismatch");
     HIPCK(c, hipMalloc(&c->d_lut[k], c->prog[k].lut.size() * 4));
     HIPCK(c, hipMemcpyAsync(c->d_lut[k], c->prog[k].lut.data(), c->prog[k].lut.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMalloc(&c->d_wave_sec[k], c->prog[k].wave_sec.size()));
+    HIPCK(c, hipMemcpyAsync(c->d_wave_sec[k], c->prog[k].wave_sec.data(), c->prog[k].wave_sec.size(), hipMemcpyHostToDevice, c->stream));
   }
   HIPCK(c, hipMalloc(&c->d_table, base_table_bytes()));
   HIPCK(c, hipMalloc(&c->d_ed, lanes * ED_STRIDE));
-  HIPCK(c, hipMalloc(&c->d_lt, lanes * LANE_STRIDE));
+  HIPCK(c, hipMalloc(&c->d_tl, lanes * TL_STRIDE));
   HIPCK(c, hipMalloc(&c->d_lr, lanes * LANE_STRIDE));
   HIPCK(c, hipMalloc(&c->d_pf, B * PF_STRIDE));
   const size_t tn = tree_nodes(n);
@@ -299,9 +318,18 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   HIPCK(c, hipMalloc(&c->d_reports, B * sizeof(tmx_report)));
   int rc = launch_init_base(c->d_table, c->stream);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_init_base launch: ") + hipGetErrorString((hipError_t)rc));
+  const char* mode = std::getenv("TMX_EDDSA");
+  c->quad = !(mode && std::string(mode) == "mono");
+  HIPCK(c, hipMalloc(&c->d_qtable, quad_table_bytes()));
+  HIPCK(c, hipMalloc(&c->d_pre, lanes * pre_bytes_per_lane()));
+  HIPCK(c, hipMalloc(&c->d_mulout, lanes * mulout_bytes_per_lane()));
+  rc = launch_init_base_quad(c->d_table, c->d_qtable, c->stream);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_init_base_quad launch: ") + hipGetErrorString((hipError_t)rc));
   HIPCK(c, hipStreamSynchronize(c->stream));
   return TMX_OK;
 }
+
+void* tmx_ctx_stream(tmx_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) : nullptr; }
 
 int32_t tmx_sync(tmx_ctx* c) {
   if (!c) return TMX_ERR_BAD_ARG;
@@ -309,31 +337,37 @@ int32_t tmx_sync(tmx_ctx* c) {
   return TMX_OK;
 }
 
-// k_proof + k_serialize over caller-visible EdDSA lane records (d_ed); ev[1..3] are recorded here
+// k_proof + k_serialize; the EdDSA lane records are already in the ED part of c->d_tl.  ev[1..3] are recorded here
 static int32_t finish_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets, const void* d_trusteds,
-                            const void* d_ed, void* d_out_elems, void* d_reports, hipStream_t s, hipEvent_t* ev) {
+                            void* d_out_elems, void* d_reports, hipStream_t s, hipEvent_t* ev) {
   const uint32_t n = c->cfg.n_max;
+  uint8_t* tl = reinterpret_cast<uint8_t*>(c->d_tl);
   ProofParams P;
   std::memset(&P, 0, sizeof P);
   P.kind = (uint32_t)kind; P.n = n; P.tree_nodes = tree_nodes(n); P.chain_id_len = c->cfg.chain_id_len; P.skip_max = c->cfg.skip_max;
   std::memcpy(P.chain_id, c->cfg.chain_id, sizeof P.chain_id);
   void* reports = d_reports ? d_reports : c->d_reports;
-  int rc = launch_proof(P, n_proofs, d_proofs, d_targets, d_trusteds, d_ed, c->d_lt, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r, reports, s);
+  int rc = launch_proof(P, n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_ED, TL_STRIDE, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf,
+                        c->d_nodes_t, c->d_nodes_r, reports, s);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_proof launch: ") + hipGetErrorString((hipError_t)rc));
   HIPCK(c, hipEventRecord(ev[2], s));
   if (d_out_elems) {
     SerializeSources src;
     std::memset(&src, 0, sizeof src);
-    src.base[SRC_PROOF] = (const uint8_t*)d_proofs; src.base[SRC_TARGET] = (const uint8_t*)d_targets;
-    src.base[SRC_TRUSTED] = (const uint8_t*)d_trusteds; src.base[SRC_ED] = (const uint8_t*)d_ed;
-    src.base[SRC_LT] = (const uint8_t*)c->d_lt; src.base[SRC_LR] = (const uint8_t*)c->d_lr; src.base[SRC_PF] = (const uint8_t*)c->d_pf;
+    src.base[SRC_TARGET] = (const uint8_t*)d_targets; src.base[SRC_TRUSTED] = (const uint8_t*)d_trusteds;
+    src.base[SRC_TL] = tl; src.base[SRC_LR] = (const uint8_t*)c->d_lr; src.base[SRC_PF] = (const uint8_t*)c->d_pf;
     src.nodes_t = (const uint8_t*)c->d_nodes_t; src.nodes_r = (const uint8_t*)c->d_nodes_r;
-    rc = launch_serialize(c->prog[kind].sp, src, c->d_lut[kind], n_proofs, d_out_elems, s);
+    rc = launch_serialize(c->prog[kind].sp, src, c->d_lut[kind], c->d_wave_sec[kind], n_proofs, d_out_elems, s);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_serialize launch: ") + hipGetErrorString((hipError_t)rc));
   }
   HIPCK(c, hipEventRecord(ev[3], s));
   c->n_calls++;
   return TMX_OK;
+}
+
+static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_ed, uint32_t ed_stride, hipStream_t s) {
+  return c->quad ? launch_eddsa_quad(n_lanes, d_lanes, d_ed, ed_stride, c->d_qtable, c->d_pre, c->d_mulout, s)
+                 : launch_eddsa(n_lanes, d_lanes, d_ed, ed_stride, c->d_table, s);
 }
 
 static int32_t check_batch_args(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets, const void* d_trusteds) {
@@ -348,20 +382,21 @@ int32_t tmx_witness_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, co
   int32_t st = check_batch_args(c, kind, n_proofs, d_proofs, d_targets, d_trusteds);
   if (st) return st;
   if (n_proofs == 0) return TMX_OK;
-  hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->stream;
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = the HIP default stream, exactly as passed
   hipEvent_t* ev = c->ev[c->n_calls % tmx_ctx::EV_RING];
   HIPCK(c, hipEventRecord(ev[0], s));
-  int rc = launch_eddsa(n_proofs * c->cfg.n_max, d_targets, c->d_ed, c->d_table, s);
+  int rc = run_eddsa(c, n_proofs * c->cfg.n_max, d_targets, reinterpret_cast<uint8_t*>(c->d_tl) + TL_OFF_ED, TL_STRIDE, s);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_eddsa launch: ") + hipGetErrorString((hipError_t)rc));
   HIPCK(c, hipEventRecord(ev[1], s));
-  return finish_batch(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, c->d_ed, d_out_elems, d_reports, s, ev);
+  return finish_batch(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out_elems, d_reports, s, ev);
 }
 
 int32_t tmx_eddsa_lanes_device(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_ed_out, void* hip_stream) {
   if (!c || !d_lanes || !d_ed_out) return TMX_ERR_BAD_ARG;
   if (n_lanes == 0) return TMX_OK;
-  hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->stream;
-  int rc = launch_eddsa(n_lanes, d_lanes, d_ed_out, c->d_table, s);
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = the HIP default stream, exactly as passed
+  if ((uint64_t)n_lanes > (uint64_t)c->cfg.max_batch * c->cfg.n_max) return fail(c, TMX_ERR_CAPACITY, "n_lanes exceeds max_batch * n_max");
+  int rc = run_eddsa(c, n_lanes, d_lanes, d_ed_out, ED_STRIDE, s);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_eddsa launch: ") + hipGetErrorString((hipError_t)rc));
   return TMX_OK;
 }
@@ -372,11 +407,14 @@ int32_t tmx_finish_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, con
   if (st) return st;
   if (!d_ed) return TMX_ERR_BAD_ARG;
   if (n_proofs == 0) return TMX_OK;
-  hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->stream;
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = the HIP default stream, exactly as passed
   hipEvent_t* ev = c->ev[c->n_calls % tmx_ctx::EV_RING];
   HIPCK(c, hipEventRecord(ev[0], s));
+  // caller's records are 448 B apart; place them into the ED part of the unified per-lane records
+  HIPCK(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(c->d_tl) + TL_OFF_ED, TL_STRIDE, d_ed, ED_STRIDE, ED_STRIDE,
+                            (size_t)n_proofs * c->cfg.n_max, hipMemcpyDeviceToDevice, s));
   HIPCK(c, hipEventRecord(ev[1], s));
-  return finish_batch(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_ed, d_out_elems, d_reports, s, ev);
+  return finish_batch(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out_elems, d_reports, s, ev);
 }
 
 int32_t tmx_kernel_ms_mean(tmx_ctx* c, uint32_t last_k, float ms[TMX_N_KERNELS]) {
@@ -430,7 +468,7 @@ int32_t tmx_witness_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const tmx
   if (kind == TMX_KIND_SKIP)
     HIPCK(c, hipMemcpyAsync(c->d_in_trusteds, trusteds, lanes * sizeof(tmx_hashfield_rec), hipMemcpyHostToDevice, c->stream));
   st = tmx_witness_batch_device(c, kind, n_proofs, c->d_in_proofs, c->d_in_targets, kind == TMX_KIND_SKIP ? c->d_in_trusteds : nullptr,
-                                out_elems ? c->d_out : nullptr, c->d_reports, nullptr);
+                                out_elems ? c->d_out : nullptr, c->d_reports, c->stream);
   if (st) return st;
   if (out_elems) {
     // rows are stride apart on the device; the last row is copied without its pad element
@@ -458,7 +496,7 @@ int32_t tmx_eddsa_lanes(tmx_ctx* c, uint32_t n_lanes, const tmx_validator_rec* l
   int32_t st = ensure_staging(c);
   if (st) return st;
   HIPCK(c, hipMemcpyAsync(c->d_in_targets, lanes, (size_t)n_lanes * sizeof(tmx_validator_rec), hipMemcpyHostToDevice, c->stream));
-  int rc = launch_eddsa(n_lanes, c->d_in_targets, c->d_ed, c->d_table, c->stream);
+  int rc = run_eddsa(c, n_lanes, c->d_in_targets, c->d_ed, ED_STRIDE, c->stream);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_eddsa launch: ") + hipGetErrorString((hipError_t)rc));
   HIPCK(c, hipMemcpyAsync(out, c->d_ed, (size_t)n_lanes * ED_STRIDE, hipMemcpyDeviceToHost, c->stream));
   HIPCK(c, hipStreamSynchronize(c->stream));

@@ -11,7 +11,10 @@ constexpr uint32_t TMX_N_LIMIT = 512;  // largest VALIDATOR_SET_SIZE_MAX (LDS si
 constexpr uint32_t ED_STRIDE = 448;  // digest[64] h[32] pts[10][32] ok u32 decode_ok u32 pad
 constexpr uint32_t ED_OFF_DIGEST = 0, ED_OFF_H = 64, ED_OFF_PTS = 96, ED_OFF_OK = 416, ED_OFF_DECODE_OK = 420;
 
-constexpr uint32_t LANE_STRIDE = 112;  // derived per-lane record (target and trusted sets alike)
+// k_eddsa and k_proof write into ONE record per target lane (TL = ED part | LT part) so that the serializer reads every
+// per-lane section from a single source: base pointer and stride are then wave-uniform (SGPRs).
+constexpr uint32_t TL_STRIDE = 560, TL_OFF_ED = 0, TL_OFF_LT = 448;
+constexpr uint32_t LANE_STRIDE = 112;  // derived per-lane part (LT inside TL; LR = the trusted set's own buffer)
 constexpr uint32_t LN_OFF_MARSHAL = 0, LN_OFF_LEAF = 48, LN_OFF_FLAGS = 80, LN_OFF_TOT = 88, LN_OFF_ACC = 96;
 // target flags bytes: [0] enabled [1] hash_in_msg [2] is_precommit [3] height_ok [4] round_ok [5] sigdata_ok
 // trusted flags bytes: [0] enabled [1] matched
@@ -33,6 +36,7 @@ constexpr uint32_t PF_OFF_CID52 = 1664;     // chain-id leaf zero-padded to 52
 constexpr uint32_t PF_OFF_LEAFV = 1728;     // header_a leaf 7 padded to 34
 constexpr uint32_t PF_OFF_LEAFX = 1776;     // skip: header_b leaf 7 (34) ; step: header_a leaf 4 (72)
 constexpr uint32_t PF_OFF_LEAFY = 1856;     // step: header_b leaf 8 (34)
+constexpr uint32_t PF_OFF_NB_A = 1656, PF_OFF_NB_B = 1660, PF_OFF_ROUND = 1896;  // copies of proof-record fields (hint elements)
 
 // ---- input record offsets (include/tmx.h structs, as raw bytes)
 constexpr uint32_t VR_STRIDE = 256, VR_OFF_PK = 0, VR_OFF_SIG = 32, VR_OFF_MSG = 96, VR_OFF_MLEN = 220, VR_OFF_VLEN = 222,
@@ -42,10 +46,10 @@ constexpr uint32_t HDR_SIZE = 1136, PR_STRIDE = 2336, PR_OFF_BLOCK_A = 0, PR_OFF
                    PR_OFF_NB_A = 56, PR_OFF_NB_B = 60, PR_OFF_HDR_A = 64, PR_OFF_HDR_B = 64 + HDR_SIZE;
 
 // ---- serializer program: the element stream is a list of sections; fixed and per-lane sections are driven by
-// look-up tables with one u32 per element:  src[31:29] | code[28:24] | byte offset[23:0]
-enum : uint32_t { SRC_PROOF = 0, SRC_TARGET = 1, SRC_TRUSTED = 2, SRC_ED = 3, SRC_LT = 4, SRC_LR = 5, SRC_PF = 6, SRC_COUNT = 7 };
+// look-up tables with one u32 per element:  code[28:24] | byte offset[23:0]; every section reads ONE source buffer
+enum : uint32_t { SRC_TARGET = 0, SRC_TRUSTED = 1, SRC_TL = 2, SRC_LR = 3, SRC_PF = 4, SRC_COUNT = 5 };
 enum : uint32_t { CODE_BIT0 = 0 /* ..7: BE bit k of the byte */, CODE_U8 = 8, CODE_U16 = 9, CODE_U32 = 10, CODE_FLAG0 = 11 /* byte&1 */ };
-constexpr uint32_t lut_entry(uint32_t src, uint32_t code, uint32_t off) { return (src << 29) | (code << 24) | off; }
+constexpr uint32_t lut_entry(uint32_t code, uint32_t off) { return (code << 24) | off; }
 
 enum : uint32_t { SEC_LUT = 0, SEC_LINEAR_T = 1, SEC_LINEAR_R = 2 };
 struct Section {
@@ -54,6 +58,9 @@ struct Section {
   uint32_t n_lanes;     // 1 for fixed sections
   uint32_t lut_off;     // index into the LUT array (SEC_LUT)
   uint32_t kind;
+  uint32_t src;         // SRC_* buffer this section reads
+  uint32_t magic;       // ceil(2^32 / lane_elems): lane = mulhi(rel, magic), exact for rel * lane_elems < 2^32
+  uint32_t pad;
 };
 constexpr int MAX_SECTIONS = 10;
 struct SerializeProgram {

@@ -58,7 +58,7 @@ def make_gpu_eddsa_fn(ctx, stream=None):
     def fn(lanes):
         lanes = lanes.contiguous()
         out = torch.empty((lanes.shape[0], ED_STRIDE), dtype=torch.uint8, device=lanes.device)
-        s = stream if stream is not None else torch.cuda.current_stream(lanes.device).cuda_stream
+        s = stream if stream is not None else int(torch.cuda.current_stream(lanes.device).cuda_stream)
         ctx.eddsa_lanes_device(lanes.shape[0], lanes.data_ptr(), out.data_ptr(), s)
         return out
     return fn
@@ -72,7 +72,7 @@ def validator_sharded_skip(ctx, kind, proof, target, trusted, group=None):
     ed = validator_sharded_eddsa(target.view(n, 256), make_gpu_eddsa_fn(ctx), group).contiguous()
     out = torch.zeros(ctx.elem_stride(kind), dtype=torch.int64, device=dev)
     rep = torch.zeros(64, dtype=torch.uint8, device=dev)
-    s = torch.cuda.current_stream(dev).cuda_stream
+    s = int(torch.cuda.current_stream(dev).cuda_stream)
     ctx.finish_batch_device(kind, 1, proof.data_ptr(), target.data_ptr(), trusted.data_ptr() if trusted is not None else None,
                             ed.data_ptr(), out.data_ptr(), rep.data_ptr(), s)
     return out[:ctx.elem_count(kind)], rep
