@@ -119,10 +119,12 @@ typedef struct {
 typedef struct tmx_ctx tmx_ctx;
 
 /* names of the kernels timed by tmx_last_kernel_ms, in launch order */
-#define TMX_N_KERNELS 3
-#define TMX_K_EDDSA 0     /* per-validator Ed25519: SHA-512, decode, s*B, h*A, R+hA, affine */
-#define TMX_K_PROOF 1     /* marshal + SHA-256 leaves + Merkle trees + header proofs + NxN match + tallies */
-#define TMX_K_SERIALIZE 2 /* Goldilocks element fill */
+#define TMX_N_KERNELS 4
+#define TMX_K_EDDSA 0     /* per-validator Ed25519 (k_ed_pre, k_ed_mul, k_ed_fin): SHA-512, decode, s*B, h*A, R+hA, affine */
+#define TMX_K_PROOF 1     /* k_proof on the context's side stream, concurrent with the EdDSA kernels: marshal + SHA-256 leaves +
+                             Merkle trees + header proofs + NxN match + tallies */
+#define TMX_K_VERDICT 2   /* join: wait for k_proof, merge the per-lane EdDSA verdicts (k_verdict) */
+#define TMX_K_SERIALIZE 3 /* Goldilocks element fill */
 
 uint32_t tmx_version(void);
 const char* tmx_status_str(int32_t status);

@@ -11,8 +11,8 @@ LIB_PATH = os.environ.get("TMX_LIB") or os.path.join(_HERE, "libtmx.so")
 
 KIND_SKIP, KIND_STEP = 0, 1
 FLAG_SIGNED, FLAG_PRESENT = 1, 2
-N_KERNELS = 3
-KERNEL_NAMES = ("k_eddsa", "k_proof", "k_serialize")
+N_KERNELS = 4
+KERNEL_NAMES = ("k_eddsa", "k_proof", "k_verdict", "k_serialize")
 ED_STRIDE = 448
 
 

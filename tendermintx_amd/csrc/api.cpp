@@ -206,14 +206,18 @@ Program build_program(int kind, uint32_t n) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ context
+constexpr int EV_RING_DECL = 128;
 struct tmx_ctx {
   tmx_config cfg;
   std::string err;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;  // k_proof runs here, concurrently with the EdDSA kernels of the caller's stream
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_side[EV_RING_DECL][2] = {};
   // ring of HIP-event sets: one set (TMX_N_KERNELS + 1 events) per enqueued batch, so that kernel durations can be
   // averaged over a whole timed region afterwards without synchronising inside it
-  static constexpr int EV_RING = 128;
-  hipEvent_t ev[EV_RING][TMX_N_KERNELS + 1] = {};
+  static constexpr int EV_RING = EV_RING_DECL;
+  hipEvent_t ev[EV_RING][4] = {};
   uint64_t n_calls = 0;
   Program prog[2];
   void* d_lut[2] = {nullptr, nullptr};
@@ -237,6 +241,71 @@ static int32_t fail(tmx_ctx* c, int32_t st, const std::string& msg) {
     hipError_t e_ = (call);                                                                               \
     if (e_ != hipSuccess) return fail(c, TMX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
   } while (0)
+
+static ProofParams proof_params(const tmx_ctx* c, int32_t kind) {
+  ProofParams P;
+  std::memset(&P, 0, sizeof P);
+  P.kind = (uint32_t)kind; P.n = c->cfg.n_max; P.tree_nodes = tree_nodes(c->cfg.n_max); P.chain_id_len = c->cfg.chain_id_len;
+  P.skip_max = c->cfg.skip_max;
+  std::memcpy(P.chain_id, c->cfg.chain_id, sizeof P.chain_id);
+  return P;
+}
+
+// Launch sequence of one batch.  Main stream s:  [ev0] EdDSA kernels [ev1] k_verdict [ev2] k_serialize [ev3]
+//                               side stream:      (after ev_fork) [side0] k_proof [side1] -> ev_join, waited on before k_verdict.
+// k_proof does not depend on the EdDSA results, so it overlaps with them; `ed_producer` enqueues whatever fills the ED part of
+// c->d_tl on s (the EdDSA kernels, or a strided copy of caller-provided lane records).
+template <typename EdProducer>
+static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets, const void* d_trusteds,
+                         void* d_out_elems, void* d_reports, hipStream_t s, EdProducer ed_producer) {
+  const uint32_t n = c->cfg.n_max;
+  uint8_t* tl = reinterpret_cast<uint8_t*>(c->d_tl);
+  void* reports = d_reports ? d_reports : c->d_reports;
+  const uint64_t slot = c->n_calls % tmx_ctx::EV_RING;
+  hipEvent_t* ev = c->ev[slot];
+  hipEvent_t* evs = c->ev_side[slot];
+  HIPCK(c, hipEventRecord(c->ev_fork, s));
+  HIPCK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+  HIPCK(c, hipEventRecord(evs[0], c->side));
+  int rc = launch_proof(proof_params(c, kind), n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf, c->d_nodes_t,
+                        c->d_nodes_r, reports, c->side);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_proof launch: ") + hipGetErrorString((hipError_t)rc));
+  HIPCK(c, hipEventRecord(evs[1], c->side));
+  HIPCK(c, hipEventRecord(c->ev_join, c->side));
+
+  HIPCK(c, hipEventRecord(ev[0], s));
+  int32_t st = ed_producer(s);
+  if (st) return st;
+  HIPCK(c, hipEventRecord(ev[1], s));
+  HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
+  rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, s);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
+  HIPCK(c, hipEventRecord(ev[2], s));
+  if (d_out_elems) {
+    SerializeSources src;
+    std::memset(&src, 0, sizeof src);
+    src.base[SRC_TARGET] = (const uint8_t*)d_targets; src.base[SRC_TRUSTED] = (const uint8_t*)d_trusteds;
+    src.base[SRC_TL] = tl; src.base[SRC_LR] = (const uint8_t*)c->d_lr; src.base[SRC_PF] = (const uint8_t*)c->d_pf;
+    src.nodes_t = (const uint8_t*)c->d_nodes_t; src.nodes_r = (const uint8_t*)c->d_nodes_r;
+    rc = launch_serialize(c->prog[kind].sp, src, c->d_lut[kind], c->d_wave_sec[kind], n_proofs, d_out_elems, s);
+    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_serialize launch: ") + hipGetErrorString((hipError_t)rc));
+  }
+  HIPCK(c, hipEventRecord(ev[3], s));
+  c->n_calls++;
+  return TMX_OK;
+}
+
+static int32_t check_batch_args(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets, const void* d_trusteds) {
+  if (!c || (kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP) || !d_proofs || !d_targets) return TMX_ERR_BAD_ARG;
+  if (kind == TMX_KIND_SKIP && !d_trusteds) return fail(c, TMX_ERR_BAD_ARG, "skip needs the trusted hash fields");
+  if (n_proofs > c->cfg.max_batch) return fail(c, TMX_ERR_CAPACITY, "n_proofs exceeds the context's max_batch");
+  return TMX_OK;
+}
+
+static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_ed, uint32_t ed_stride, hipStream_t s) {
+  return c->quad ? launch_eddsa_quad(n_lanes, d_lanes, d_ed, ed_stride, c->d_qtable, c->d_pre, c->d_mulout, s)
+                 : launch_eddsa(n_lanes, d_lanes, d_ed, ed_stride, c->d_table, s);
+}
 
 extern "C" {
 
@@ -278,6 +347,12 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   for (auto& set : c->ev)
     for (auto& e : set)
       if (e) (void)hipEventDestroy(e);
+  for (auto& set : c->ev_side)
+    for (auto& e : set)
+      if (e) (void)hipEventDestroy(e);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->side) (void)hipStreamDestroy(c->side);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -295,6 +370,11 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   if (cfg->device < 0 || cfg->device >= ndev) return fail(c, TMX_ERR_BAD_ARG, "device ordinal out of range");
   HIPCK(c, hipSetDevice(cfg->device));
   HIPCK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  for (auto& set : c->ev_side)
+    for (auto& ev : set) HIPCK(c, hipEventCreate(&ev));
   for (auto& set : c->ev)
     for (auto& ev : set) HIPCK(c, hipEventCreate(&ev));
   const uint32_t n = cfg->n_max;
@@ -337,67 +417,26 @@ int32_t tmx_sync(tmx_ctx* c) {
   return TMX_OK;
 }
 
-// k_proof + k_serialize; the EdDSA lane records are already in the ED part of c->d_tl.  ev[1..3] are recorded here
-static int32_t finish_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets, const void* d_trusteds,
-                            void* d_out_elems, void* d_reports, hipStream_t s, hipEvent_t* ev) {
-  const uint32_t n = c->cfg.n_max;
-  uint8_t* tl = reinterpret_cast<uint8_t*>(c->d_tl);
-  ProofParams P;
-  std::memset(&P, 0, sizeof P);
-  P.kind = (uint32_t)kind; P.n = n; P.tree_nodes = tree_nodes(n); P.chain_id_len = c->cfg.chain_id_len; P.skip_max = c->cfg.skip_max;
-  std::memcpy(P.chain_id, c->cfg.chain_id, sizeof P.chain_id);
-  void* reports = d_reports ? d_reports : c->d_reports;
-  int rc = launch_proof(P, n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_ED, TL_STRIDE, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf,
-                        c->d_nodes_t, c->d_nodes_r, reports, s);
-  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_proof launch: ") + hipGetErrorString((hipError_t)rc));
-  HIPCK(c, hipEventRecord(ev[2], s));
-  if (d_out_elems) {
-    SerializeSources src;
-    std::memset(&src, 0, sizeof src);
-    src.base[SRC_TARGET] = (const uint8_t*)d_targets; src.base[SRC_TRUSTED] = (const uint8_t*)d_trusteds;
-    src.base[SRC_TL] = tl; src.base[SRC_LR] = (const uint8_t*)c->d_lr; src.base[SRC_PF] = (const uint8_t*)c->d_pf;
-    src.nodes_t = (const uint8_t*)c->d_nodes_t; src.nodes_r = (const uint8_t*)c->d_nodes_r;
-    rc = launch_serialize(c->prog[kind].sp, src, c->d_lut[kind], c->d_wave_sec[kind], n_proofs, d_out_elems, s);
-    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_serialize launch: ") + hipGetErrorString((hipError_t)rc));
-  }
-  HIPCK(c, hipEventRecord(ev[3], s));
-  c->n_calls++;
-  return TMX_OK;
-}
-
-static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_ed, uint32_t ed_stride, hipStream_t s) {
-  return c->quad ? launch_eddsa_quad(n_lanes, d_lanes, d_ed, ed_stride, c->d_qtable, c->d_pre, c->d_mulout, s)
-                 : launch_eddsa(n_lanes, d_lanes, d_ed, ed_stride, c->d_table, s);
-}
-
-static int32_t check_batch_args(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets, const void* d_trusteds) {
-  if (!c || (kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP) || !d_proofs || !d_targets) return TMX_ERR_BAD_ARG;
-  if (kind == TMX_KIND_SKIP && !d_trusteds) return fail(c, TMX_ERR_BAD_ARG, "skip needs the trusted hash fields");
-  if (n_proofs > c->cfg.max_batch) return fail(c, TMX_ERR_CAPACITY, "n_proofs exceeds the context's max_batch");
-  return TMX_OK;
-}
-
 int32_t tmx_witness_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
                                  const void* d_trusteds, void* d_out_elems, void* d_reports, void* hip_stream) {
   int32_t st = check_batch_args(c, kind, n_proofs, d_proofs, d_targets, d_trusteds);
   if (st) return st;
   if (n_proofs == 0) return TMX_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = the HIP default stream, exactly as passed
-  hipEvent_t* ev = c->ev[c->n_calls % tmx_ctx::EV_RING];
-  HIPCK(c, hipEventRecord(ev[0], s));
-  int rc = run_eddsa(c, n_proofs * c->cfg.n_max, d_targets, reinterpret_cast<uint8_t*>(c->d_tl) + TL_OFF_ED, TL_STRIDE, s);
-  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_eddsa launch: ") + hipGetErrorString((hipError_t)rc));
-  HIPCK(c, hipEventRecord(ev[1], s));
-  return finish_batch(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out_elems, d_reports, s, ev);
+  return run_batch(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out_elems, d_reports, s, [&](hipStream_t ss) -> int32_t {
+    int rc = run_eddsa(c, n_proofs * c->cfg.n_max, d_targets, reinterpret_cast<uint8_t*>(c->d_tl) + TL_OFF_ED, TL_STRIDE, ss);
+    if (rc) return fail(c, TMX_ERR_HIP, std::string("EdDSA kernel launch: ") + hipGetErrorString((hipError_t)rc));
+    return TMX_OK;
+  });
 }
 
 int32_t tmx_eddsa_lanes_device(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_ed_out, void* hip_stream) {
   if (!c || !d_lanes || !d_ed_out) return TMX_ERR_BAD_ARG;
   if (n_lanes == 0) return TMX_OK;
-  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = the HIP default stream, exactly as passed
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
   if ((uint64_t)n_lanes > (uint64_t)c->cfg.max_batch * c->cfg.n_max) return fail(c, TMX_ERR_CAPACITY, "n_lanes exceeds max_batch * n_max");
   int rc = run_eddsa(c, n_lanes, d_lanes, d_ed_out, ED_STRIDE, s);
-  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_eddsa launch: ") + hipGetErrorString((hipError_t)rc));
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("EdDSA kernel launch: ") + hipGetErrorString((hipError_t)rc));
   return TMX_OK;
 }
 
@@ -407,14 +446,13 @@ int32_t tmx_finish_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, con
   if (st) return st;
   if (!d_ed) return TMX_ERR_BAD_ARG;
   if (n_proofs == 0) return TMX_OK;
-  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = the HIP default stream, exactly as passed
-  hipEvent_t* ev = c->ev[c->n_calls % tmx_ctx::EV_RING];
-  HIPCK(c, hipEventRecord(ev[0], s));
-  // caller's records are 448 B apart; place them into the ED part of the unified per-lane records
-  HIPCK(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(c->d_tl) + TL_OFF_ED, TL_STRIDE, d_ed, ED_STRIDE, ED_STRIDE,
-                            (size_t)n_proofs * c->cfg.n_max, hipMemcpyDeviceToDevice, s));
-  HIPCK(c, hipEventRecord(ev[1], s));
-  return finish_batch(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out_elems, d_reports, s, ev);
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  return run_batch(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out_elems, d_reports, s, [&](hipStream_t ss) -> int32_t {
+    // caller's records are 448 B apart; place them into the ED part of the unified per-lane records
+    HIPCK(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(c->d_tl) + TL_OFF_ED, TL_STRIDE, d_ed, ED_STRIDE, ED_STRIDE,
+                              (size_t)n_proofs * c->cfg.n_max, hipMemcpyDeviceToDevice, ss));
+    return TMX_OK;
+  });
 }
 
 int32_t tmx_kernel_ms_mean(tmx_ctx* c, uint32_t last_k, float ms[TMX_N_KERNELS]) {
@@ -425,12 +463,14 @@ int32_t tmx_kernel_ms_mean(tmx_ctx* c, uint32_t last_k, float ms[TMX_N_KERNELS])
   double acc[TMX_N_KERNELS] = {0};
   for (uint32_t j = 0; j < last_k; j++) {
     hipEvent_t* ev = c->ev[(c->n_calls - 1 - j) % tmx_ctx::EV_RING];
-    HIPCK(c, hipEventSynchronize(ev[TMX_N_KERNELS]));
-    for (int k = 0; k < TMX_N_KERNELS; k++) {
-      float t = 0;
-      HIPCK(c, hipEventElapsedTime(&t, ev[k], ev[k + 1]));
-      acc[k] += t;
-    }
+    HIPCK(c, hipEventSynchronize(ev[3]));
+    hipEvent_t* evs = c->ev_side[(c->n_calls - 1 - j) % tmx_ctx::EV_RING];
+    HIPCK(c, hipEventSynchronize(evs[1]));
+    float t = 0;
+    HIPCK(c, hipEventElapsedTime(&t, ev[0], ev[1])); acc[TMX_K_EDDSA] += t;
+    HIPCK(c, hipEventElapsedTime(&t, evs[0], evs[1])); acc[TMX_K_PROOF] += t;
+    HIPCK(c, hipEventElapsedTime(&t, ev[1], ev[2])); acc[TMX_K_VERDICT] += t;
+    HIPCK(c, hipEventElapsedTime(&t, ev[2], ev[3])); acc[TMX_K_SERIALIZE] += t;
   }
   for (int k = 0; k < TMX_N_KERNELS; k++) ms[k] = (float)(acc[k] / last_k);
   return TMX_OK;
