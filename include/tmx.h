@@ -169,6 +169,9 @@ int32_t tmx_last_kernel_ms(tmx_ctx* ctx, float ms[TMX_N_KERNELS]);
  * a whole region without synchronising inside it */
 int32_t tmx_kernel_ms_mean(tmx_ctx* ctx, uint32_t last_k, float ms[TMX_N_KERNELS]);
 int32_t tmx_sync(tmx_ctx* ctx);
+/* EdDSA stage bookkeeping of the last launch: number of distinct (effective) public keys among its lanes and whether h*A used the
+ * per-key fixed-base tables (>= 8 lanes per key on average; TMX_DEDUP=0|1|2 forces never / automatic / always).  Blocks. */
+int32_t tmx_last_dedup(tmx_ctx* ctx, uint32_t* n_unique, uint32_t* used_tables);
 
 /* ---- per-lane Level-1 EdDSA values only (unit-test / profiling hook of the dominant kernel).
  * d_out: 448 B per lane = digest[64] | h[32] | A.x A.y R.x R.y sB.x sB.y hA.x hA.y sum.x sum.y [10][32] | ok u32 |

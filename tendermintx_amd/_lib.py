@@ -128,6 +128,7 @@ def lib():
     L.tmx_ctx_stream.restype = C.c_void_p
     L.tmx_ctx_stream.argtypes = [C.c_void_p]
     L.tmx_sync.argtypes = [C.c_void_p]
+    L.tmx_last_dedup.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.tmx_eddsa_lanes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.tmx_skip_inputs_from_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64,
                                             C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]

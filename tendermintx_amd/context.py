@@ -108,5 +108,11 @@ class Context:
         check(self._L.tmx_kernel_ms_mean(self._h, last_k, ms), self._h)
         return dict(zip(_lib.KERNEL_NAMES, (float(x) for x in ms)))
 
+    def last_dedup(self):
+        """(distinct public keys, table path used) of the last EdDSA launch."""
+        u, t = C.c_uint32(), C.c_uint32()
+        check(self._L.tmx_last_dedup(self._h, C.byref(u), C.byref(t)), self._h)
+        return int(u.value), bool(t.value)
+
     def sync(self):
         check(self._L.tmx_sync(self._h), self._h)

@@ -66,6 +66,7 @@ void emit_proof_d(LutBuilder& L, int q) { L.bytes(PF_OFF_PROOFD + 160 * q, 160);
 struct Program {
   SerializeProgram sp;
   std::vector<uint32_t> lut;
+  uint32_t mask_inputs = 0, mask_proof = 0, mask_final = 0;  // sections by readiness: inputs only / after k_proof / after EdDSA
   std::vector<uint8_t> wave_sec;  // per 128-element span of a row: its section, or 0xff if it straddles a boundary / the row end
   uint32_t hint_elems;
 };
@@ -77,7 +78,9 @@ Program build_program(int kind, uint32_t n) {
   const bool skip = kind == TMX_KIND_SKIP;
   const uint32_t tn = tree_nodes(n);
   uint32_t elem = 0;
-  auto add_section = [&](uint32_t lane_elems, uint32_t n_lanes, uint32_t lut_off, uint32_t kind_, uint32_t src) {
+  // ready: 0 = needs only the input records, 1 = needs k_proof, 2 = needs the EdDSA kernels / the verdict
+  auto add_section = [&](uint32_t lane_elems, uint32_t n_lanes, uint32_t lut_off, uint32_t kind_, uint32_t src, int ready) {
+    (ready == 0 ? P.mask_inputs : ready == 1 ? P.mask_proof : P.mask_final) |= 1u << P.sp.n_sections;
     Section& s = P.sp.sec[P.sp.n_sections++];
     s.elem_start = elem; s.lane_elems = lane_elems; s.n_lanes = n_lanes; s.lut_off = lut_off; s.kind = kind_; s.src = src;
     s.magic = (uint32_t)((0x100000000ull + lane_elems - 1) / lane_elems);  // lane = mulhi(rel, magic); rel * lane_elems < 2^32 here
@@ -89,7 +92,7 @@ Program build_program(int kind, uint32_t n) {
   // H.1 target_header / next_header : Bytes32
   mark = (uint32_t)L.v.size();
   L.bytes(PF_OFF_HEADER, 32);
-  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT, SRC_PF);
+  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT, SRC_PF, 1);
 
   // H.2 validators[N] : ValidatorVariable (variables.rs:69-79) = pubkey, signature{r, s}, message[124],
   //     message_byte_length, voting_power, validator_byte_length, signed
@@ -102,7 +105,7 @@ Program build_program(int kind, uint32_t n) {
   L.u64(VR_OFF_POWER);
   L.u8(VR_OFF_VLEN);
   L.flag0(VR_OFF_FLAGS);
-  add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_TARGET);
+  add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_TARGET, 0);
 
   // H.3 nb_validators, round, ChainIdProofVariable, HeightProofVariable, validators-hash proof, then
   //     skip: trusted nb + trusted validators-hash proof ; step: last_block_id proof + prev next_validators_hash proof
@@ -123,7 +126,7 @@ Program build_program(int kind, uint32_t n) {
     emit_inclusion_proof(L, 3, PF_OFF_LEAFX, 72);
     emit_inclusion_proof(L, 4, PF_OFF_LEAFY, 34);
   }
-  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT, SRC_PF);
+  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT, SRC_PF, 1);
 
   // H.4 skip: trusted_header_validator_hash_fields[N] : ValidatorHashFieldVariable (variables.rs:82-88)
   if (skip) {
@@ -131,7 +134,7 @@ Program build_program(int kind, uint32_t n) {
     L.bytes(HR_OFF_PK, 32);
     L.u64(HR_OFF_POWER);
     L.u8(HR_OFF_VLEN);
-    add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_TRUSTED);
+    add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_TRUSTED, 0);
   }
   P.hint_elems = elem;
 
@@ -146,7 +149,7 @@ Program build_program(int kind, uint32_t n) {
   for (int f = 0; f < 6; f++) L.u8(TL_OFF_LT + LN_OFF_FLAGS + f);
   L.u64(TL_OFF_LT + LN_OFF_TOT);
   L.u64(TL_OFF_LT + LN_OFF_ACC);
-  add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_TL);
+  add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_TL, 2);
 
   // D.2 per trusted lane
   if (skip) {
@@ -157,12 +160,12 @@ Program build_program(int kind, uint32_t n) {
     L.u8(LN_OFF_FLAGS + 1);
     L.u64(LN_OFF_TOT);
     L.u64(LN_OFF_ACC);
-    add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_LR);
+    add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_LR, 1);
   }
   // D.3 / D.4 tree nodes
   if (tn) {
-    add_section(tn * 256, 1, 0, SEC_LINEAR_T, SRC_PF);
-    if (skip) add_section(tn * 256, 1, 0, SEC_LINEAR_R, SRC_PF);
+    add_section(tn * 256, 1, 0, SEC_LINEAR_T, SRC_PF, 1);
+    if (skip) add_section(tn * 256, 1, 0, SEC_LINEAR_R, SRC_PF, 1);
   }
   // D.5 header proofs, tallies, checks, verdict
   mark = (uint32_t)L.v.size();
@@ -183,7 +186,8 @@ Program build_program(int kind, uint32_t n) {
   const int n_checks = skip ? 12 : 14;
   for (int k = 0; k < n_checks; k++) L.u32(PF_OFF_CHECKS + 4 * k);
   L.u32(PF_OFF_ALLOK);
-  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT, SRC_PF);
+  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT, SRC_PF, 2);
+  P.mask_final |= 1u << 31;  // boundary waves are written last, when every source is ready
 
   P.sp.elem_count = elem;
   P.sp.elem_stride = (elem + 1) & ~1u;
@@ -224,6 +228,16 @@ struct tmx_ctx {
   void* d_wave_sec[2] = {nullptr, nullptr};
   void* d_table = nullptr;
   void *d_qtable = nullptr, *d_pre = nullptr, *d_mulout = nullptr;
+  void *d_hash = nullptr, *d_cnt = nullptr, *d_owner_of = nullptr, *d_uid_of_owner = nullptr, *d_owners = nullptr, *d_keyrec = nullptr,
+       *d_anchors = nullptr, *d_keytab = nullptr;
+  uint32_t hash_mask = 0, key_cap = 0, dedup_mode = 1;  // TMX_DEDUP=0|1|2: never / automatic / always build per-key tables
+  hipStream_t side2 = nullptr;  // distinct-key pipeline, concurrent with phase 1
+  hipStream_t side3 = nullptr;  // early serialization of the input-only sections
+  hipEvent_t ev_join3 = nullptr;
+  hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_hash_clean = nullptr;
+  uint32_t parity = 0;  // which of the two key counters this launch uses
+  uint64_t last_lanes = 0;
+  bool ser_split = true;  // TMX_SER_SPLIT=0: one k_serialize launch at the end (used to time the kernel on its own)
   bool quad = true;  // TMX_EDDSA=mono selects the first-generation one-lane-per-thread kernel (kept for A/B runs)
   // scratch sized for cfg.max_batch proofs
   void *d_ed = nullptr, *d_tl = nullptr, *d_lr = nullptr, *d_pf = nullptr, *d_nodes_t = nullptr, *d_nodes_r = nullptr, *d_reports = nullptr;
@@ -264,13 +278,33 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   const uint64_t slot = c->n_calls % tmx_ctx::EV_RING;
   hipEvent_t* ev = c->ev[slot];
   hipEvent_t* evs = c->ev_side[slot];
+  SerializeSources src;
+  std::memset(&src, 0, sizeof src);
+  src.base[SRC_TARGET] = (const uint8_t*)d_targets; src.base[SRC_TRUSTED] = (const uint8_t*)d_trusteds;
+  src.base[SRC_TL] = tl; src.base[SRC_LR] = (const uint8_t*)c->d_lr; src.base[SRC_PF] = (const uint8_t*)c->d_pf;
+  src.nodes_t = (const uint8_t*)c->d_nodes_t; src.nodes_r = (const uint8_t*)c->d_nodes_r;
+  const Program& prog = c->prog[kind];
+  auto serialize = [&](uint32_t mask, hipStream_t on) -> int32_t {
+    if (!d_out_elems) return TMX_OK;
+    int r = launch_serialize(prog.sp, src, c->d_lut[kind], c->d_wave_sec[kind], n_proofs, d_out_elems, mask, on);
+    if (r) return fail(c, TMX_ERR_HIP, std::string("k_serialize launch: ") + hipGetErrorString((hipError_t)r));
+    return TMX_OK;
+  };
   HIPCK(c, hipEventRecord(c->ev_fork, s));
   HIPCK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+  HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_fork, 0));
+  // side3: the sections that are a pure expansion of the input records (42 % of a skip row) -- HBM is idle while EdDSA runs
+  int32_t st0 = c->ser_split ? serialize(prog.mask_inputs, c->side3) : TMX_OK;
+  if (st0) return st0;
+  HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
+  // side: k_proof, then the sections that only need its results
   HIPCK(c, hipEventRecord(evs[0], c->side));
   int rc = launch_proof(proof_params(c, kind), n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf, c->d_nodes_t,
                         c->d_nodes_r, reports, c->side);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_proof launch: ") + hipGetErrorString((hipError_t)rc));
   HIPCK(c, hipEventRecord(evs[1], c->side));
+  st0 = c->ser_split ? serialize(prog.mask_proof, c->side) : TMX_OK;
+  if (st0) return st0;
   HIPCK(c, hipEventRecord(c->ev_join, c->side));
 
   HIPCK(c, hipEventRecord(ev[0], s));
@@ -278,18 +312,12 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   if (st) return st;
   HIPCK(c, hipEventRecord(ev[1], s));
   HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
+  HIPCK(c, hipStreamWaitEvent(s, c->ev_join3, 0));
   rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, s);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
   HIPCK(c, hipEventRecord(ev[2], s));
-  if (d_out_elems) {
-    SerializeSources src;
-    std::memset(&src, 0, sizeof src);
-    src.base[SRC_TARGET] = (const uint8_t*)d_targets; src.base[SRC_TRUSTED] = (const uint8_t*)d_trusteds;
-    src.base[SRC_TL] = tl; src.base[SRC_LR] = (const uint8_t*)c->d_lr; src.base[SRC_PF] = (const uint8_t*)c->d_pf;
-    src.nodes_t = (const uint8_t*)c->d_nodes_t; src.nodes_r = (const uint8_t*)c->d_nodes_r;
-    rc = launch_serialize(c->prog[kind].sp, src, c->d_lut[kind], c->d_wave_sec[kind], n_proofs, d_out_elems, s);
-    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_serialize launch: ") + hipGetErrorString((hipError_t)rc));
-  }
+  st0 = serialize(c->ser_split ? prog.mask_final : (prog.mask_inputs | prog.mask_proof | prog.mask_final), s);
+  if (st0) return st0;
   HIPCK(c, hipEventRecord(ev[3], s));
   c->n_calls++;
   return TMX_OK;
@@ -302,9 +330,34 @@ static int32_t check_batch_args(tmx_ctx* c, int32_t kind, uint32_t n_proofs, con
   return TMX_OK;
 }
 
+// EdDSA stage on stream s.  Quad path: the distinct-key pipeline runs on side2 beside phase 1, both join before h*A.
 static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_ed, uint32_t ed_stride, hipStream_t s) {
-  return c->quad ? launch_eddsa_quad(n_lanes, d_lanes, d_ed, ed_stride, c->d_qtable, c->d_pre, c->d_mulout, s)
-                 : launch_eddsa(n_lanes, d_lanes, d_ed, ed_stride, c->d_table, s);
+  if (!c->quad) return launch_eddsa(n_lanes, d_lanes, d_ed, ed_stride, c->d_table, s);
+  EdQuad Q;
+  Q.n_lanes = n_lanes; Q.d_target = d_lanes; Q.d_ed = d_ed; Q.ed_stride = ed_stride; Q.d_qtable = c->d_qtable; Q.d_pre = c->d_pre;
+  Q.d_mulout = c->d_mulout; Q.d_hash = c->d_hash; Q.hash_mask = c->hash_mask; Q.d_owner_of = c->d_owner_of;
+  Q.d_uid_of_owner = c->d_uid_of_owner; Q.d_owners = c->d_owners; Q.d_keyrec = c->d_keyrec; Q.d_anchors = c->d_anchors; Q.d_keytab = c->d_keytab;
+  Q.key_cap = c->key_cap; Q.mode = c->dedup_mode;
+  c->last_lanes = n_lanes;
+  Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * c->parity;
+  Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1);
+  c->parity ^= 1;
+  hipError_t e;
+  // the hash table was cleared on side2 at the end of the previous launch (or at context creation)
+  if ((e = hipStreamWaitEvent(s, c->ev_hash_clean, 0)) != hipSuccess) return (int)e;
+  int rc = launch_ed_dedup(Q, s);
+  if (rc) return rc;
+  if ((e = hipEventRecord(c->ev_fork2, s)) != hipSuccess) return (int)e;
+  if ((e = hipStreamWaitEvent(c->side2, c->ev_fork2, 0)) != hipSuccess) return (int)e;
+  rc = launch_ed_keys_pipeline(Q, c->side2);
+  if (rc) return rc;
+  if ((e = hipEventRecord(c->ev_join2, c->side2)) != hipSuccess) return (int)e;
+  if ((e = hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, c->side2)) != hipSuccess) return (int)e;  // for the next launch
+  if ((e = hipEventRecord(c->ev_hash_clean, c->side2)) != hipSuccess) return (int)e;
+  rc = launch_ed_phase1(Q, s);
+  if (rc) return rc;
+  if ((e = hipStreamWaitEvent(s, c->ev_join2, 0)) != hipSuccess) return (int)e;
+  return launch_ed_mul_fin(Q, s);
 }
 
 extern "C" {
@@ -340,7 +393,8 @@ const char* tmx_last_error(const tmx_ctx* ctx) { return ctx ? ctx->err.c_str() :
 
 void tmx_ctx_destroy(tmx_ctx* c) {
   if (!c) return;
-  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
+  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_owner_of, c->d_uid_of_owner, c->d_owners, c->d_keyrec,
+                  c->d_anchors, c->d_keytab, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
                   c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -352,6 +406,12 @@ void tmx_ctx_destroy(tmx_ctx* c) {
       if (e) (void)hipEventDestroy(e);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
+  if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
+  if (c->ev_hash_clean) (void)hipEventDestroy(c->ev_hash_clean);
+  if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
+  if (c->side3) (void)hipStreamDestroy(c->side3);
+  if (c->side2) (void)hipStreamDestroy(c->side2);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -370,7 +430,17 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   if (cfg->device < 0 || cfg->device >= ndev) return fail(c, TMX_ERR_BAD_ARG, "device ordinal out of range");
   HIPCK(c, hipSetDevice(cfg->device));
   HIPCK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIPCK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  // The key pipeline is on the critical path (high priority); k_proof and the early serialization only fill otherwise idle
+  // resources and must not starve the caller's stream (low priority).
+  int prio_low = 0, prio_high = 0;
+  HIPCK(c, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+  HIPCK(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_low));
+  HIPCK(c, hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, prio_high));
+  HIPCK(c, hipStreamCreateWithPriority(&c->side3, hipStreamNonBlocking, prio_low));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_hash_clean, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   for (auto& set : c->ev_side)
@@ -398,11 +468,36 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   HIPCK(c, hipMalloc(&c->d_reports, B * sizeof(tmx_report)));
   int rc = launch_init_base(c->d_table, c->stream);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_init_base launch: ") + hipGetErrorString((hipError_t)rc));
+  const char* ss = std::getenv("TMX_SER_SPLIT");
+  c->ser_split = !(ss && ss[0] == '0');
   const char* mode = std::getenv("TMX_EDDSA");
   c->quad = !(mode && std::string(mode) == "mono");
   HIPCK(c, hipMalloc(&c->d_qtable, quad_table_bytes()));
   HIPCK(c, hipMalloc(&c->d_pre, lanes * pre_bytes_per_lane()));
   HIPCK(c, hipMalloc(&c->d_mulout, lanes * mulout_bytes_per_lane()));
+  {
+    const char* dm = std::getenv("TMX_DEDUP");
+    if (dm && dm[0] >= '0' && dm[0] <= '2') c->dedup_mode = (uint32_t)(dm[0] - '0');
+    uint32_t cap = 1;
+    while (cap < 2 * lanes) cap <<= 1;
+    c->hash_mask = cap - 1;
+    // tables pay off from ~4 lanes per key; automatic mode asks for 8, so lanes/8 keys suffice (mode 2: as many as fit)
+    size_t kc = c->dedup_mode == 2 ? lanes : (lanes + 7) / 8;
+    if (kc < 16) kc = lanes < 16 ? lanes : 16;
+    if (kc > 4096) kc = 4096;
+    c->key_cap = (uint32_t)kc;
+    HIPCK(c, hipMalloc(&c->d_hash, (size_t)cap * 4));
+    HIPCK(c, hipMalloc(&c->d_cnt, 32));
+    HIPCK(c, hipMemsetAsync(c->d_hash, 0xff, (size_t)cap * 4, c->side2));
+    HIPCK(c, hipMemsetAsync(c->d_cnt, 0, 32, c->side2));
+    HIPCK(c, hipEventRecord(c->ev_hash_clean, c->side2));
+    HIPCK(c, hipMalloc(&c->d_owner_of, lanes * 4));
+    HIPCK(c, hipMalloc(&c->d_uid_of_owner, lanes * 4));
+    HIPCK(c, hipMalloc(&c->d_owners, lanes * 4));
+    HIPCK(c, hipMalloc(&c->d_keyrec, lanes * key_bytes_per_key()));
+    HIPCK(c, hipMalloc(&c->d_anchors, kc * anchor_bytes_per_key()));
+    HIPCK(c, hipMalloc(&c->d_keytab, kc * keytab_bytes_per_key()));
+  }
   rc = launch_init_base_quad(c->d_table, c->d_qtable, c->stream);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_init_base_quad launch: ") + hipGetErrorString((hipError_t)rc));
   HIPCK(c, hipStreamSynchronize(c->stream));
@@ -410,6 +505,19 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
 }
 
 void* tmx_ctx_stream(tmx_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) : nullptr; }
+
+// distinct public keys seen by the last EdDSA launch and whether the per-key table path was taken (blocks until that launch is done)
+int32_t tmx_last_dedup(tmx_ctx* c, uint32_t* n_unique, uint32_t* used_tables) {
+  if (!c || !n_unique || !used_tables) return TMX_ERR_BAD_ARG;
+  *n_unique = 0; *used_tables = 0;
+  if (!c->quad || !c->d_cnt) return TMX_OK;
+  HIPCK(c, hipDeviceSynchronize());
+  uint32_t v = 0;
+  HIPCK(c, hipMemcpy(&v, reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1), 4, hipMemcpyDeviceToHost));
+  *n_unique = v;
+  *used_tables = (c->dedup_mode != 0 && v <= c->key_cap && (c->dedup_mode == 2 || (uint64_t)v * 8 <= c->last_lanes)) ? 1u : 0u;
+  return TMX_OK;
+}
 
 int32_t tmx_sync(tmx_ctx* c) {
   if (!c) return TMX_ERR_BAD_ARG;

@@ -69,20 +69,20 @@ TMX_DEV fe fe_select(const fe& a, const fe& b, bool c) {
   return r;
 }
 
-// Signed carry chain over ten 64-bit column sums -> carried limbs.
+// Signed carry chain over ten 64-bit column sums -> carried limbs.  Two interleaved chains (limbs 0..4 and 5..9) halve the
+// dependent depth: a lone wave per SIMD spends most of a 255-squaring exponentiation waiting on this chain.
+//   (0,5) (1,6) (2,7) (3,8) (4,9: limb 9 wraps into limb 0 times 19) then (0,5) once more
+TMX_DEV void fe_carry_step(int64_t h[10], int i) {
+  const int bits = (i & 1) ? 25 : 26;
+  int64_t c = (h[i] + ((int64_t)1 << (bits - 1))) >> bits;
+  h[i] -= c << bits;
+  if (i < 9) h[i + 1] += c; else h[0] += 19 * c;
+}
 TMX_DEV fe fe_carry_wide(int64_t h[10]) {
 #pragma unroll
-  for (int i = 0; i < 10; i++) {
-    const int bits = (i & 1) ? 25 : 26;
-    int64_t c = (h[i] + ((int64_t)1 << (bits - 1))) >> bits;
-    h[i] -= c << bits;
-    if (i < 9) h[i + 1] += c; else h[0] += 19 * c;
-  }
-  {
-    int64_t c = (h[0] + ((int64_t)1 << 25)) >> 26;
-    h[0] -= c << 26;
-    h[1] += c;
-  }
+  for (int i = 0; i < 5; i++) { fe_carry_step(h, i); fe_carry_step(h, i + 5); }
+  fe_carry_step(h, 0);
+  fe_carry_step(h, 5);
   fe r;
 #pragma unroll
   for (int i = 0; i < 10; i++) r.v[i] = (int32_t)h[i];

@@ -11,17 +11,38 @@ size_t base_table_bytes();
 // each returns a hipError_t value (0 = success); all launches are asynchronous on `stream` (hipStream_t)
 int launch_init_base(void* d_table, void* stream);
 int launch_eddsa(uint32_t n_lanes, const void* d_target, void* d_ed, uint32_t ed_stride, const void* d_table, void* stream);
-// quad-parallel EdDSA path (k_ed_pre -> k_ed_mul -> k_ed_fin)
+// quad-parallel EdDSA path.  Three launch groups so that api.cpp can run the key pipeline on a side stream:
+//   keys pipeline (dedup -> decode distinct keys -> optional per-key tables)  ||  phase 1 (decode R, SHA-512 mod l, s*B)
+//   then h*A + finish
+struct EdQuad {
+  uint32_t n_lanes;
+  const void* d_target;
+  void* d_ed;
+  uint32_t ed_stride;
+  const void* d_qtable;
+  void *d_pre, *d_mulout;
+  void* d_hash;
+  uint32_t hash_mask;
+  void *d_cnt, *d_cnt_next, *d_owner_of, *d_uid_of_owner, *d_owners, *d_keyrec, *d_anchors, *d_keytab;
+  uint32_t key_cap;  // keys the table buffers can hold
+  uint32_t mode;     // 0 never build tables, 1 automatic (>= 8 lanes per key), 2 whenever they fit
+};
 size_t quad_table_bytes();
 size_t pre_bytes_per_lane();
 size_t mulout_bytes_per_lane();
+size_t key_bytes_per_key();
+size_t anchor_bytes_per_key();
+size_t keytab_bytes_per_key();
 int launch_init_base_quad(const void* d_table, void* d_qtable, void* stream);
-int launch_eddsa_quad(uint32_t n_lanes, const void* d_target, void* d_ed, uint32_t ed_stride, const void* d_qtable, void* d_pre, void* d_mulout,
-                      void* stream);
+int launch_ed_dedup(const EdQuad& Q, void* stream);
+int launch_ed_keys_pipeline(const EdQuad& Q, void* stream);
+int launch_ed_phase1(const EdQuad& Q, void* stream);
+int launch_ed_mul_fin(const EdQuad& Q, void* stream);
 int launch_proof(const ProofParams& P, uint32_t n_proofs, const void* d_proofs, const void* d_target, const void* d_trusted, void* d_lt,
                  uint32_t lt_stride, void* d_lr, void* d_pf, void* d_nodes_t, void* d_nodes_r, void* d_reports, void* stream);
 int launch_verdict(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_ed, uint32_t ed_stride, void* d_pf, void* d_reports, void* stream);
+// sec_mask: bit s = section s, bit 31 = waves straddling a section boundary / the row end
 int launch_serialize(const SerializeProgram& S, const SerializeSources& src, const void* d_lut, const void* d_wave_sec, uint32_t n_proofs,
-                     void* d_out, void* stream);
+                     void* d_out, uint32_t sec_mask, void* stream);
 
 }  // namespace tmx

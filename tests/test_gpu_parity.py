@@ -387,3 +387,35 @@ def test_validator_sharded_single_proof(tmx, oracle):
         assert bytes(rep.cpu().numpy()[:32]) == orep["header"]
     finally:
         dist.destroy_process_group()
+
+
+def test_key_dedup_paths(tmx, oracle):
+    """The EdDSA stage decodes every distinct public key once and, when keys repeat (>= 8 lanes per key), walks per-key fixed-base
+    tables instead of doubling: both schedules must give the same bits.  Batches: one validator set repeated (tables), every proof
+    with its own validator set (direct), and a mix just around the switch-over."""
+    from tendermintx_amd.synth import Workload
+    n = 16
+
+    def cat(wls):
+        return b"".join(w.proofs for w in wls), b"".join(w.targets for w in wls), b"".join(w.trusteds for w in wls)
+
+    same = Workload(0, n, 24, 16, chain_id=b"celestia", seed=1, signed_permille=1000)
+    distinct = [Workload(0, n, 1, 16, chain_id=b"celestia", seed=100 + i, signed_permille=1000) for i in range(24)]
+    mixed = [Workload(0, n, 12, 16, chain_id=b"celestia", seed=7, signed_permille=900)] + distinct[:6]
+    with tmx.Context(n, b"celestia", max_batch=24) as ctx:
+        _, reps = _check_vs_oracle(tmx, oracle, 0, n, same.proofs, same.targets, same.trusteds, b"celestia", ctx=ctx)
+        assert all(r["all_ok"] for r in reps)
+        uniq, tables = ctx.last_dedup()
+        assert uniq == 16 and tables                      # 384 lanes, 16 keys
+        p, t, r = cat(distinct)
+        _, reps = _check_vs_oracle(tmx, oracle, 0, n, p, t, r, b"celestia", ctx=ctx)
+        assert all(x["all_ok"] for x in reps)
+        uniq, tables = ctx.last_dedup()
+        assert uniq == 24 * 16 and not tables              # every key once: direct h*A
+        p, t, r = cat(mixed)
+        _, reps = _check_vs_oracle(tmx, oracle, 0, n, p, t, r, b"celestia", ctx=ctx)
+        uniq, tables = ctx.last_dedup()
+        assert uniq >= 16 + 6 * 16                         # (+ the dummy key of unsigned lanes)
+        # the same batch again must not see stale keys / tables from the previous launches
+        _, reps2 = _check_vs_oracle(tmx, oracle, 0, n, same.proofs, same.targets, same.trusteds, b"celestia", ctx=ctx)
+        assert ctx.last_dedup() == (16, True)

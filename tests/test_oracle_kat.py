@@ -191,3 +191,56 @@ def test_multithreaded_batch_equals_single(oracle, cases):
     a, ra = oracle.witness_batch(0, 6, proof * 6, target * 6, trusted * 6, 4, b"mocha-4", 100800, n_threads=3)
     b, rb = oracle.witness_batch(0, 6, proof * 6, target * 6, trusted * 6, 4, b"mocha-4", 100800, n_threads=1)
     assert np.array_equal(a, b) and ra == rb and all(r["all_ok"] for r in ra)
+
+
+def test_sc_fold_model():
+    """Model of the radix-2^21 folding reduction used by the HIP path (tendermintx_amd/csrc/sc25519.hpp::sc_reduce512):
+    same steps in Python ints, checked against x % l and for intermediate magnitudes < 2^62 (int64 accumulators)."""
+    ell = ed.L
+    c = ell - 2**252
+    digs, t = [], c
+    for _ in range(6):
+        d = t & ((1 << 21) - 1)
+        if d >= 1 << 20:
+            d -= 1 << 21
+        digs.append(d)
+        t = (t - d) >> 21
+    assert t == 0
+    m = [-d for d in digs]
+    assert m == [666643, 470296, 654183, -997805, 136657, -683901]  # the constants hard-coded in sc25519.hpp
+    rng = np.random.default_rng(21)
+    xs = [0, 1, ell - 1, ell, ell + 1, 2**512 - 1, 2**511, 2**252, 2**252 - 1] + [int.from_bytes(rng.bytes(64), "little") for _ in range(3000)]
+    for x in xs:
+        s = [(x >> (21 * i)) & 0x1FFFFF for i in range(23)] + [x >> 483]
+        worst = 0
+
+        def fold(i):
+            nonlocal worst
+            for k in range(6):
+                s[i - 12 + k] += s[i] * m[k]
+                worst = max(worst, abs(s[i - 12 + k]))
+            s[i] = 0
+        for i in range(23, 17, -1):
+            fold(i)
+        for i in range(6, 17):
+            cy = (s[i] + (1 << 20)) >> 21
+            s[i] -= cy << 21
+            s[i + 1] += cy
+        for i in range(17, 11, -1):
+            fold(i)
+        for i in range(12):
+            cy = (s[i] + (1 << 20)) >> 21
+            s[i] -= cy << 21
+            s[i + 1] += cy
+        for _ in range(2):
+            fold(12)
+            for i in range(12):
+                cy = s[i] >> 21
+                s[i] -= cy << 21
+                s[i + 1] += cy
+        assert s[12] in (0, 1) and all(0 <= v < 1 << 21 for v in s[:12]) and worst < 2**62
+        y = sum(v << (21 * i) for i, v in enumerate(s[:13]))
+        for _ in range(2):
+            if y >= ell:
+                y -= ell
+        assert y == x % ell

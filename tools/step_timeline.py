@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Print the kernel timeline of one full-batch step from a rocprofv3 rocpd database (development aid)."""
+import sqlite3
+import sys
+db = sqlite3.connect(sys.argv[1])
+rows = db.execute("select name,start,end,stream_id from kernels order by start").fetchall()
+ser = [i for i, r in enumerate(rows) if "k_serialize" in r[0] and r[2] - r[1] > 100000]
+i1, i2 = ser[-3], ser[-2]
+t0 = None
+for r in rows[i1 + 1:i2 + 1]:
+    if t0 is None:
+        t0 = r[1]
+    print(f"{r[0][:30]:30s} start {((r[1]-t0)/1e3):9.1f} us  dur {((r[2]-r[1])/1e3):8.1f} us  stream {r[3]}")
