@@ -128,6 +128,22 @@ def main():
         torch.cuda.synchronize(dev)
         k_s = ctx1.kernel_ms_mean(5)["k_serialize"]
         ctx1.close()
+        # transparency: the same step with the per-key tables switched off (every lane does its own 252 doublings for h*A)
+        os.environ["TMX_DEDUP"] = "0"
+        ctx0 = Context(n, b"celestia", 100800, device=local_rank, max_batch=P)
+        del os.environ["TMX_DEDUP"]
+        for _ in range(3):
+            ctx0.witness_batch_device(KIND_SKIP, P, d_proofs.data_ptr(), d_targets.data_ptr(), d_trusteds.data_ptr(), d_out.data_ptr(),
+                                      d_rep.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        a0 = time.perf_counter()
+        for _ in range(10):
+            ctx0.witness_batch_device(KIND_SKIP, P, d_proofs.data_ptr(), d_targets.data_ptr(), d_trusteds.data_ptr(), d_out.data_ptr(),
+                                      d_rep.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        ms_no_tables = 1e3 * (time.perf_counter() - a0) / 10
+        k_e_no_tables = ctx0.kernel_ms_mean(10)["k_eddsa"]
+        ctx0.close()
 
         traffic, traffic_ser = None, None
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), only if they were taken on this configuration
@@ -147,7 +163,9 @@ def main():
                     "valu": {"achieved": round(ed_mads / (k_e * 1e-3) / 1e9, 1), "peak": MAD_PEAK_GOPS, "unit": "Gmad/s",
                              "frac": round(ed_mads / (k_e * 1e-3) / 1e9 / MAD_PEAK_GOPS, 4), "algorithmic_mads": ed_mads,
                              "note": "multiply-adds the chosen algorithm needs, not the instructions issued"},
-                    "dedup": {"lanes": lanes, "distinct_keys": n_unique, "per_key_tables": used_tables},
+                    "dedup": {"lanes": lanes, "distinct_keys": n_unique, "per_key_tables": used_tables,
+                              "without_key_tables": {"ms_per_step": round(ms_no_tables, 4), "k_eddsa_ms": round(k_e_no_tables, 4),
+                                                     "valu_frac": round(lanes * MADS_PER_LANE / (k_e_no_tables * 1e-3) / 1e9 / MAD_PEAK_GOPS, 4)}},
                     "k_serialize": {"bound": "hbm", "ms_alone": round(k_s, 4), "achieved": round(gbs(ser_bytes, k_s), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(gbs(ser_bytes, k_s) / HBM_PEAK_GBS, 4), "traffic": traffic_ser, "algorithmic_bytes": ser_bytes},
                     "pass": {"bound": "hbm", "achieved": round(gbs(in_bytes + out_bytes, ms_per_step), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -390,6 +390,8 @@ def test_validator_sharded_single_proof(tmx, oracle):
 
 
 def test_key_dedup_paths(tmx, oracle):
+    if os.environ.get("TMX_EDDSA") == "mono":
+        pytest.skip("the first-generation kernel has no key deduplication")
     """The EdDSA stage decodes every distinct public key once and, when keys repeat (>= 8 lanes per key), walks per-key fixed-base
     tables instead of doubling: both schedules must give the same bits.  Batches: one validator set repeated (tables), every proof
     with its own validator set (direct), and a mix just around the switch-over."""
