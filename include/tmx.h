@@ -189,6 +189,26 @@ int32_t tmx_step_inputs_from_json(const char* prev_commit_json, const char* next
                                   uint32_t n_max, uint64_t prev_block, const uint8_t prev_header_hash[32],
                                   tmx_proof_rec* proof, tmx_validator_rec* target);
 
+/* ---- the caller of the path: `is_valid_skip` (reference circuits/input/tendermint_utils.rs:444-482) for many
+ * candidate target blocks at once -- what `find_block_to_request` (reference circuits/input/mod.rs:160-186) asks block by block.
+ * For candidate c:  shared = sum over start validators found (by address) in target set c of
+ *                            power_in_target * #(commit signatures of c carrying that address, commit or nil votes alike),
+ *                   valid  = f64(total power of target set c) * (1/3) <= f64(shared)      (IEEE double, as the reference computes it). */
+typedef struct {
+  uint8_t address[20];
+  uint8_t has_address; /* signatures: CommitSig::validator_address().is_some() (flags 2 and 3); validators: 1 */
+  uint8_t pad[3];
+  uint64_t voting_power; /* validators only */
+} tmx_addr_rec; /* 32 B */
+/* start[n_start]; per candidate: targets[c][n_max] (n_targets[c] used), sigs[c][n_max] (n_sigs[c] used).  Outputs per candidate. */
+int32_t tmx_valid_skip_batch(tmx_ctx* ctx, uint32_t n_candidates, const tmx_addr_rec* start, uint32_t n_start,
+                             const tmx_addr_rec* targets, const uint32_t* n_targets, const tmx_addr_rec* sigs, const uint32_t* n_sigs,
+                             uint8_t* valid, uint64_t* shared_power, uint64_t* total_power);
+/* codec for it: `/validators` JSON of the start block, `/validators` + `/commit` JSON of one candidate -> records (each array n_max long) */
+int32_t tmx_skipcheck_inputs_from_json(const char* start_validators_json, const char* target_validators_json, const char* target_commit_json,
+                                       uint32_t n_max, tmx_addr_rec* start, uint32_t* n_start, tmx_addr_rec* target, uint32_t* n_target,
+                                       tmx_addr_rec* sigs, uint32_t* n_sigs);
+
 /* ---- public I/O packing: abi.encodePacked(uint64,bytes32,uint64) / (uint64,bytes32)
  * (reference contracts/src/TendermintX.sol:104-108, circuits/skip.rs:120-122, circuits/step.rs:107-108) */
 void tmx_pack_skip_input(uint64_t trusted_block, const uint8_t trusted_header_hash[32], uint64_t target_block, uint8_t out[48]);

@@ -68,6 +68,9 @@ void tmxo_fixed_shape_tree(const uint8_t* leaf_hashes, size_t n, size_t nb_enabl
 int tmxo_tally(const uint64_t* powers, size_t n, size_t nb, const uint8_t* in_group, uint64_t num, uint64_t den,
                uint64_t* tot_prefix, uint64_t* acc_prefix, uint64_t scal[4], int* no_overflow);
 
+int tmxo_is_valid_skip(const uint8_t* start, uint32_t n_start, const uint8_t* target, uint32_t n_target, const uint8_t* sigs, uint32_t n_sigs,
+                       uint64_t* shared, uint64_t* total);
+
 size_t tmxo_elem_count(int kind, size_t n);
 /* one proof; out must hold tmxo_elem_count(kind, n) elements.  trusted_recs ignored for step. returns 0 / <0 */
 int tmxo_witness(int kind, const uint8_t* proof_rec, const uint8_t* target_recs, const uint8_t* trusted_recs, uint32_t n,

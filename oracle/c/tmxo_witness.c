@@ -347,6 +347,30 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
   return E.n == tmxo_elem_count(kind, n) ? 0 : -2;
 }
 
+/* is_valid_skip (reference circuits/input/tendermint_utils.rs:444-482), loop for loop, on 32-byte address records
+ * (address[20], has_address, pad[3], voting_power).  Returns the predicate; *shared / *total as the reference accumulates them
+ * (including its early exit, so *shared may be a partial sum when the result is true). */
+int tmxo_is_valid_skip(const uint8_t* start, uint32_t n_start, const uint8_t* target, uint32_t n_target, const uint8_t* sigs, uint32_t n_sigs,
+                       uint64_t* shared, uint64_t* total) {
+  const double threshold = 1.0 / 3.0;
+  uint64_t shared_voting_power = 0, total_power = 0;
+  for (uint32_t j = 0; j < n_target; j++) total_power += rd64(target + 32 * j + 24);
+  uint32_t idx = 0;
+  while ((double)total_power * threshold > (double)shared_voting_power && idx < n_start) {
+    for (uint32_t j = 0; j < n_target; j++) {
+      if (memcmp(start + 32 * idx, target + 32 * j, 20) == 0) {            /* target_validator_set.validator(address) */
+        for (uint32_t k = 0; k < n_sigs; k++)
+          if (sigs[32 * k + 20] && memcmp(sigs + 32 * k, target + 32 * j, 20) == 0) shared_voting_power += rd64(target + 32 * j + 24);
+        break;
+      }
+    }
+    idx++;
+  }
+  if (shared) *shared = shared_voting_power;
+  if (total) *total = total_power;
+  return (double)total_power * threshold <= (double)shared_voting_power;
+}
+
 typedef struct {
   int kind; uint32_t lo, hi, n; const uint8_t *p, *t, *r, *cid; uint32_t cid_len; uint64_t skip_max; uint64_t* out; tmxo_report* reps; int rc;
 } job;

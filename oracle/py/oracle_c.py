@@ -120,6 +120,14 @@ def tally(powers, nb, in_group, num, den):
                 scaled_total=sc[3], no_overflow=bool(no.value))
 
 
+def is_valid_skip(start, target, sigs):
+    """start/target/sigs: bytes of 32-byte address records.  Returns (valid, shared_at_exit, total)."""
+    sh, to = C.c_uint64(), C.c_uint64()
+    v = lib().tmxo_is_valid_skip(bytes(start), C.c_uint32(len(start) // 32), bytes(target), C.c_uint32(len(target) // 32), bytes(sigs),
+                                 C.c_uint32(len(sigs) // 32), C.byref(sh), C.byref(to))
+    return bool(v), sh.value, to.value
+
+
 def elem_count(kind, n):
     return lib().tmxo_elem_count(kind, n)
 

@@ -517,3 +517,38 @@ def witness(kind, proof_rec, target_recs, trusted_recs, chain_id, skip_max):
     report = dict(header=header, all_ok=all_ok, fail_mask=fail_mask, first_bad_sig=first_bad_sig,
                   gt_target=tal_t["gt"], gt_trusted=(tal_r["gt"] if kind == KIND_SKIP else None))
     return E.v, report
+
+
+# ------------------------------------------------------------------------------------------------ is_valid_skip (operator side)
+def pack_addr(address20, has_address, power):
+    return struct.pack("<20sB3xQ", address20, 1 if has_address else 0, power)
+
+
+def skipcheck_records(start_validators, target_validators, target_commit):
+    """JSON objects -> (start, target, sigs) lists of 32-byte records for is_valid_skip."""
+    def vset(vals):
+        infos = sorted(((bytes.fromhex(v["address"]), int(v["voting_power"])) for v in vals), key=lambda t: (-t[1], t[0]))
+        return [pack_addr(a, True, p) for a, p in infos]
+    sigs = []
+    for cs in target_commit["signatures"]:
+        if cs["block_id_flag"] != 1 and cs.get("validator_address"):
+            sigs.append(pack_addr(bytes.fromhex(cs["validator_address"]), True, 0))
+        else:
+            sigs.append(pack_addr(bytes(20), False, 0))
+    return vset(start_validators), vset(target_validators), sigs
+
+
+def is_valid_skip(start, target, sigs):
+    """reference circuits/input/tendermint_utils.rs:444-482 on records; Python floats are IEEE doubles like Rust's f64."""
+    threshold = 1.0 / 3.0
+    total = sum(struct.unpack_from("<Q", t, 24)[0] for t in target) & U64
+    shared, idx = 0, 0
+    while float(total) * threshold > float(shared) and idx < len(start):
+        for t in target:
+            if t[:20] == start[idx][:20]:
+                for s in sigs:
+                    if s[20] and s[:20] == t[:20]:
+                        shared = (shared + struct.unpack_from("<Q", t, 24)[0]) & U64
+                break
+        idx += 1
+    return float(total) * threshold <= float(shared), shared, total

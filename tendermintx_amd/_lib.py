@@ -47,13 +47,17 @@ class Report(C.Structure):
                     gt_trusted=bool(self.gt_trusted), dist_ok=bool(self.dist_ok))
 
 
+class AddrRec(C.Structure):
+    _fields_ = [("address", C.c_uint8 * 20), ("has_address", C.c_uint8), ("pad", C.c_uint8 * 3), ("voting_power", C.c_uint64)]
+
+
 class Config(C.Structure):
     _fields_ = [("n_max", C.c_uint32), ("chain_id_len", C.c_uint32), ("chain_id", C.c_uint8 * 52),
                 ("skip_max", C.c_uint64), ("device", C.c_int32), ("max_batch", C.c_uint32)]
 
 
 assert C.sizeof(ValidatorRec) == 256 and C.sizeof(HashFieldRec) == 48 and C.sizeof(ProofRec) == 2336
-assert C.sizeof(Report) == 64
+assert C.sizeof(Report) == 64 and C.sizeof(AddrRec) == 32
 
 _lib = None
 _hip = None
@@ -134,6 +138,10 @@ def lib():
                                             C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tmx_step_inputs_from_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64, C.c_char_p,
                                             C.c_void_p, C.c_void_p]
+    L.tmx_valid_skip_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tmx_skipcheck_inputs_from_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p,
+                                                 C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(C.c_uint32)]
     L.tmx_pack_skip_input.argtypes = [C.c_uint64, C.c_char_p, C.c_uint64, C.c_char_p]
     L.tmx_pack_skip_input.restype = None
     L.tmx_unpack_skip_input.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.c_char_p, C.POINTER(C.c_uint64)]

@@ -75,6 +75,42 @@ class InputDataFetcher:
         return bytes(proof), bytes(target)
 
 
+    # ---- operator side
+    def get_skipcheck_inputs(self, n_max, start_block, target_block):
+        """Address/power records of the start set, the target set and the target commit for is_valid_skip."""
+        from ._lib import AddrRec
+        start, target, sigs = (AddrRec * n_max)(), (AddrRec * n_max)(), (AddrRec * n_max)()
+        ns, nt, ng = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        st = self._L.tmx_skipcheck_inputs_from_json(self.get_validator_set_json(start_block), self.get_validator_set_json(target_block),
+                                                    self.get_signed_header_json(target_block), n_max, start, C.byref(ns), target, C.byref(nt),
+                                                    sigs, C.byref(ng))
+        check(st)
+        return bytes(start), ns.value, bytes(target), nt.value, bytes(sigs), ng.value
+
+    def find_block_to_request(self, ctx, start_block, max_end_block):
+        """find_block_to_request (mod.rs:160-186): the reference tests max_end, then keeps halving towards start_block, one RPC round and
+        one is_valid_skip per candidate.  Here every candidate on that descent is fetched first and all predicates are evaluated in one
+        launch (tmx_valid_skip_batch); the first valid one wins, exactly as in the reference."""
+        cands, cur = [], max_end_block
+        while cur - start_block != 1:
+            cands.append(cur)
+            cur = (cur + start_block) // 2
+        if not cands:
+            return cur
+        n = ctx.n_max
+        start = None
+        targets, sigs, nts, ngs = [], [], [], []
+        for cb in cands:
+            s, ns, t, nt, g, ng = self.get_skipcheck_inputs(n, start_block, cb)
+            start, n_start = s, ns
+            targets.append(t); sigs.append(g); nts.append(nt); ngs.append(ng)
+        valid, _, _ = ctx.valid_skip_batch(start, n_start, b"".join(targets), nts, b"".join(sigs), ngs)
+        for cb, ok in zip(cands, valid):
+            if ok:
+                return cb
+        return cur  # == start_block + 1: fall back to a step
+
+
 class _Circuit:
     kind = None
 

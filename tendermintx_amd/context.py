@@ -74,6 +74,16 @@ class Context:
         elems = out.reshape(n, stride)[:, :count] if want_elems else None
         return elems, [r.as_dict() for r in reps]
 
+    def valid_skip_batch(self, start, n_start, targets, n_targets, sigs, n_sigs):
+        """is_valid_skip for len(n_targets) candidates.  start: bytes [n_max x 32]; targets, sigs: bytes [n_cand x n_max x 32].
+        Returns (valid [bool], shared power [int], total power [int])."""
+        nc = len(n_targets)
+        assert len(targets) == nc * self.n_max * 32 == len(sigs)
+        nt, ns = (C.c_uint32 * nc)(*n_targets), (C.c_uint32 * nc)(*n_sigs)
+        valid, sh, to = (C.c_uint8 * nc)(), (C.c_uint64 * nc)(), (C.c_uint64 * nc)()
+        check(self._L.tmx_valid_skip_batch(self._h, nc, bytes(start), n_start, bytes(targets), nt, bytes(sigs), ns, valid, sh, to), self._h)
+        return [bool(v) for v in valid], list(sh), list(to)
+
     def eddsa_lanes(self, lanes):
         n = len(lanes) // 256
         out = np.zeros(n * _lib.ED_STRIDE, dtype=np.uint8)

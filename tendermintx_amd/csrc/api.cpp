@@ -651,6 +651,41 @@ int32_t tmx_eddsa_lanes(tmx_ctx* c, uint32_t n_lanes, const tmx_validator_rec* l
   return TMX_OK;
 }
 
+int32_t tmx_valid_skip_batch(tmx_ctx* c, uint32_t n_cand, const tmx_addr_rec* start, uint32_t n_start, const tmx_addr_rec* targets,
+                             const uint32_t* n_targets, const tmx_addr_rec* sigs, const uint32_t* n_sigs, uint8_t* valid, uint64_t* shared_power,
+                             uint64_t* total_power) {
+  if (!c || !start || !targets || !n_targets || !sigs || !n_sigs || !valid || !shared_power || !total_power) return TMX_ERR_BAD_ARG;
+  if (n_cand == 0) return TMX_OK;
+  const uint32_t n = c->cfg.n_max;
+  if (n_start > n) return fail(c, TMX_ERR_SET_TOO_LARGE, "start validator set larger than VALIDATOR_SET_SIZE_MAX");
+  static_assert(sizeof(tmx_addr_rec) == 32, "address record layout");
+  const size_t per = (size_t)n * 32;
+  // small, latency-only call: temporary device buffers on the context's stream
+  void *d_start = nullptr, *d_t = nullptr, *d_s = nullptr, *d_nt = nullptr, *d_ns = nullptr, *d_v = nullptr, *d_sh = nullptr, *d_to = nullptr;
+  auto cleanup = [&]() { for (void* p : {d_start, d_t, d_s, d_nt, d_ns, d_v, d_sh, d_to}) if (p) (void)hipFree(p); };
+  hipError_t e = hipSuccess;
+  auto ck = [&](hipError_t r) { if (e == hipSuccess && r != hipSuccess) e = r; };
+  ck(hipMalloc(&d_start, per)); ck(hipMalloc(&d_t, per * n_cand)); ck(hipMalloc(&d_s, per * n_cand)); ck(hipMalloc(&d_nt, 4 * (size_t)n_cand));
+  ck(hipMalloc(&d_ns, 4 * (size_t)n_cand)); ck(hipMalloc(&d_v, n_cand)); ck(hipMalloc(&d_sh, 8 * (size_t)n_cand)); ck(hipMalloc(&d_to, 8 * (size_t)n_cand));
+  if (e == hipSuccess) {
+    ck(hipMemcpyAsync(d_start, start, (size_t)n_start * 32, hipMemcpyHostToDevice, c->stream));
+    ck(hipMemcpyAsync(d_t, targets, per * n_cand, hipMemcpyHostToDevice, c->stream));
+    ck(hipMemcpyAsync(d_s, sigs, per * n_cand, hipMemcpyHostToDevice, c->stream));
+    ck(hipMemcpyAsync(d_nt, n_targets, 4 * (size_t)n_cand, hipMemcpyHostToDevice, c->stream));
+    ck(hipMemcpyAsync(d_ns, n_sigs, 4 * (size_t)n_cand, hipMemcpyHostToDevice, c->stream));
+  }
+  if (e == hipSuccess) ck((hipError_t)launch_valid_skip(n_cand, n, d_start, n_start, d_t, d_nt, d_s, d_ns, d_v, d_sh, d_to, c->stream));
+  if (e == hipSuccess) {
+    ck(hipMemcpyAsync(valid, d_v, n_cand, hipMemcpyDeviceToHost, c->stream));
+    ck(hipMemcpyAsync(shared_power, d_sh, 8 * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
+    ck(hipMemcpyAsync(total_power, d_to, 8 * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
+    ck(hipStreamSynchronize(c->stream));
+  }
+  cleanup();
+  if (e != hipSuccess) return fail(c, TMX_ERR_HIP, std::string("tmx_valid_skip_batch: ") + hipGetErrorString(e));
+  return TMX_OK;
+}
+
 // ---- public I/O packing (big-endian, abi.encodePacked): TendermintX.sol:104-108, skip.rs:120-122, step.rs:107-108
 static void be64(uint64_t v, uint8_t* o) { for (int i = 0; i < 8; i++) o[i] = (uint8_t)(v >> (56 - 8 * i)); }
 static uint64_t rd_be64(const uint8_t* p) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | p[i]; return v; }

@@ -516,4 +516,61 @@ int32_t tmx_step_inputs_from_json(const char* prev_commit_json, const char* next
   return build_target_lanes(nv, nsh, n_max, target);
 }
 
+// records for tmx_valid_skip_batch: validator sets by address, commit signatures by address (tendermint_utils.rs:444-482)
+int32_t tmx_skipcheck_inputs_from_json(const char* start_validators_json, const char* target_validators_json, const char* target_commit_json,
+                                       uint32_t n_max, tmx_addr_rec* start, uint32_t* n_start, tmx_addr_rec* target, uint32_t* n_target,
+                                       tmx_addr_rec* sigs, uint32_t* n_sigs) {
+  if (!start_validators_json || !target_validators_json || !target_commit_json || !start || !n_start || !target || !n_target || !sigs || !n_sigs ||
+      n_max == 0 || n_max > TMX_N_MAX_LIMIT)
+    return TMX_ERR_BAD_ARG;
+  std::vector<JPtr> keep;
+  std::vector<Validator> sv, tv;
+  int32_t st;
+  if ((st = parse_validators(start_validators_json, sv, keep))) return st;
+  if ((st = parse_validators(target_validators_json, tv, keep))) return st;
+  if (sv.size() > n_max || tv.size() > n_max) return TMX_ERR_SET_TOO_LARGE;
+  auto by_power = [](const Validator& a, const Validator& b) {  // Set::new order (power desc, address asc); the result does not depend on it
+    if (a.power != b.power) return a.power > b.power;
+    return a.address < b.address;
+  };
+  std::stable_sort(sv.begin(), sv.end(), by_power);
+  std::stable_sort(tv.begin(), tv.end(), by_power);
+  auto fill = [&](const std::vector<Validator>& v, tmx_addr_rec* out) {
+    std::memset(out, 0, sizeof(tmx_addr_rec) * n_max);
+    for (size_t i = 0; i < v.size(); i++) {
+      if (v[i].address.size() != 20) return false;
+      std::memcpy(out[i].address, v[i].address.data(), 20);
+      out[i].has_address = 1;
+      out[i].voting_power = v[i].power;
+    }
+    return true;
+  };
+  if (!fill(sv, start) || !fill(tv, target)) return TMX_ERR_PARSE;
+  *n_start = (uint32_t)sv.size();
+  *n_target = (uint32_t)tv.size();
+  // signatures: raw JSON again for the addresses (SignedHeader above keeps only what the witness path needs)
+  JParser P{target_commit_json, target_commit_json + std::strlen(target_commit_json)};
+  JPtr root = P.parse();
+  if (!P.ok) return TMX_ERR_PARSE;
+  const JVal* res = root->get("result");
+  const JVal* sh = res ? res->get("signed_header") : nullptr;
+  const JVal* cm = sh ? sh->get("commit") : nullptr;
+  const JVal* sg = cm ? cm->get("signatures") : nullptr;
+  if (!sg || sg->kind != JVal::Arr) return TMX_ERR_PARSE;
+  if (sg->a.size() > n_max) return TMX_ERR_SET_TOO_LARGE;
+  std::memset(sigs, 0, sizeof(tmx_addr_rec) * n_max);
+  for (size_t i = 0; i < sg->a.size(); i++) {
+    uint64_t flag = 0;
+    if (!to_u64(sg->a[i]->get("block_id_flag"), flag)) return TMX_ERR_PARSE;
+    const JVal* ad = sg->a[i]->get("validator_address");
+    Bytes addr;
+    if (flag != 1 && ad && ad->kind == JVal::Str && from_hex(ad->s, addr) && addr.size() == 20) {  // absent votes carry no address
+      std::memcpy(sigs[i].address, addr.data(), 20);
+      sigs[i].has_address = 1;
+    }
+  }
+  *n_sigs = (uint32_t)sg->a.size();
+  return TMX_OK;
+}
+
 }  // extern "C"
