@@ -67,6 +67,7 @@ struct Program {
   SerializeProgram sp;
   std::vector<uint32_t> lut;
   uint32_t mask_inputs = 0, mask_proof = 0, mask_final = 0;  // sections by readiness: inputs only / after k_proof / after EdDSA
+  std::vector<uint32_t> seam_waves;  // indices of the spans that straddle a boundary (0xff entries of wave_sec)
   std::vector<uint8_t> wave_sec;  // per 128-element span of a row: its section, or 0xff if it straddles a boundary / the row end
   uint32_t hint_elems;
 };
@@ -202,6 +203,7 @@ Program build_program(int kind, uint32_t n) {
         const uint32_t lo = P.sp.sec[s].elem_start, hi = lo + P.sp.sec[s].lane_elems * P.sp.sec[s].n_lanes;
         if (first >= lo && last < hi) sec = (uint8_t)s;
       }
+    if (sec == 0xff) P.seam_waves.push_back(w);
     P.wave_sec.push_back(sec);
   }
   return P;
@@ -226,6 +228,7 @@ struct tmx_ctx {
   Program prog[2];
   void* d_lut[2] = {nullptr, nullptr};
   void* d_wave_sec[2] = {nullptr, nullptr};
+  void* d_seams[2] = {nullptr, nullptr};
   void* d_table = nullptr;
   void *d_qtable = nullptr, *d_pre = nullptr, *d_mulout = nullptr;
   void *d_hash = nullptr, *d_cnt = nullptr, *d_owner_of = nullptr, *d_uid_of_owner = nullptr, *d_owners = nullptr, *d_keyrec = nullptr,
@@ -286,7 +289,8 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   const Program& prog = c->prog[kind];
   auto serialize = [&](uint32_t mask, hipStream_t on) -> int32_t {
     if (!d_out_elems) return TMX_OK;
-    int r = launch_serialize(prog.sp, src, c->d_lut[kind], c->d_wave_sec[kind], n_proofs, d_out_elems, mask, on);
+    int r = launch_serialize(prog.sp, src, c->d_lut[kind], c->d_wave_sec[kind], c->d_seams[kind], (uint32_t)prog.seam_waves.size(), n_proofs,
+                             d_out_elems, mask, on);
     if (r) return fail(c, TMX_ERR_HIP, std::string("k_serialize launch: ") + hipGetErrorString((hipError_t)r));
     return TMX_OK;
   };
@@ -393,7 +397,7 @@ const char* tmx_last_error(const tmx_ctx* ctx) { return ctx ? ctx->err.c_str() :
 
 void tmx_ctx_destroy(tmx_ctx* c) {
   if (!c) return;
-  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_owner_of, c->d_uid_of_owner, c->d_owners, c->d_keyrec,
+  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_owner_of, c->d_uid_of_owner, c->d_owners, c->d_keyrec,
                   c->d_anchors, c->d_keytab, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
                   c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out};
   for (void* b : bufs)
@@ -456,6 +460,8 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     HIPCK(c, hipMemcpyAsync(c->d_lut[k], c->prog[k].lut.data(), c->prog[k].lut.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMalloc(&c->d_wave_sec[k], c->prog[k].wave_sec.size()));
     HIPCK(c, hipMemcpyAsync(c->d_wave_sec[k], c->prog[k].wave_sec.data(), c->prog[k].wave_sec.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMalloc(&c->d_seams[k], c->prog[k].seam_waves.size() * 4 + 4));
+    HIPCK(c, hipMemcpyAsync(c->d_seams[k], c->prog[k].seam_waves.data(), c->prog[k].seam_waves.size() * 4, hipMemcpyHostToDevice, c->stream));
   }
   HIPCK(c, hipMalloc(&c->d_table, base_table_bytes()));
   HIPCK(c, hipMalloc(&c->d_ed, lanes * ED_STRIDE));
