@@ -37,16 +37,16 @@ namespace {
 
 struct LutBuilder {  // offsets are relative to the section's single source record
   std::vector<uint32_t> v;
-  void bytes(uint32_t off, uint32_t n) {
+  void bytes(uint32_t off, uint32_t n) {  // ByteVariable: 8 elements per byte, most significant bit first
     for (uint32_t i = 0; i < n; i++)
-      for (uint32_t k = 0; k < 8; k++) v.push_back(lut_entry(CODE_BIT0 + k, off + i));
+      for (uint32_t k = 0; k < 8; k++) v.push_back(lut_field(W_BIT, off + i, 7 - k));
   }
-  void u8(uint32_t off) { v.push_back(lut_entry(CODE_U8, off)); }
-  void u16(uint32_t off) { v.push_back(lut_entry(CODE_U16, off)); }
-  void u32(uint32_t off) { v.push_back(lut_entry(CODE_U32, off)); }
+  void u8(uint32_t off) { v.push_back(lut_field(W_U8, off, 0)); }
+  void u16(uint32_t off) { v.push_back(lut_field(W_U16, off, 0)); }  // 2-aligned inside its dword
+  void u32(uint32_t off) { v.push_back(lut_field(W_U32, off, 0)); }  // 4-aligned
   void u64(uint32_t off) { u32(off); u32(off + 4); }
   void u256(uint32_t off) { for (uint32_t k = 0; k < 8; k++) u32(off + 4 * k); }
-  void flag0(uint32_t off) { v.push_back(lut_entry(CODE_FLAG0, off)); }
+  void flag0(uint32_t off) { v.push_back(lut_field(W_BIT, off, 0)); }
 };
 
 uint32_t tree_nodes(uint32_t n) {
@@ -85,7 +85,7 @@ Program build_program(int kind, uint32_t n) {
     Section& s = P.sp.sec[P.sp.n_sections++];
     s.elem_start = elem; s.lane_elems = lane_elems; s.n_lanes = n_lanes; s.lut_off = lut_off; s.kind = kind_; s.src = src;
     s.magic = (uint32_t)((0x100000000ull + lane_elems - 1) / lane_elems);  // lane = mulhi(rel, magic); rel * lane_elems < 2^32 here
-    s.pad = 0;
+    s.rec_stride = 0; s.rec_mul = 0; s.pad = 0; s.base = nullptr;
     elem += lane_elems * n_lanes;
   };
   uint32_t mark;
@@ -397,6 +397,10 @@ const char* tmx_last_error(const tmx_ctx* ctx) { return ctx ? ctx->err.c_str() :
 
 void tmx_ctx_destroy(tmx_ctx* c) {
   if (!c) return;
+  if (c->stream) {  // side streams may still hold work enqueued by the last call (hash-table reset for the next launch)
+    (void)hipSetDevice(c->cfg.device);
+    (void)hipDeviceSynchronize();
+  }
   void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_owner_of, c->d_uid_of_owner, c->d_owners, c->d_keyrec,
                   c->d_anchors, c->d_keytab, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
                   c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out};
@@ -593,6 +597,7 @@ int32_t tmx_last_kernel_ms(tmx_ctx* c, float ms[TMX_N_KERNELS]) { return tmx_ker
 
 static int32_t ensure_staging(tmx_ctx* c) {
   if (c->d_in_proofs) return TMX_OK;
+  HIPCK(c, hipSetDevice(c->cfg.device));
   const size_t B = c->cfg.max_batch, lanes = B * c->cfg.n_max;
   HIPCK(c, hipMalloc(&c->d_in_proofs, B * sizeof(tmx_proof_rec)));
   HIPCK(c, hipMalloc(&c->d_in_targets, lanes * sizeof(tmx_validator_rec)));

@@ -46,10 +46,15 @@ constexpr uint32_t HDR_SIZE = 1136, PR_STRIDE = 2336, PR_OFF_BLOCK_A = 0, PR_OFF
                    PR_OFF_NB_A = 56, PR_OFF_NB_B = 60, PR_OFF_HDR_A = 64, PR_OFF_HDR_B = 64 + HDR_SIZE;
 
 // ---- serializer program: the element stream is a list of sections; fixed and per-lane sections are driven by
-// look-up tables with one u32 per element:  code[28:24] | byte offset[23:0]; every section reads ONE source buffer
+// look-up tables with one u32 per element (lut_field below); every section reads ONE source buffer
 enum : uint32_t { SRC_TARGET = 0, SRC_TRUSTED = 1, SRC_TL = 2, SRC_LR = 3, SRC_PF = 4, SRC_COUNT = 5 };
-enum : uint32_t { CODE_BIT0 = 0 /* ..7: BE bit k of the byte */, CODE_U8 = 8, CODE_U16 = 9, CODE_U32 = 10, CODE_FLAG0 = 11 /* byte&1 */ };
-constexpr uint32_t lut_entry(uint32_t code, uint32_t off) { return (code << 24) | off; }
+// One entry describes a bit-field of a 4-byte-aligned dword of the source record (every multi-byte field of the records is 4-aligned):
+//   width code [31:30] (0: 1 bit, 1: 8 bits, 2: 16 bits, 3: the whole dword) | first bit [29:25] | aligned byte offset [24:0]
+// so the kernel is one aligned dword load + one bit-field extract per element, with no branches on the field type.
+enum : uint32_t { W_BIT = 0, W_U8 = 1, W_U16 = 2, W_U32 = 3 };
+constexpr uint32_t lut_field(uint32_t width_code, uint32_t byte_off, uint32_t bit_in_byte) {
+  return (width_code << 30) | ((8 * (byte_off & 3u) + bit_in_byte) << 25) | (byte_off & ~3u);
+}
 
 enum : uint32_t { SEC_LUT = 0, SEC_LINEAR_T = 1, SEC_LINEAR_R = 2 };
 struct Section {
@@ -60,7 +65,11 @@ struct Section {
   uint32_t kind;
   uint32_t src;         // SRC_* buffer this section reads
   uint32_t magic;       // ceil(2^32 / lane_elems): lane = mulhi(rel, magic), exact for rel * lane_elems < 2^32
+  // resolved per launch (launch_serialize) so that the kernel does no buffer selection:
+  uint32_t rec_stride;  // bytes per source record
+  uint32_t rec_mul;     // record = proof * rec_mul + lane   (lanes-per-proof for per-lane buffers, 1 for per-proof ones)
   uint32_t pad;
+  const uint8_t* base;  // source buffer
 };
 constexpr int MAX_SECTIONS = 10;
 struct SerializeProgram {
