@@ -32,8 +32,8 @@ MADS_PER_KEY = 1_060_000       # once per distinct key: decode + 252 doublings +
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--proofs", type=int, default=256, help="proofs per GPU per step")
     ap.add_argument("--n-max", type=int, default=128)
     ap.add_argument("--nb", type=int, default=None, help="real validators per set (default n_max)")
@@ -122,11 +122,11 @@ def main():
         os.environ["TMX_SER_SPLIT"] = "0"
         ctx1 = Context(n, b"celestia", 100800, device=local_rank, max_batch=P)
         del os.environ["TMX_SER_SPLIT"]
-        for _ in range(6):
+        for _ in range(30):  # (the first launches after a context creation run at ramping clocks)
             ctx1.witness_batch_device(KIND_SKIP, P, d_proofs.data_ptr(), d_targets.data_ptr(), d_trusteds.data_ptr(), d_out.data_ptr(),
                                       d_rep.data_ptr(), stream.cuda_stream)
         torch.cuda.synchronize(dev)
-        k_s = ctx1.kernel_ms_mean(5)["k_serialize"]
+        k_s = ctx1.kernel_ms_mean(20)["k_serialize"]
         ctx1.close()
         # transparency: the same step with the per-key tables switched off (every lane does its own 252 doublings for h*A)
         os.environ["TMX_DEDUP"] = "0"

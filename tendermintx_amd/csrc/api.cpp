@@ -66,9 +66,9 @@ void emit_proof_d(LutBuilder& L, int q) { L.bytes(PF_OFF_PROOFD + 160 * q, 160);
 struct Program {
   SerializeProgram sp;
   std::vector<uint32_t> lut;
-  uint32_t mask_inputs = 0, mask_proof = 0, mask_final = 0;  // sections by readiness: inputs only / after k_proof / after EdDSA
+  uint32_t mask_inputs = 0, mask_proof = 0, mask_final = 0, mask_tail = 0;  // sections by readiness: inputs only / after k_proof / after EdDSA / after k_verdict
   std::vector<uint32_t> seam_waves;  // indices of the spans that straddle a boundary (0xff entries of wave_sec)
-  std::vector<uint8_t> wave_sec;  // per 128-element span of a row: its section, or 0xff if it straddles a boundary / the row end
+  std::vector<uint8_t> wave_sec;  // per sp.span-element span of a row: its section, or 0xff if it straddles a boundary / the row end
   uint32_t hint_elems;
 };
 
@@ -79,9 +79,9 @@ Program build_program(int kind, uint32_t n) {
   const bool skip = kind == TMX_KIND_SKIP;
   const uint32_t tn = tree_nodes(n);
   uint32_t elem = 0;
-  // ready: 0 = needs only the input records, 1 = needs k_proof, 2 = needs the EdDSA kernels / the verdict
+  // ready: 0 = needs only the input records, 1 = needs k_proof, 2 = needs the EdDSA kernels (and k_proof), 3 = needs k_verdict
   auto add_section = [&](uint32_t lane_elems, uint32_t n_lanes, uint32_t lut_off, uint32_t kind_, uint32_t src, int ready) {
-    (ready == 0 ? P.mask_inputs : ready == 1 ? P.mask_proof : P.mask_final) |= 1u << P.sp.n_sections;
+    (ready == 0 ? P.mask_inputs : ready == 1 ? P.mask_proof : ready == 2 ? P.mask_final : P.mask_tail) |= 1u << P.sp.n_sections;
     Section& s = P.sp.sec[P.sp.n_sections++];
     s.elem_start = elem; s.lane_elems = lane_elems; s.n_lanes = n_lanes; s.lut_off = lut_off; s.kind = kind_; s.src = src;
     s.magic = (uint32_t)((0x100000000ull + lane_elems - 1) / lane_elems);  // lane = mulhi(rel, magic); rel * lane_elems < 2^32 here
@@ -187,16 +187,19 @@ Program build_program(int kind, uint32_t n) {
   const int n_checks = skip ? 12 : 14;
   for (int k = 0; k < n_checks; k++) L.u32(PF_OFF_CHECKS + 4 * k);
   L.u32(PF_OFF_ALLOK);
-  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT, SRC_PF, 2);
-  P.mask_final |= 1u << 31;  // boundary waves are written last, when every source is ready
+  add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT, SRC_PF, 3);
+  P.mask_tail |= 1u << 31;  // boundary waves are written last, when every source is ready
 
   P.sp.elem_count = elem;
   P.sp.elem_stride = (elem + 1) & ~1u;
   P.sp.n = n;
   P.sp.tree_nodes = tn;
   P.lut = std::move(L.v);
-  for (uint32_t w = 0; w * 128 < P.sp.elem_stride; w++) {
-    const uint32_t first = w * 128, last = first + 127;
+  const char* sp_env = std::getenv("TMX_SER_SPAN");  // tuning knob; 256 measured best on MI355X
+  const uint32_t span = sp_env && (std::atoi(sp_env) == 128 || std::atoi(sp_env) == 512) ? (uint32_t)std::atoi(sp_env) : 256u;
+  P.sp.span = span;
+  for (uint32_t w = 0; w * span < P.sp.elem_stride; w++) {
+    const uint32_t first = w * span, last = first + span - 1;
     uint8_t sec = 0xff;
     if (last < P.sp.elem_count)
       for (uint32_t s = 0; s < P.sp.n_sections; s++) {
@@ -219,7 +222,9 @@ struct tmx_ctx {
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;  // k_proof runs here, concurrently with the EdDSA kernels of the caller's stream
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  hipEvent_t ev_side[EV_RING_DECL][2] = {};
+  hipEvent_t ev_side[EV_RING_DECL][4] = {};
+  hipEvent_t ev_tail = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_hash_clean = nullptr, ev_keys = nullptr, ev_mul = nullptr;
+  bool ev_mul_recorded = false;
   // ring of HIP-event sets: one set (TMX_N_KERNELS + 1 events) per enqueued batch, so that kernel durations can be
   // averaged over a whole timed region afterwards without synchronising inside it
   static constexpr int EV_RING = EV_RING_DECL;
@@ -237,7 +242,6 @@ struct tmx_ctx {
   hipStream_t side2 = nullptr;  // distinct-key pipeline, concurrent with phase 1
   hipStream_t side3 = nullptr;  // early serialization of the input-only sections
   hipEvent_t ev_join3 = nullptr;
-  hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_hash_clean = nullptr;
   uint32_t parity = 0;  // which of the two key counters this launch uses
   uint64_t last_lanes = 0;
   bool ser_split = true;  // TMX_SER_SPLIT=0: one k_serialize launch at the end (used to time the kernel on its own)
@@ -268,8 +272,9 @@ static ProofParams proof_params(const tmx_ctx* c, int32_t kind) {
   return P;
 }
 
-// Launch sequence of one batch.  Main stream s:  [ev0] EdDSA kernels [ev1] k_verdict [ev2] k_serialize [ev3]
-//                               side stream:      (after ev_fork) [side0] k_proof [side1] -> ev_join, waited on before k_verdict.
+// Launch sequence of one batch.  Main stream s:  [ev0] EdDSA kernels [ev1] (joins) [ev2] k_serialize of the EdDSA-dependent section [ev3]
+//                               side stream:      (after ev_fork) [side0] k_proof [side1] -> ev_join, waited on before the tail;
+//                               side2 (tail):     [side2] k_verdict [side3] k_serialize of the sections that carry the verdict -> ev_tail.
 // k_proof does not depend on the EdDSA results, so it overlaps with them; `ed_producer` enqueues whatever fills the ED part of
 // c->d_tl on s (the EdDSA kernels, or a strided copy of caller-provided lane records).
 template <typename EdProducer>
@@ -307,21 +312,42 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
                         c->d_nodes_r, reports, c->side);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_proof launch: ") + hipGetErrorString((hipError_t)rc));
   HIPCK(c, hipEventRecord(evs[1], c->side));
+
+  HIPCK(c, hipEventRecord(ev[0], s));
+  c->ev_mul_recorded = false;
+  int32_t st = ed_producer(s);
+  if (st) return st;
+  if (c->ev_mul_recorded) HIPCK(c, hipStreamWaitEvent(c->side, c->ev_mul, 0));
   st0 = c->ser_split ? serialize(prog.mask_proof, c->side) : TMX_OK;
   if (st0) return st0;
   HIPCK(c, hipEventRecord(c->ev_join, c->side));
-
-  HIPCK(c, hipEventRecord(ev[0], s));
-  int32_t st = ed_producer(s);
-  if (st) return st;
   HIPCK(c, hipEventRecord(ev[1], s));
-  HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
-  HIPCK(c, hipStreamWaitEvent(s, c->ev_join3, 0));
-  rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, s);
-  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
-  HIPCK(c, hipEventRecord(ev[2], s));
-  st0 = serialize(c->ser_split ? prog.mask_final : (prog.mask_inputs | prog.mask_proof | prog.mask_final), s);
-  if (st0) return st0;
+  if (c->ser_split) {
+    // tail: the per-lane derived section (a quarter of the row) only needs k_ed_fin + k_proof, so it is written on s while the
+    // verdict and the few sections that carry it go through the high-priority side stream.  (ev[2] = ev[1] here: every packet
+    // between k_ed_fin and the serializer is latency on the critical path.)
+    HIPCK(c, hipStreamWaitEvent(c->side2, ev[1], 0));
+    HIPCK(c, hipStreamWaitEvent(c->side2, evs[1], 0));  // k_proof itself, not the serializer launches queued behind it
+    HIPCK(c, hipEventRecord(evs[2], c->side2));
+    rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, c->side2);
+    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
+    HIPCK(c, hipEventRecord(evs[3], c->side2));
+    if ((st0 = serialize(prog.mask_tail, c->side2))) return st0;
+    HIPCK(c, hipEventRecord(c->ev_tail, c->side2));
+    HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
+    if ((st0 = serialize(prog.mask_final, s))) return st0;
+    HIPCK(c, hipStreamWaitEvent(s, c->ev_tail, 0));
+    HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));   // the early serializer launches on the low-priority streams
+    HIPCK(c, hipStreamWaitEvent(s, c->ev_join3, 0));
+  } else {
+    HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    HIPCK(c, hipEventRecord(evs[2], s));
+    rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, s);
+    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
+    HIPCK(c, hipEventRecord(evs[3], s));
+    HIPCK(c, hipEventRecord(ev[2], s));
+    if ((st0 = serialize(prog.mask_inputs | prog.mask_proof | prog.mask_final | prog.mask_tail, s))) return st0;
+  }
   HIPCK(c, hipEventRecord(ev[3], s));
   c->n_calls++;
   return TMX_OK;
@@ -334,7 +360,7 @@ static int32_t check_batch_args(tmx_ctx* c, int32_t kind, uint32_t n_proofs, con
   return TMX_OK;
 }
 
-// EdDSA stage on stream s.  Quad path: the distinct-key pipeline runs on side2 beside phase 1, both join before h*A.
+// EdDSA stage: begins and ends on stream s.
 static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_ed, uint32_t ed_stride, hipStream_t s) {
   if (!c->quad) return launch_eddsa(n_lanes, d_lanes, d_ed, ed_stride, c->d_table, s);
   EdQuad Q;
@@ -347,21 +373,35 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1);
   c->parity ^= 1;
   hipError_t e;
-  // the hash table was cleared on side2 at the end of the previous launch (or at context creation)
-  if ((e = hipStreamWaitEvent(s, c->ev_hash_clean, 0)) != hipSuccess) return (int)e;
+  // dedup on s, then the distinct-key pipeline (decode -> anchors -> table: a latency chain of a few waves) on the high-priority
+  // stream side2 beside phase 1 on s; both join before h*A.  (Queue priority also decides which waves issue first on a shared
+  // SIMD: with the chain on a normal-priority queue k_ed_keys alone takes 230 us instead of 100.)
+  if ((e = hipStreamWaitEvent(s, c->ev_hash_clean, 0)) != hipSuccess) return (int)e;  // cleared on side2 by the previous launch
   int rc = launch_ed_dedup(Q, s);
   if (rc) return rc;
   if ((e = hipEventRecord(c->ev_fork2, s)) != hipSuccess) return (int)e;
   if ((e = hipStreamWaitEvent(c->side2, c->ev_fork2, 0)) != hipSuccess) return (int)e;
-  rc = launch_ed_keys_pipeline(Q, c->side2);
+  rc = launch_ed_keys(Q, c->side2);
+  if (rc) return rc;
+  if ((e = hipEventRecord(c->ev_keys, c->side2)) != hipSuccess) return (int)e;
+  rc = launch_ed_key_tables(Q, c->side2);
   if (rc) return rc;
   if ((e = hipEventRecord(c->ev_join2, c->side2)) != hipSuccess) return (int)e;
   if ((e = hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, c->side2)) != hipSuccess) return (int)e;  // for the next launch
   if ((e = hipEventRecord(c->ev_hash_clean, c->side2)) != hipSuccess) return (int)e;
   rc = launch_ed_phase1(Q, s);
   if (rc) return rc;
+  if ((e = hipStreamWaitEvent(s, c->ev_keys, 0)) != hipSuccess) return (int)e;
+  rc = launch_ed_mul_direct(Q, s);  // empty when the tables are used: enqueued before the wait for them
+  if (rc) return rc;
   if ((e = hipStreamWaitEvent(s, c->ev_join2, 0)) != hipSuccess) return (int)e;
-  return launch_ed_mul_fin(Q, s);
+  rc = launch_ed_mul_tab(Q, s);
+  if (rc) return rc;
+  // the table walk is the one EdDSA kernel that streams from L2 / HBM: run_batch holds the serializer launches of the side stream
+  // back until it is done (beside it they double its run time; beside the latency-bound k_ed_fin they are free)
+  if ((e = hipEventRecord(c->ev_mul, s)) != hipSuccess) return (int)e;
+  c->ev_mul_recorded = true;
+  return launch_ed_fin(Q, s);
 }
 
 extern "C" {
@@ -416,8 +456,11 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
   if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
+  if (c->ev_keys) (void)hipEventDestroy(c->ev_keys);
+  if (c->ev_mul) (void)hipEventDestroy(c->ev_mul);
   if (c->ev_hash_clean) (void)hipEventDestroy(c->ev_hash_clean);
   if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
+  if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
   if (c->side3) (void)hipStreamDestroy(c->side3);
   if (c->side2) (void)hipStreamDestroy(c->side2);
   if (c->side) (void)hipStreamDestroy(c->side);
@@ -446,8 +489,11 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   HIPCK(c, hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, prio_high));
   HIPCK(c, hipStreamCreateWithPriority(&c->side3, hipStreamNonBlocking, prio_low));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_mul, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_hash_clean, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -587,8 +633,8 @@ int32_t tmx_kernel_ms_mean(tmx_ctx* c, uint32_t last_k, float ms[TMX_N_KERNELS])
     float t = 0;
     HIPCK(c, hipEventElapsedTime(&t, ev[0], ev[1])); acc[TMX_K_EDDSA] += t;
     HIPCK(c, hipEventElapsedTime(&t, evs[0], evs[1])); acc[TMX_K_PROOF] += t;
-    HIPCK(c, hipEventElapsedTime(&t, ev[1], ev[2])); acc[TMX_K_VERDICT] += t;
-    HIPCK(c, hipEventElapsedTime(&t, ev[2], ev[3])); acc[TMX_K_SERIALIZE] += t;
+    HIPCK(c, hipEventElapsedTime(&t, evs[2], evs[3])); acc[TMX_K_VERDICT] += t;
+    HIPCK(c, hipEventElapsedTime(&t, c->ser_split ? ev[1] : ev[2], ev[3])); acc[TMX_K_SERIALIZE] += t;
   }
   for (int k = 0; k < TMX_N_KERNELS; k++) ms[k] = (float)(acc[k] / last_k);
   return TMX_OK;

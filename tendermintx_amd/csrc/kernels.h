@@ -35,9 +35,12 @@ size_t anchor_bytes_per_key();
 size_t keytab_bytes_per_key();
 int launch_init_base_quad(const void* d_table, void* d_qtable, void* stream);
 int launch_ed_dedup(const EdQuad& Q, void* stream);
-int launch_ed_keys_pipeline(const EdQuad& Q, void* stream);
+int launch_ed_keys(const EdQuad& Q, void* stream);
+int launch_ed_key_tables(const EdQuad& Q, void* stream);
+int launch_ed_mul_direct(const EdQuad& Q, void* stream);
 int launch_ed_phase1(const EdQuad& Q, void* stream);
-int launch_ed_mul_fin(const EdQuad& Q, void* stream);
+int launch_ed_mul_tab(const EdQuad& Q, void* stream);
+int launch_ed_fin(const EdQuad& Q, void* stream);
 int launch_proof(const ProofParams& P, uint32_t n_proofs, const void* d_proofs, const void* d_target, const void* d_trusted, void* d_lt,
                  uint32_t lt_stride, void* d_lr, void* d_pf, void* d_nodes_t, void* d_nodes_r, void* d_reports, void* stream);
 int launch_valid_skip(uint32_t n_cand, uint32_t n_max, const void* d_start, uint32_t n_start, const void* d_targets, const void* d_nt, const void* d_sigs,

@@ -79,6 +79,7 @@ struct SerializeProgram {
   uint32_t elem_stride;  // row stride (even)
   uint32_t n;            // lanes per proof
   uint32_t tree_nodes;   // nodes per validator tree
+  uint32_t span;         // elements one wave serializes (128, 256 or 512): SPAN/128 coalesced 16-byte stores per thread, all loads in flight together
 };
 struct SerializeSources {
   const uint8_t* base[SRC_COUNT];

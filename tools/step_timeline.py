@@ -4,8 +4,9 @@ import sqlite3
 import sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name,start,end,stream_id from kernels order by start").fetchall()
-ser = [i for i, r in enumerate(rows) if "k_serialize" in r[0] and r[2] - r[1] > 100000]
-i1, i2 = ser[-3], ser[-2]
+# a step starts with k_ed_dedup; print the step before the last one
+ded = [i for i, r in enumerate(rows) if "k_ed_dedup" in r[0]]
+i1, i2 = ded[-2] - 1, ded[-1] - 1
 t0 = None
 for r in rows[i1 + 1:i2 + 1]:
     if t0 is None:
