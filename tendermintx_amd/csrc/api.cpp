@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -225,6 +226,7 @@ struct tmx_ctx {
   hipEvent_t ev_side[EV_RING_DECL][4] = {};
   hipEvent_t ev_tail = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_hash_clean = nullptr, ev_keys = nullptr, ev_mul = nullptr;
   bool ev_mul_recorded = false;
+  bool have_streams = false;
   // ring of HIP-event sets: one set (TMX_N_KERNELS + 1 events) per enqueued batch, so that kernel durations can be
   // averaged over a whole timed region afterwards without synchronising inside it
   static constexpr int EV_RING = EV_RING_DECL;
@@ -435,9 +437,67 @@ uint64_t tmx_hint_elem_count(int32_t kind, uint32_t n) {
 
 const char* tmx_last_error(const tmx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+}  // extern "C"
+
+// One set of streams per device, shared by every context of the process.  The HIP runtime multiplexes streams onto at most four
+// hardware queues per priority level, and two streams that land on the same queue lose their concurrency (measured: a step goes
+// from 0.86 ms to 1.3-1.7 ms once a fifth stream of a level exists) -- so streams are treated as a scarce per-process resource.
+// Sharing is safe: every cross-stream dependency of a batch is an event of its own context; stream order only adds ordering.
+namespace {
+struct DeviceStreams {
+  hipStream_t stream = nullptr, side = nullptr, side2 = nullptr, side3 = nullptr;
+  int refs = 0;
+};
+std::mutex g_streams_mu;
+DeviceStreams g_streams[64];
+
+hipError_t acquire_streams(int device, DeviceStreams** out) {
+  std::lock_guard<std::mutex> lk(g_streams_mu);
+  DeviceStreams& d = g_streams[device];
+  if (d.refs == 0) {
+    // The key pipeline is on the critical path (high priority); k_proof and the early serialization only fill otherwise idle
+    // resources and must not starve the caller's stream (low priority).
+    int prio_low = 0, prio_high = 0;
+    hipError_t e;
+    if ((e = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high)) != hipSuccess) return e;
+    if ((e = hipStreamCreateWithPriority(&d.side, hipStreamNonBlocking, prio_low)) != hipSuccess) return e;
+    if ((e = hipStreamCreateWithPriority(&d.side2, hipStreamNonBlocking, prio_high)) != hipSuccess) return e;
+    if ((e = hipStreamCreateWithPriority(&d.side3, hipStreamNonBlocking, prio_low)) != hipSuccess) return e;
+  }
+  d.refs++;
+  *out = &d;
+  return hipSuccess;
+}
+// The normal-priority stream the host-buffer entry points work on: created on first use, because the device-pointer entry points
+// run on the caller's stream and an idle extra stream would still take one of the four normal-priority hardware queues.
+hipError_t host_stream(int device, hipStream_t* out) {
+  std::lock_guard<std::mutex> lk(g_streams_mu);
+  DeviceStreams& d = g_streams[device];
+  if (!d.stream) {
+    hipError_t e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+  }
+  *out = d.stream;
+  return hipSuccess;
+}
+void release_streams(int device) {
+  std::lock_guard<std::mutex> lk(g_streams_mu);
+  DeviceStreams& d = g_streams[device];
+  if (d.refs > 0 && --d.refs == 0) {
+    if (d.side3) (void)hipStreamDestroy(d.side3);
+    if (d.side2) (void)hipStreamDestroy(d.side2);
+    if (d.side) (void)hipStreamDestroy(d.side);
+    if (d.stream) (void)hipStreamDestroy(d.stream);
+    d = DeviceStreams();
+  }
+}
+}  // namespace
+
+extern "C" {
+
 void tmx_ctx_destroy(tmx_ctx* c) {
   if (!c) return;
-  if (c->stream) {  // side streams may still hold work enqueued by the last call (hash-table reset for the next launch)
+  if (c->have_streams) {  // side streams may still hold work enqueued by the last call (hash-table reset for the next launch)
     (void)hipSetDevice(c->cfg.device);
     (void)hipDeviceSynchronize();
   }
@@ -461,10 +521,7 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   if (c->ev_hash_clean) (void)hipEventDestroy(c->ev_hash_clean);
   if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
   if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
-  if (c->side3) (void)hipStreamDestroy(c->side3);
-  if (c->side2) (void)hipStreamDestroy(c->side2);
-  if (c->side) (void)hipStreamDestroy(c->side);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->have_streams) release_streams(c->cfg.device);
   delete c;
 }
 
@@ -480,14 +537,11 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   if (e != hipSuccess || ndev <= 0) return fail(c, TMX_ERR_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
   if (cfg->device < 0 || cfg->device >= ndev) return fail(c, TMX_ERR_BAD_ARG, "device ordinal out of range");
   HIPCK(c, hipSetDevice(cfg->device));
-  HIPCK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  // The key pipeline is on the critical path (high priority); k_proof and the early serialization only fill otherwise idle
-  // resources and must not starve the caller's stream (low priority).
-  int prio_low = 0, prio_high = 0;
-  HIPCK(c, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-  HIPCK(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_low));
-  HIPCK(c, hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, prio_high));
-  HIPCK(c, hipStreamCreateWithPriority(&c->side3, hipStreamNonBlocking, prio_low));
+  if (cfg->device >= 64) return fail(c, TMX_ERR_BAD_ARG, "device ordinal out of range");
+  DeviceStreams* ds = nullptr;
+  HIPCK(c, acquire_streams(cfg->device, &ds));
+  c->side = ds->side; c->side2 = ds->side2; c->side3 = ds->side3;
+  c->have_streams = true;
   HIPCK(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming));
@@ -507,11 +561,11 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     c->prog[k] = build_program(k, n);
     if (c->prog[k].sp.elem_count != tmx_elem_count(k, n)) return fail(c, TMX_ERR_BAD_ARG, "internal: layout size mismatch");
     HIPCK(c, hipMalloc(&c->d_lut[k], c->prog[k].lut.size() * 4));
-    HIPCK(c, hipMemcpyAsync(c->d_lut[k], c->prog[k].lut.data(), c->prog[k].lut.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->d_lut[k], c->prog[k].lut.data(), c->prog[k].lut.size() * 4, hipMemcpyHostToDevice, c->side2));
     HIPCK(c, hipMalloc(&c->d_wave_sec[k], c->prog[k].wave_sec.size()));
-    HIPCK(c, hipMemcpyAsync(c->d_wave_sec[k], c->prog[k].wave_sec.data(), c->prog[k].wave_sec.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->d_wave_sec[k], c->prog[k].wave_sec.data(), c->prog[k].wave_sec.size(), hipMemcpyHostToDevice, c->side2));
     HIPCK(c, hipMalloc(&c->d_seams[k], c->prog[k].seam_waves.size() * 4 + 4));
-    HIPCK(c, hipMemcpyAsync(c->d_seams[k], c->prog[k].seam_waves.data(), c->prog[k].seam_waves.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->d_seams[k], c->prog[k].seam_waves.data(), c->prog[k].seam_waves.size() * 4, hipMemcpyHostToDevice, c->side2));
   }
   HIPCK(c, hipMalloc(&c->d_table, base_table_bytes()));
   HIPCK(c, hipMalloc(&c->d_ed, lanes * ED_STRIDE));
@@ -522,7 +576,7 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   HIPCK(c, hipMalloc(&c->d_nodes_t, B * (tn + 1) * 32));
   HIPCK(c, hipMalloc(&c->d_nodes_r, B * (tn + 1) * 32));
   HIPCK(c, hipMalloc(&c->d_reports, B * sizeof(tmx_report)));
-  int rc = launch_init_base(c->d_table, c->stream);
+  int rc = launch_init_base(c->d_table, c->side2);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_init_base launch: ") + hipGetErrorString((hipError_t)rc));
   const char* ss = std::getenv("TMX_SER_SPLIT");
   c->ser_split = !(ss && ss[0] == '0');
@@ -554,13 +608,19 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     HIPCK(c, hipMalloc(&c->d_anchors, kc * anchor_bytes_per_key()));
     HIPCK(c, hipMalloc(&c->d_keytab, kc * keytab_bytes_per_key()));
   }
-  rc = launch_init_base_quad(c->d_table, c->d_qtable, c->stream);
+  rc = launch_init_base_quad(c->d_table, c->d_qtable, c->side2);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_init_base_quad launch: ") + hipGetErrorString((hipError_t)rc));
-  HIPCK(c, hipStreamSynchronize(c->stream));
+  HIPCK(c, hipStreamSynchronize(c->side2));
   return TMX_OK;
 }
 
-void* tmx_ctx_stream(tmx_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) : nullptr; }
+static int32_t ensure_host_stream(tmx_ctx* c) {
+  if (c->stream) return TMX_OK;
+  HIPCK(c, hipSetDevice(c->cfg.device));
+  HIPCK(c, host_stream(c->cfg.device, &c->stream));
+  return TMX_OK;
+}
+void* tmx_ctx_stream(tmx_ctx* c) { return c && ensure_host_stream(c) == TMX_OK ? reinterpret_cast<void*>(c->stream) : nullptr; }
 
 // distinct public keys seen by the last EdDSA launch and whether the per-key table path was taken (blocks until that launch is done)
 int32_t tmx_last_dedup(tmx_ctx* c, uint32_t* n_unique, uint32_t* used_tables) {
@@ -577,7 +637,7 @@ int32_t tmx_last_dedup(tmx_ctx* c, uint32_t* n_unique, uint32_t* used_tables) {
 
 int32_t tmx_sync(tmx_ctx* c) {
   if (!c) return TMX_ERR_BAD_ARG;
-  HIPCK(c, hipStreamSynchronize(c->stream));
+  if (c->stream) HIPCK(c, hipStreamSynchronize(c->stream));  // (the host-buffer entry points already synchronise before returning)
   return TMX_OK;
 }
 
@@ -642,6 +702,8 @@ int32_t tmx_kernel_ms_mean(tmx_ctx* c, uint32_t last_k, float ms[TMX_N_KERNELS])
 int32_t tmx_last_kernel_ms(tmx_ctx* c, float ms[TMX_N_KERNELS]) { return tmx_kernel_ms_mean(c, 1, ms); }
 
 static int32_t ensure_staging(tmx_ctx* c) {
+  int32_t hs = ensure_host_stream(c);
+  if (hs) return hs;
   if (c->d_in_proofs) return TMX_OK;
   HIPCK(c, hipSetDevice(c->cfg.device));
   const size_t B = c->cfg.max_batch, lanes = B * c->cfg.n_max;
@@ -716,6 +778,8 @@ int32_t tmx_valid_skip_batch(tmx_ctx* c, uint32_t n_cand, const tmx_addr_rec* st
   const uint32_t n = c->cfg.n_max;
   if (n_start > n) return fail(c, TMX_ERR_SET_TOO_LARGE, "start validator set larger than VALIDATOR_SET_SIZE_MAX");
   static_assert(sizeof(tmx_addr_rec) == 32, "address record layout");
+  int32_t hs = ensure_host_stream(c);
+  if (hs) return hs;
   const size_t per = (size_t)n * 32;
   // small, latency-only call: temporary device buffers on the context's stream
   void *d_start = nullptr, *d_t = nullptr, *d_s = nullptr, *d_nt = nullptr, *d_ns = nullptr, *d_v = nullptr, *d_sh = nullptr, *d_to = nullptr;
