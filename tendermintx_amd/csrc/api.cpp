@@ -237,6 +237,7 @@ struct tmx_ctx {
   void* d_wave_sec[2] = {nullptr, nullptr};
   void* d_seams[2] = {nullptr, nullptr};
   void* d_table = nullptr;
+  uint32_t base_w = 8;
   void *d_qtable = nullptr, *d_pre = nullptr, *d_mulout = nullptr;
   void *d_hash = nullptr, *d_cnt = nullptr, *d_owner_of = nullptr, *d_uid_of_owner = nullptr, *d_owners = nullptr, *d_keyrec = nullptr,
        *d_anchors = nullptr, *d_keytab = nullptr;
@@ -366,7 +367,7 @@ static int32_t check_batch_args(tmx_ctx* c, int32_t kind, uint32_t n_proofs, con
 static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_ed, uint32_t ed_stride, hipStream_t s) {
   if (!c->quad) return launch_eddsa(n_lanes, d_lanes, d_ed, ed_stride, c->d_table, s);
   EdQuad Q;
-  Q.n_lanes = n_lanes; Q.d_target = d_lanes; Q.d_ed = d_ed; Q.ed_stride = ed_stride; Q.d_qtable = c->d_qtable; Q.d_pre = c->d_pre;
+  Q.n_lanes = n_lanes; Q.d_target = d_lanes; Q.d_ed = d_ed; Q.ed_stride = ed_stride; Q.d_qtable = c->d_qtable; Q.base_w = c->base_w; Q.d_pre = c->d_pre;
   Q.d_mulout = c->d_mulout; Q.d_hash = c->d_hash; Q.hash_mask = c->hash_mask; Q.d_owner_of = c->d_owner_of;
   Q.d_uid_of_owner = c->d_uid_of_owner; Q.d_owners = c->d_owners; Q.d_keyrec = c->d_keyrec; Q.d_anchors = c->d_anchors; Q.d_keytab = c->d_keytab;
   Q.key_cap = c->key_cap; Q.mode = c->dedup_mode;
@@ -567,7 +568,6 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     HIPCK(c, hipMalloc(&c->d_seams[k], c->prog[k].seam_waves.size() * 4 + 4));
     HIPCK(c, hipMemcpyAsync(c->d_seams[k], c->prog[k].seam_waves.data(), c->prog[k].seam_waves.size() * 4, hipMemcpyHostToDevice, c->side2));
   }
-  HIPCK(c, hipMalloc(&c->d_table, base_table_bytes()));
   HIPCK(c, hipMalloc(&c->d_ed, lanes * ED_STRIDE));
   HIPCK(c, hipMalloc(&c->d_tl, lanes * TL_STRIDE));
   HIPCK(c, hipMalloc(&c->d_lr, lanes * LANE_STRIDE));
@@ -576,13 +576,18 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   HIPCK(c, hipMalloc(&c->d_nodes_t, B * (tn + 1) * 32));
   HIPCK(c, hipMalloc(&c->d_nodes_r, B * (tn + 1) * 32));
   HIPCK(c, hipMalloc(&c->d_reports, B * sizeof(tmx_report)));
-  int rc = launch_init_base(c->d_table, c->side2);
-  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_init_base launch: ") + hipGetErrorString((hipError_t)rc));
   const char* ss = std::getenv("TMX_SER_SPLIT");
   c->ser_split = !(ss && ss[0] == '0');
   const char* mode = std::getenv("TMX_EDDSA");
   c->quad = !(mode && std::string(mode) == "mono");
-  HIPCK(c, hipMalloc(&c->d_qtable, quad_table_bytes()));
+  // fixed-base table of B: signed windows of base_w bits (the one-thread-per-lane kernel keeps the 4-bit table it was written for).
+  // 8 bits = 32 additions per s*B from a 655 KB table that stays in every XCD's L2.
+  const char* bw = std::getenv("TMX_BASE_W");
+  c->base_w = !c->quad ? 4u : (bw && std::atoi(bw) == 4) ? 4u : (bw && std::atoi(bw) == 10) ? 10u : 8u;
+  HIPCK(c, hipMalloc(&c->d_table, base_table_bytes(c->base_w)));
+  int rc = launch_init_base(c->d_table, c->base_w, c->side2);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_init_base launch: ") + hipGetErrorString((hipError_t)rc));
+  HIPCK(c, hipMalloc(&c->d_qtable, quad_table_bytes(c->base_w)));
   HIPCK(c, hipMalloc(&c->d_pre, lanes * pre_bytes_per_lane()));
   HIPCK(c, hipMalloc(&c->d_mulout, lanes * mulout_bytes_per_lane()));
   {
@@ -608,7 +613,7 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     HIPCK(c, hipMalloc(&c->d_anchors, kc * anchor_bytes_per_key()));
     HIPCK(c, hipMalloc(&c->d_keytab, kc * keytab_bytes_per_key()));
   }
-  rc = launch_init_base_quad(c->d_table, c->d_qtable, c->side2);
+  rc = launch_init_base_quad(c->d_table, c->d_qtable, c->base_w, c->side2);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_init_base_quad launch: ") + hipGetErrorString((hipError_t)rc));
   HIPCK(c, hipStreamSynchronize(c->side2));
   return TMX_OK;

@@ -7,9 +7,9 @@
 
 namespace tmx {
 
-size_t base_table_bytes();
+size_t base_table_bytes(uint32_t w_bits);
 // each returns a hipError_t value (0 = success); all launches are asynchronous on `stream` (hipStream_t)
-int launch_init_base(void* d_table, void* stream);
+int launch_init_base(void* d_table, uint32_t w_bits, void* stream);
 int launch_eddsa(uint32_t n_lanes, const void* d_target, void* d_ed, uint32_t ed_stride, const void* d_table, void* stream);
 // quad-parallel EdDSA path.  Three launch groups so that api.cpp can run the key pipeline on a side stream:
 //   keys pipeline (dedup -> decode distinct keys -> optional per-key tables)  ||  phase 1 (decode R, SHA-512 mod l, s*B)
@@ -20,6 +20,7 @@ struct EdQuad {
   void* d_ed;
   uint32_t ed_stride;
   const void* d_qtable;
+  uint32_t base_w;   // window width of the fixed-base table of B (4, 8 or 10 bits)
   void *d_pre, *d_mulout;
   void* d_hash;
   uint32_t hash_mask;
@@ -27,13 +28,13 @@ struct EdQuad {
   uint32_t key_cap;  // keys the table buffers can hold
   uint32_t mode;     // 0 never build tables, 1 automatic (>= 8 lanes per key), 2 whenever they fit
 };
-size_t quad_table_bytes();
+size_t quad_table_bytes(uint32_t w_bits);
 size_t pre_bytes_per_lane();
 size_t mulout_bytes_per_lane();
 size_t key_bytes_per_key();
 size_t anchor_bytes_per_key();
 size_t keytab_bytes_per_key();
-int launch_init_base_quad(const void* d_table, void* d_qtable, void* stream);
+int launch_init_base_quad(const void* d_table, void* d_qtable, uint32_t w_bits, void* stream);
 int launch_ed_dedup(const EdQuad& Q, void* stream);
 int launch_ed_keys(const EdQuad& Q, void* stream);
 int launch_ed_key_tables(const EdQuad& Q, void* stream);
