@@ -24,8 +24,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MAD_PEAK_GOPS = 39321.6        # v_mad_i64_i32: 4 cycles / wave64 (tools/microbench) -> 1024 SIMDs * 64 / 4 * 2.4 GHz
-MADS_PER_LANE = 291_000        # 1925 fe-mul x 100 + 1792 fe-sq x 55 v_mad_i64_i32 per lane (direct h*A: 252 doublings + 64 additions)
-MADS_PER_LANE_TABLES = 137_000 # per-key fixed-base tables: 1090 fe-mul + 509 fe-sq per lane (s*B and h*A 64 additions each, decode R, finish)
+MADS_PER_LANE = 265_400        # 1669 fe-mul x 100 + 1792 fe-sq x 55 v_mad_i64_i32 per lane (direct h*A: 252 doublings + 64 additions; s*B: 32)
+MADS_PER_LANE_TABLES = 112_600 # per-key fixed-base tables: 846 fe-mul + 509 fe-sq per lane (s*B 32 additions, h*A 64 + 1 merge, decode R, finish)
+SIMDS, CLOCK_GHZ, CYCLES_PER_VALU = 1024, 2.4, 4   # 256 CUs x 4 SIMD16; every VALU instruction of a wave64 occupies its SIMD for 4 cycles (tools/microbench)
 MADS_PER_KEY = 1_060_000       # once per distinct key: decode + 252 doublings + 64 x (1 doubling + 6 additions + 8 conversions)
 
 
@@ -145,12 +146,22 @@ def main():
         k_e_no_tables = ctx0.kernel_ms_mean(10)["k_eddsa"]
         ctx0.close()
 
-        traffic, traffic_ser = None, None
-        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), only if they were taken on this configuration
+        traffic, traffic_ser, issue = None, None, None
+        try:  # per-batch PMC figures from the committed rocprofv3 passes (profiles/), only if they were taken on this configuration
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
             if pmc["config"] == {"n_max": n, "proofs_per_gpu": P}:
-                traffic = int((pmc["kernels"]["k_eddsa"]["fetch_kb"] + pmc["kernels"]["k_eddsa"]["write_kb"]) * 1024)
-                traffic_ser = int((pmc["kernels"]["k_serialize"]["fetch_kb"] + pmc["kernels"]["k_serialize"]["write_kb"]) * 1024)
+                pk = pmc["kernels"]
+                traffic = int((pk["k_eddsa"]["fetch_kb"] + pk["k_eddsa"]["write_kb"]) * 1024)
+                traffic_ser = int((pk["k_serialize"]["fetch_kb"] + pk["k_serialize"]["write_kb"]) * 1024)
+                if used_tables and "valu_insts" in pk["k_eddsa"]:
+                    # VALU issue: wave-level instructions x 4 cycles against SIMD-cycles available in the measured time
+                    def frac(insts, ms):
+                        return round(insts * CYCLES_PER_VALU / (SIMDS * ms * 1e-3 * CLOCK_GHZ * 1e9), 4)
+                    step_insts = sum(pk[g].get("valu_insts", 0) for g in pk)
+                    issue = {"unit": "wave-level VALU instructions per batch (SQ_INSTS_VALU)", "cycles_per_instruction": CYCLES_PER_VALU,
+                             "k_eddsa": {"insts": int(pk["k_eddsa"]["valu_insts"]), "frac_of_issue_slots": frac(pk["k_eddsa"]["valu_insts"], k_e)},
+                             "step": {"insts": int(step_insts), "frac_of_issue_slots": frac(step_insts, ms_per_step)},
+                             "note": "fraction of the 1024 SIMDs' issue cycles (2.4 GHz) that the step's VALU instructions occupy; per kernel in DESIGN.md"}
         except (OSError, KeyError, ValueError):
             pass
 
@@ -163,6 +174,7 @@ def main():
                     "valu": {"achieved": round(ed_mads / (k_e * 1e-3) / 1e9, 1), "peak": MAD_PEAK_GOPS, "unit": "Gmad/s",
                              "frac": round(ed_mads / (k_e * 1e-3) / 1e9 / MAD_PEAK_GOPS, 4), "algorithmic_mads": ed_mads,
                              "note": "multiply-adds the chosen algorithm needs, not the instructions issued"},
+                    "valu_issue": issue,
                     "dedup": {"lanes": lanes, "distinct_keys": n_unique, "per_key_tables": used_tables,
                               "without_key_tables": {"ms_per_step": round(ms_no_tables, 4), "k_eddsa_ms": round(k_e_no_tables, 4),
                                                      "valu_frac": round(lanes * MADS_PER_LANE / (k_e_no_tables * 1e-3) / 1e9 / MAD_PEAK_GOPS, 4)}},
