@@ -325,7 +325,18 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   if (st0) return st0;
   HIPCK(c, hipEventRecord(c->ev_join, c->side));
   HIPCK(c, hipEventRecord(ev[1], s));
-  if (c->ser_split) {
+  // (a small batch is pure latency: its tail stays on s, two cross-stream hops cost more than the overlap gains)
+  const bool tail_aside = c->ser_split && (uint64_t)n_proofs * n >= 4096;
+  if (c->ser_split && !tail_aside) {
+    HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
+    HIPCK(c, hipEventRecord(evs[2], s));
+    rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, s);
+    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
+    HIPCK(c, hipEventRecord(evs[3], s));
+    if ((st0 = serialize(prog.mask_final | prog.mask_tail, s))) return st0;
+    HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    HIPCK(c, hipStreamWaitEvent(s, c->ev_join3, 0));
+  } else if (c->ser_split) {
     // tail: the per-lane derived section (a quarter of the row) only needs k_ed_fin + k_proof, so it is written on s while the
     // verdict and the few sections that carry it go through the high-priority side stream.  (ev[2] = ev[1] here: every packet
     // between k_ed_fin and the serializer is latency on the critical path.)
