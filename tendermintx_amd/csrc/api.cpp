@@ -222,7 +222,7 @@ struct tmx_ctx {
   std::string err;
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;  // k_proof runs here, concurrently with the EdDSA kernels of the caller's stream
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_join = nullptr;
   hipEvent_t ev_side[EV_RING_DECL][4] = {};
   hipEvent_t ev_tail = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_hash_clean = nullptr, ev_keys = nullptr, ev_mul = nullptr;
   bool ev_mul_recorded = false;
@@ -276,7 +276,7 @@ static ProofParams proof_params(const tmx_ctx* c, int32_t kind) {
 }
 
 // Launch sequence of one batch.  Main stream s:  [ev0] EdDSA kernels [ev1] (joins) [ev2] k_serialize of the EdDSA-dependent section [ev3]
-//                               side stream:      (after ev_fork) [side0] k_proof [side1] -> ev_join, waited on before the tail;
+//                               side stream:      (after ev0) [side0] k_proof [side1] -> ev_join, waited on before the tail;
 //                               side2 (tail):     [side2] k_verdict [side3] k_serialize of the sections that carry the verdict -> ev_tail.
 // k_proof does not depend on the EdDSA results, so it overlaps with them; `ed_producer` enqueues whatever fills the ED part of
 // c->d_tl on s (the EdDSA kernels, or a strided copy of caller-provided lane records).
@@ -302,9 +302,11 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     if (r) return fail(c, TMX_ERR_HIP, std::string("k_serialize launch: ") + hipGetErrorString((hipError_t)r));
     return TMX_OK;
   };
-  HIPCK(c, hipEventRecord(c->ev_fork, s));
-  HIPCK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-  HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_fork, 0));
+  // (every record / wait is a packet the command processor handles in order: the caller's stream carries the critical path, so
+  // events are shared where they mark the same point and joins are chained through the side streams)
+  HIPCK(c, hipEventRecord(ev[0], s));
+  HIPCK(c, hipStreamWaitEvent(c->side, ev[0], 0));
+  HIPCK(c, hipStreamWaitEvent(c->side3, ev[0], 0));
   // side3: the sections that are a pure expansion of the input records (42 % of a skip row) -- HBM is idle while EdDSA runs
   int32_t st0 = c->ser_split ? serialize(prog.mask_inputs, c->side3) : TMX_OK;
   if (st0) return st0;
@@ -316,13 +318,13 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_proof launch: ") + hipGetErrorString((hipError_t)rc));
   HIPCK(c, hipEventRecord(evs[1], c->side));
 
-  HIPCK(c, hipEventRecord(ev[0], s));
   c->ev_mul_recorded = false;
   int32_t st = ed_producer(s);
   if (st) return st;
   if (c->ev_mul_recorded) HIPCK(c, hipStreamWaitEvent(c->side, c->ev_mul, 0));
   st0 = c->ser_split ? serialize(prog.mask_proof, c->side) : TMX_OK;
   if (st0) return st0;
+  HIPCK(c, hipStreamWaitEvent(c->side, c->ev_join3, 0));  // ev_join = both low-priority streams done
   HIPCK(c, hipEventRecord(c->ev_join, c->side));
   HIPCK(c, hipEventRecord(ev[1], s));
   // (a small batch is pure latency: its tail stays on s, two cross-stream hops cost more than the overlap gains)
@@ -335,7 +337,6 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     HIPCK(c, hipEventRecord(evs[3], s));
     if ((st0 = serialize(prog.mask_final | prog.mask_tail, s))) return st0;
     HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
-    HIPCK(c, hipStreamWaitEvent(s, c->ev_join3, 0));
   } else if (c->ser_split) {
     // tail: the per-lane derived section (a quarter of the row) only needs k_ed_fin + k_proof, so it is written on s while the
     // verdict and the few sections that carry it go through the high-priority side stream.  (ev[2] = ev[1] here: every packet
@@ -347,12 +348,11 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
     HIPCK(c, hipEventRecord(evs[3], c->side2));
     if ((st0 = serialize(prog.mask_tail, c->side2))) return st0;
+    HIPCK(c, hipStreamWaitEvent(c->side2, c->ev_join, 0));  // ev_tail = every side stream done
     HIPCK(c, hipEventRecord(c->ev_tail, c->side2));
     HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
     if ((st0 = serialize(prog.mask_final, s))) return st0;
     HIPCK(c, hipStreamWaitEvent(s, c->ev_tail, 0));
-    HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));   // the early serializer launches on the low-priority streams
-    HIPCK(c, hipStreamWaitEvent(s, c->ev_join3, 0));
   } else {
     HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
     HIPCK(c, hipEventRecord(evs[2], s));
@@ -524,13 +524,12 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   for (auto& set : c->ev_side)
     for (auto& e : set)
       if (e) (void)hipEventDestroy(e);
-  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
   if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
   if (c->ev_keys) (void)hipEventDestroy(c->ev_keys);
-  if (c->ev_mul) (void)hipEventDestroy(c->ev_mul);
   if (c->ev_hash_clean) (void)hipEventDestroy(c->ev_hash_clean);
+  if (c->ev_mul) (void)hipEventDestroy(c->ev_mul);
   if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
   if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
   if (c->have_streams) release_streams(c->cfg.device);
@@ -559,9 +558,8 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   HIPCK(c, hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
-  HIPCK(c, hipEventCreateWithFlags(&c->ev_mul, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_hash_clean, hipEventDisableTiming));
-  HIPCK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_mul, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   for (auto& set : c->ev_side)
     for (auto& ev : set) HIPCK(c, hipEventCreate(&ev));
@@ -615,8 +613,8 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     HIPCK(c, hipMalloc(&c->d_hash, (size_t)cap * 4));
     HIPCK(c, hipMalloc(&c->d_cnt, 32));
     HIPCK(c, hipMemsetAsync(c->d_hash, 0xff, (size_t)cap * 4, c->side2));
-    HIPCK(c, hipMemsetAsync(c->d_cnt, 0, 32, c->side2));
     HIPCK(c, hipEventRecord(c->ev_hash_clean, c->side2));
+    HIPCK(c, hipMemsetAsync(c->d_cnt, 0, 32, c->side2));
     HIPCK(c, hipMalloc(&c->d_owner_of, lanes * 4));
     HIPCK(c, hipMalloc(&c->d_uid_of_owner, lanes * 4));
     HIPCK(c, hipMalloc(&c->d_owners, lanes * 4));
