@@ -208,6 +208,22 @@ def main():
             lat.append(1e3 * (time.perf_counter() - a))
         result["latency_single_proof_ms"] = round(sorted(lat)[len(lat) // 2], 4)
 
+        # SURVEY 8(d)'s host-to-host variant (never `value`): pageable host buffers in, witness rows + reports back in host memory,
+        # through the host-buffer entry point tmx_witness_batch (H2D + the same step + D2H of 1.2 GB)
+        if world == 1:
+            pinned = torch.empty(P * stride, dtype=torch.int64, pin_memory=True)
+            host_out = pinned.numpy().view(np.uint64)
+            hh = []
+            for _ in range(3):
+                a = time.perf_counter()
+                ctx.witness_batch(KIND_SKIP, wl.proofs, wl.targets, wl.trusteds, out=host_out)
+                hh.append(1e3 * (time.perf_counter() - a))
+            hb = in_bytes + out_bytes + P * 64
+            result["host_to_host"] = {"ms_per_step": round(min(hh), 3), "ms_per_proof": round(min(hh) / P, 5), "bytes_over_pcie": hb,
+                                      "effective_gbs": round(hb / (min(hh) * 1e-3) / 1e9, 1),
+                                      "note": "pageable inputs, page-locked output rows; PCIe-bound, reported for completeness"}
+            del pinned, host_out
+
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle", "py"))
             import oracle_c as oc  # checker + reported CPU baseline only

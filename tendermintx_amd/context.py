@@ -58,15 +58,23 @@ class Context:
         return int(self._L.tmx_hint_elem_count(kind, self.n_max))
 
     # ---- host-buffer path
-    def witness_batch(self, kind, proofs, targets, trusteds=None, want_elems=True):
+    def witness_batch(self, kind, proofs, targets, trusteds=None, want_elems=True, out=None):
         """proofs: bytes (n x 2336); targets: bytes (n x n_max x 256); trusteds: bytes (n x n_max x 48) for skip.
+        out: optional preallocated np.uint64 array of n * elem_stride elements (e.g. a view of page-locked memory: the 1.1 GB of a
+        256-proof batch come back at PCIe speed instead of through the runtime's pageable staging).
         Returns (np.uint64 [n, elem_count] or None, [report dict])."""
         n = len(proofs) // 2336
         assert len(proofs) == n * 2336 and len(targets) == n * self.n_max * 256
         if kind == KIND_SKIP:
             assert trusteds is not None and len(trusteds) == n * self.n_max * 48
         count, stride = self.elem_count(kind), self.elem_stride(kind)
-        out = np.zeros(n * stride, dtype=np.uint64) if want_elems else None
+        if want_elems and out is None:
+            out = np.zeros(n * stride, dtype=np.uint64)
+        elif want_elems:
+            assert out.dtype == np.uint64 and out.size >= n * stride and out.flags["C_CONTIGUOUS"]
+            out = out.reshape(-1)[:n * stride]
+        else:
+            out = None
         reps = (Report * n)()
         st = self._L.tmx_witness_batch(self._h, kind, n, bytes(proofs), bytes(targets), bytes(trusteds) if trusteds else None,
                                        out.ctypes.data if want_elems else None, out.size if want_elems else 0, reps)
