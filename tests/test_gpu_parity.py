@@ -389,6 +389,25 @@ def test_validator_sharded_single_proof(tmx, oracle):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("knobs", [
+    {"TMX_BASE_W": "4"}, {"TMX_BASE_W": "10"}, {"TMX_MUL_SPLIT": "1"}, {"TMX_DEDUP": "0"}, {"TMX_DEDUP": "2"},
+    {"TMX_SER_SPLIT": "0"}, {"TMX_SER_SPAN": "128"}, {"TMX_SER_SPAN": "512"}, {"TMX_EDDSA": "mono"}], ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+def test_schedule_knobs_give_the_same_bits(tmx, oracle, monkeypatch, knobs):
+    """Every tuning knob changes a schedule (window widths, table use, launch splitting, the first-generation kernel), never a value:
+    a repeated-validator-set batch (tables, dummy lanes, a failing signature) is bit-exact vs the oracle under each of them."""
+    from tendermintx_amd.synth import Workload
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)      # read at context creation / launch time
+    n, P = 16, 20
+    wl = Workload(0, n, P, 13, chain_id=b"celestia", seed=4242, signed_permille=850)
+    targets = bytearray(wl.targets)
+    lane = next(l for l in range(n) if targets[l * 256 + 223] & 1)   # a lane of proof 0 that did sign
+    targets[lane * 256 + 40] ^= 0x10  # corrupt its signature (R): the equation must fail on exactly that lane
+    with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+        _, reps = _check_vs_oracle(tmx, oracle, 0, n, wl.proofs, bytes(targets), wl.trusteds, b"celestia", ctx=ctx)
+    assert reps[0]["first_bad_sig"] == lane and not reps[0]["all_ok"] and all(r["first_bad_sig"] == -1 for r in reps[1:])
+
+
 def test_key_dedup_paths(tmx, oracle):
     if os.environ.get("TMX_EDDSA") == "mono":
         pytest.skip("the first-generation kernel has no key deduplication")
