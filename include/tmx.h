@@ -216,6 +216,19 @@ void tmx_unpack_skip_input(const uint8_t in[48], uint64_t* trusted_block, uint8_
 void tmx_pack_step_input(uint64_t prev_block, const uint8_t prev_header_hash[32], uint8_t out[40]);
 void tmx_unpack_step_input(const uint8_t in[40], uint64_t* prev_block, uint8_t prev_header_hash[32]);
 
+/* ---- Goldilocks NTT / coset low-degree extension (the step after the witness fill of a plonky2-style prover).
+ * Own statement of the published definitions (plonky2_field is not in the reference tree; parity pinned against oracle/c/tmxo_ntt.c):
+ * p = 2^64 - 2^32 + 1, g = 7, omega_N = g^((p-1)/N); forward X[j] = sum_i x[i] omega_N^(ij), inverse with N^-1, natural order in and
+ * out, any u64 input taken mod p, canonical outputs.  n_cols columns of 2^log_n elements, column c at element c << log_n; device
+ * pointers, asynchronous on hip_stream (used exactly as passed).  In place (d_out == d_in) is allowed.
+ * tmx_lde_goldilocks_device: evaluations on <omega_N> -> evaluations on the coset g <omega_M>, M = N << log_blowup (interpolate,
+ * scale coefficient i by g^i, zero-pad, evaluate); d_out holds n_cols << (log_n + log_blowup) elements. */
+#define TMX_NTT_MAX_LOG 22
+int32_t tmx_ntt_goldilocks_device(tmx_ctx* ctx, uint32_t log_n, uint32_t n_cols, const uint64_t* d_in, uint64_t* d_out,
+                                  int32_t inverse, void* hip_stream);
+int32_t tmx_lde_goldilocks_device(tmx_ctx* ctx, uint32_t log_n, uint32_t log_blowup, uint32_t n_cols, const uint64_t* d_in,
+                                  uint64_t* d_out, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

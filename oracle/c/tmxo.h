@@ -80,6 +80,12 @@ int tmxo_witness_batch(int kind, uint32_t n_proofs, const uint8_t* proof_recs, c
                        const uint8_t* trusted_recs, uint32_t n, const uint8_t* chain_id, uint32_t chain_id_len,
                        uint64_t skip_max, uint64_t* out, tmxo_report* reps, uint32_t n_threads);
 
+/* ---- Goldilocks NTT / coset LDE (tmxo_ntt.c; parity unpinned against plonky2, see the file header) */
+uint64_t tmxo_gl_pow(uint64_t b, uint64_t e);
+uint64_t tmxo_gl_root(uint32_t log_n);
+void tmxo_ntt(uint64_t* x, uint32_t log_n, int inverse);
+void tmxo_lde(const uint64_t* in, uint64_t* out, uint32_t log_n, uint32_t log_blowup);
+
 #ifdef __cplusplus
 }
 #endif

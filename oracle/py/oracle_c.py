@@ -161,3 +161,45 @@ def witness_batch(kind, n_proofs, proof_recs, target_recs, trusted_recs, n, chai
     if rc:
         raise RuntimeError(f"tmxo_witness_batch rc={rc}")
     return (out.reshape(n_proofs, ec) if want_out else None), [_rep(r) for r in reps]
+
+
+# ---- Goldilocks NTT / coset LDE (oracle/c/tmxo_ntt.c)
+GL_P = 2**64 - 2**32 + 1
+
+
+def gl_root(log_n):
+    L = lib()
+    L.tmxo_gl_root.restype = C.c_uint64
+    L.tmxo_gl_root.argtypes = [C.c_uint32]
+    return int(L.tmxo_gl_root(log_n))
+
+
+def ntt(values, inverse=False):
+    """values: 1-D np.uint64 of power-of-two length (one column) or 2-D [cols, n]; returns a new array, natural order."""
+    a = np.ascontiguousarray(values, dtype=np.uint64).copy()
+    cols = a.reshape(1, -1) if a.ndim == 1 else a
+    n = cols.shape[1]
+    log_n = n.bit_length() - 1
+    assert 1 << log_n == n
+    L = lib()
+    L.tmxo_ntt.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+    L.tmxo_ntt.restype = None
+    for c in cols:
+        L.tmxo_ntt(c.ctypes.data, log_n, 1 if inverse else 0)
+    return a
+
+
+def lde(values, log_blowup):
+    a = np.ascontiguousarray(values, dtype=np.uint64)
+    cols = a.reshape(1, -1) if a.ndim == 1 else a
+    n = cols.shape[1]
+    log_n = n.bit_length() - 1
+    assert 1 << log_n == n
+    out = np.zeros((cols.shape[0], n << log_blowup), dtype=np.uint64)
+    L = lib()
+    L.tmxo_lde.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    L.tmxo_lde.restype = None
+    for i, c in enumerate(cols):
+        c = np.ascontiguousarray(c)
+        L.tmxo_lde(c.ctypes.data, out[i].ctypes.data, log_n, log_blowup)
+    return out[0] if a.ndim == 1 else out

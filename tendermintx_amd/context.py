@@ -108,6 +108,13 @@ class Context:
         check(self._L.tmx_witness_batch_device(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports,
                                                self._stream(stream)), self._h)
 
+    # ---- Goldilocks NTT / coset LDE (device pointers; columns of 2**log_n u64, column c at element c << log_n)
+    def ntt_device(self, log_n, n_cols, d_in, d_out, inverse=False, stream=None):
+        check(self._L.tmx_ntt_goldilocks_device(self._h, log_n, n_cols, d_in, d_out, 1 if inverse else 0, self._stream(stream)), self._h)
+
+    def lde_device(self, log_n, log_blowup, n_cols, d_in, d_out, stream=None):
+        check(self._L.tmx_lde_goldilocks_device(self._h, log_n, log_blowup, n_cols, d_in, d_out, self._stream(stream)), self._h)
+
     def eddsa_lanes_device(self, n_lanes, d_lanes, d_ed_out, stream=None):
         check(self._L.tmx_eddsa_lanes_device(self._h, n_lanes, d_lanes, d_ed_out, self._stream(stream)), self._h)
 

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "ntt.h"
 #include "tmx.h"
 
 using namespace tmx;
@@ -254,6 +255,10 @@ struct tmx_ctx {
   // staging for the host-buffer entry points
   void *d_in_proofs = nullptr, *d_in_targets = nullptr, *d_in_trusteds = nullptr, *d_out = nullptr;
   uint64_t d_out_elems = 0;
+  // Goldilocks NTT: twiddle tables per transform size (built on first use), scratch for the four-step split / LDE
+  void* d_ntt_w[TMX_NTT_MAX_LOG + 1] = {};
+  void* d_ntt_tmp = nullptr;
+  size_t ntt_tmp_bytes = 0;
 };
 
 static int32_t fail(tmx_ctx* c, int32_t st, const std::string& msg) {
@@ -518,6 +523,9 @@ void tmx_ctx_destroy(tmx_ctx* c) {
                   c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  for (void* w : c->d_ntt_w)
+    if (w) (void)hipFree(w);
+  if (c->d_ntt_tmp) (void)hipFree(c->d_ntt_tmp);
   for (auto& set : c->ev)
     for (auto& e : set)
       if (e) (void)hipEventDestroy(e);
@@ -832,5 +840,116 @@ void tmx_unpack_skip_input(const uint8_t in[48], uint64_t* trusted_block, uint8_
 }
 void tmx_pack_step_input(uint64_t prev_block, const uint8_t h[32], uint8_t out[40]) { be64(prev_block, out); std::memcpy(out + 8, h, 32); }
 void tmx_unpack_step_input(const uint8_t in[40], uint64_t* prev_block, uint8_t h[32]) { *prev_block = rd_be64(in); std::memcpy(h, in + 8, 32); }
+
+
+// ---- Goldilocks NTT / coset LDE ------------------------------------------------------------------------------------------------
+static int32_t ntt_table(tmx_ctx* c, uint32_t log_n, hipStream_t s, void** w) {
+  if (!c->d_ntt_w[log_n]) {
+    const size_t half = log_n ? ((size_t)1 << (log_n - 1)) : 1;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipMalloc(&c->d_ntt_w[log_n], half * 8));
+    int rc = launch_ntt_table(c->d_ntt_w[log_n], log_n, s);
+    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_ntt_table launch: ") + hipGetErrorString((hipError_t)rc));
+    HIPCK(c, hipStreamSynchronize(s));  // once per size: later calls may come on another stream
+  }
+  *w = c->d_ntt_w[log_n];
+  return TMX_OK;
+}
+static int32_t ntt_scratch(tmx_ctx* c, size_t bytes, hipStream_t s) {
+  if (c->ntt_tmp_bytes >= bytes) return TMX_OK;
+  HIPCK(c, hipSetDevice(c->cfg.device));
+  if (c->d_ntt_tmp) {
+    HIPCK(c, hipStreamSynchronize(s));  // earlier transforms on this stream may still read it
+    HIPCK(c, hipFree(c->d_ntt_tmp));
+    c->d_ntt_tmp = nullptr; c->ntt_tmp_bytes = 0;
+  }
+  HIPCK(c, hipMalloc(&c->d_ntt_tmp, bytes));
+  c->ntt_tmp_bytes = bytes;
+  return TMX_OK;
+}
+static uint64_t gl_pow_host(uint64_t b, uint64_t e) {
+  const unsigned __int128 p = 0xffffffff00000001ull;
+  unsigned __int128 r = 1, x = b % p;
+  while (e) {
+    if (e & 1) r = r * x % p;
+    x = x * x % p;
+    e >>= 1;
+  }
+  return (uint64_t)r;
+}
+// columns of 2^log_n elements, column c at element c * col_stride; `tmp` (n_cols << log_n elements) only for log_n > 11
+static int32_t ntt_run(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const void* d_in, uint64_t in_stride, void* d_out, uint64_t out_stride,
+                       void* tmp, bool inverse, hipStream_t s) {
+  void* w = nullptr;
+  int32_t st = ntt_table(c, log_n, s, &w);
+  if (st) return st;
+  const uint64_t n_inv = inverse ? gl_pow_host((uint64_t)1 << log_n, 0xffffffff00000001ull - 2) : 1;
+  NttPass P;
+  std::memset(&P, 0, sizeof P);
+  P.log_n = log_n; P.inverse = inverse ? 1 : 0;
+  int rc;
+  if (log_n <= 11) {  // one pass: whole columns in LDS, T columns per tile
+    P.log_l = log_n; P.log_t = 12 - log_n;
+    if (((uint64_t)1 << P.log_t) > n_cols) { P.log_t = 0; while (((uint64_t)2 << P.log_t) <= n_cols) P.log_t++; }
+    const uint32_t T = 1u << P.log_t;
+    // the "columns" of the kernel are groups of T real columns: sub-transform t of a group = column, stride = column stride
+    P.tiles_per_col = (n_cols + T - 1) / T; P.n_sub = n_cols;
+    P.col_stride_in = 0; P.t_stride_in = in_stride; P.j_stride_in = 1;
+    P.col_stride_out = 0; P.t_stride_out = out_stride; P.j_stride_out = 1;
+    P.scale = n_inv;
+    rc = launch_ntt_pass(P, 1, d_in, d_out, w, s);
+    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_ntt_tile launch: ") + hipGetErrorString((hipError_t)rc));
+    return TMX_OK;
+  }
+  const uint32_t a = (log_n + 1) / 2, b = log_n - a;  // N = N1 N2, N1 = 2^a (pass A, strided), N2 = 2^b (pass B, contiguous)
+  const uint64_t N = (uint64_t)1 << log_n, N1 = (uint64_t)1 << a, N2 = (uint64_t)1 << b;
+  P.log_l = a; P.log_t = 12 - a; P.n_sub = N2; P.tiles_per_col = (uint32_t)(N2 >> P.log_t);
+  P.col_stride_in = in_stride; P.t_stride_in = 1; P.j_stride_in = N2;
+  P.col_stride_out = N; P.t_stride_out = 1; P.j_stride_out = N2;
+  P.post_twiddle = 1; P.scale = 1;
+  rc = launch_ntt_pass(P, n_cols, d_in, tmp, w, s);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_ntt_tile launch: ") + hipGetErrorString((hipError_t)rc));
+  P.log_l = b; P.log_t = 12 - b; P.n_sub = N1; P.tiles_per_col = (uint32_t)(N1 >> P.log_t);
+  P.col_stride_in = N; P.t_stride_in = N2; P.j_stride_in = 1;
+  P.col_stride_out = out_stride; P.t_stride_out = 1; P.j_stride_out = N1;
+  P.post_twiddle = 0; P.scale = n_inv;
+  rc = launch_ntt_pass(P, n_cols, tmp, d_out, w, s);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_ntt_tile launch: ") + hipGetErrorString((hipError_t)rc));
+  return TMX_OK;
+}
+
+int32_t tmx_ntt_goldilocks_device(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const uint64_t* d_in, uint64_t* d_out, int32_t inverse,
+                                  void* hip_stream) {
+  if (!c || !d_in || !d_out) return TMX_ERR_BAD_ARG;
+  if (log_n > TMX_NTT_MAX_LOG) return fail(c, TMX_ERR_CAPACITY, "log_n exceeds TMX_NTT_MAX_LOG");
+  if (n_cols == 0) return TMX_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  const uint64_t N = (uint64_t)1 << log_n;
+  if (log_n > 11) {
+    int32_t st = ntt_scratch(c, (size_t)n_cols * N * 8, s);
+    if (st) return st;
+  }
+  return ntt_run(c, log_n, n_cols, d_in, N, d_out, N, c->d_ntt_tmp, inverse != 0, s);
+}
+
+int32_t tmx_lde_goldilocks_device(tmx_ctx* c, uint32_t log_n, uint32_t log_blowup, uint32_t n_cols, const uint64_t* d_in, uint64_t* d_out,
+                                  void* hip_stream) {
+  if (!c || !d_in || !d_out) return TMX_ERR_BAD_ARG;
+  const uint32_t log_m = log_n + log_blowup;
+  if (log_m > TMX_NTT_MAX_LOG) return fail(c, TMX_ERR_CAPACITY, "log_n + log_blowup exceeds TMX_NTT_MAX_LOG");
+  if (n_cols == 0) return TMX_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  const uint64_t N = (uint64_t)1 << log_n, M = (uint64_t)1 << log_m;
+  // scratch: [coefficients, n_cols x M] [four-step intermediate, n_cols x M]
+  int32_t st = ntt_scratch(c, (size_t)n_cols * M * 8 * 2, s);
+  if (st) return st;
+  uint64_t* coef = reinterpret_cast<uint64_t*>(c->d_ntt_tmp);
+  uint64_t* tmp = coef + (size_t)n_cols * M;
+  st = ntt_run(c, log_n, n_cols, d_in, N, coef, M, tmp, true, s);  // coefficients into the first N slots of every M-slot column
+  if (st) return st;
+  int rc = launch_lde_expand(coef, log_n, log_m, n_cols, s);           // c_i g^i, zero padding
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_lde_expand launch: ") + hipGetErrorString((hipError_t)rc));
+  return ntt_run(c, log_m, n_cols, coef, M, d_out, M, tmp, false, s);
+}
 
 }  // extern "C"

@@ -1,0 +1,24 @@
+// Launch wrappers of ntt.hip (host side: plain C++, no HIP headers needed)
+#pragma once
+#include <cstdint>
+
+namespace tmx {
+
+struct NttPass {
+  uint32_t log_n;        // size of the whole transform (selects the twiddle table omega_N)
+  uint32_t log_l;        // length of the sub-transforms of this pass
+  uint32_t log_t;        // sub-transforms per tile (tile = 2^(log_l + log_t) <= 4096 elements)
+  uint32_t tiles_per_col;
+  uint64_t n_sub;        // sub-transforms per column
+  uint64_t col_stride_in, t_stride_in, j_stride_in;     // element strides: column, sub-transform, index inside it
+  uint64_t col_stride_out, t_stride_out, j_stride_out;
+  uint32_t inverse;
+  uint32_t post_twiddle;  // multiply output k of sub-transform t by omega_N^(t k) (four-step pass A)
+  uint64_t scale;         // multiply every output by this (N^-1 on the last pass of an inverse transform), 1 = none
+};
+
+int launch_ntt_table(void* d_w, uint32_t log_n, void* stream);
+int launch_ntt_pass(const NttPass& P, uint32_t n_cols, const void* d_in, void* d_out, const void* d_w, void* stream);
+int launch_lde_expand(void* d_buf, uint32_t log_n, uint32_t log_m, uint32_t n_cols, void* stream);
+
+}  // namespace tmx
