@@ -49,11 +49,13 @@ constexpr uint32_t HDR_SIZE = 1136, PR_STRIDE = 2336, PR_OFF_BLOCK_A = 0, PR_OFF
 // look-up tables with one u32 per element (lut_field below); every section reads ONE source buffer
 enum : uint32_t { SRC_TARGET = 0, SRC_TRUSTED = 1, SRC_TL = 2, SRC_LR = 3, SRC_PF = 4, SRC_COUNT = 5 };
 // One entry describes a bit-field of a 4-byte-aligned dword of the source record (every multi-byte field of the records is 4-aligned):
-//   width code [31:30] (0: 1 bit, 1: 8 bits, 2: 16 bits, 3: the whole dword) | first bit [29:25] | aligned byte offset [24:0]
-// so the kernel is one aligned dword load + one bit-field extract per element, with no branches on the field type.
-enum : uint32_t { W_BIT = 0, W_U8 = 1, W_U16 = 2, W_U32 = 3 };
-constexpr uint32_t lut_field(uint32_t width_code, uint32_t byte_off, uint32_t bit_in_byte) {
-  return (width_code << 30) | ((8 * (byte_off & 3u) + bit_in_byte) << 25) | (byte_off & ~3u);
+//   width [31:27] (1, 8, 16; 0 = the whole dword) | first bit [26:22] | aligned byte offset [21:0]
+// so the kernel is one aligned dword load + one v_bfe_u32 per element (its offset / width operands only look at their low five bits,
+// so both come from the entry by a plain shift), with no branch on the field type.
+enum : uint32_t { W_BIT = 1, W_U8 = 8, W_U16 = 16, W_U32 = 0 };
+constexpr uint32_t LUT_OFF_MASK = 0x3fffffu;
+constexpr uint32_t lut_field(uint32_t width, uint32_t byte_off, uint32_t bit_in_byte) {
+  return (width << 27) | ((8 * (byte_off & 3u) + bit_in_byte) << 22) | (byte_off & ~3u);
 }
 
 enum : uint32_t { SEC_LUT = 0, SEC_LINEAR_T = 1, SEC_LINEAR_R = 2 };
