@@ -238,7 +238,7 @@ struct tmx_ctx {
   void* d_wave_sec[2] = {nullptr, nullptr};
   void* d_seams[2] = {nullptr, nullptr};
   void* d_table = nullptr;
-  uint32_t base_w = 8;
+  uint32_t base_w = 8, key_w = 6;
   void *d_qtable = nullptr, *d_pre = nullptr, *d_mulout = nullptr;
   void *d_hash = nullptr, *d_cnt = nullptr, *d_owner_of = nullptr, *d_uid_of_owner = nullptr, *d_owners = nullptr, *d_keyrec = nullptr,
        *d_anchors = nullptr, *d_keytab = nullptr;
@@ -386,7 +386,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   Q.n_lanes = n_lanes; Q.d_target = d_lanes; Q.d_ed = d_ed; Q.ed_stride = ed_stride; Q.d_qtable = c->d_qtable; Q.base_w = c->base_w; Q.d_pre = c->d_pre;
   Q.d_mulout = c->d_mulout; Q.d_hash = c->d_hash; Q.hash_mask = c->hash_mask; Q.d_owner_of = c->d_owner_of;
   Q.d_uid_of_owner = c->d_uid_of_owner; Q.d_owners = c->d_owners; Q.d_keyrec = c->d_keyrec; Q.d_anchors = c->d_anchors; Q.d_keytab = c->d_keytab;
-  Q.key_cap = c->key_cap; Q.mode = c->dedup_mode;
+  Q.key_cap = c->key_cap; Q.key_w = c->key_w; Q.mode = c->dedup_mode;
   c->last_lanes = n_lanes;
   Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * c->parity;
   Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1);
@@ -627,8 +627,12 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     HIPCK(c, hipMalloc(&c->d_uid_of_owner, lanes * 4));
     HIPCK(c, hipMalloc(&c->d_owners, lanes * 4));
     HIPCK(c, hipMalloc(&c->d_keyrec, lanes * key_bytes_per_key()));
-    HIPCK(c, hipMalloc(&c->d_anchors, kc * anchor_bytes_per_key()));
-    HIPCK(c, hipMalloc(&c->d_keytab, kc * keytab_bytes_per_key()));
+    {
+      const char* kw = std::getenv("TMX_KEY_W");  // window width of the per-key tables
+      c->key_w = (kw && std::atoi(kw) == 4) ? 4u : 6u;
+    }
+    HIPCK(c, hipMalloc(&c->d_anchors, kc * anchor_bytes_per_key(c->key_w)));
+    HIPCK(c, hipMalloc(&c->d_keytab, kc * keytab_bytes_per_key(c->key_w)));
   }
   rc = launch_init_base_quad(c->d_table, c->d_qtable, c->base_w, c->side2);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_init_base_quad launch: ") + hipGetErrorString((hipError_t)rc));

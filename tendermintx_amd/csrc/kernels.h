@@ -25,6 +25,7 @@ struct EdQuad {
   void* d_hash;
   uint32_t hash_mask;
   void *d_cnt, *d_cnt_next, *d_owner_of, *d_uid_of_owner, *d_owners, *d_keyrec, *d_anchors, *d_keytab;
+  uint32_t key_w;    // window width of the per-key tables (4 or 6 bits)
   uint32_t key_cap;  // keys the table buffers can hold
   uint32_t mode;     // 0 never build tables, 1 automatic (>= 8 lanes per key), 2 whenever they fit
 };
@@ -32,8 +33,8 @@ size_t quad_table_bytes(uint32_t w_bits);
 size_t pre_bytes_per_lane();
 size_t mulout_bytes_per_lane();
 size_t key_bytes_per_key();
-size_t anchor_bytes_per_key();
-size_t keytab_bytes_per_key();
+size_t anchor_bytes_per_key(uint32_t key_w);
+size_t keytab_bytes_per_key(uint32_t key_w);
 int launch_init_base_quad(const void* d_table, void* d_qtable, uint32_t w_bits, void* stream);
 int launch_ed_dedup(const EdQuad& Q, void* stream);
 int launch_ed_keys(const EdQuad& Q, void* stream);
