@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MAD_PEAK_GOPS = 39321.6        # v_mad_i64_i32: 4 cycles / wave64 (tools/microbench) -> 1024 SIMDs * 64 / 4 * 2.4 GHz
 MADS_PER_LANE = 250_300        # 1658 fe-mul x 100 + 1538 fe-sq x 55 v_mad_i64_i32 per lane (direct h*A: 252 doublings + 64 additions; s*B: 32; no R decode)
-MADS_PER_LANE_TABLES = 80_700  # per-key tables: 667 fe-mul + 255 fe-sq per lane (s*B 32 additions, h*A 43 + 1 merge, finish with one inversion)
+MADS_PER_LANE_TABLES = 75_900  # per-key tables: 619 fe-mul + 255 fe-sq per lane (s*B 26 additions, h*A 43 + 1 merge, finish with one inversion)
 SIMDS, CLOCK_GHZ, CYCLES_PER_VALU = 1024, 2.4, 4   # 256 CUs x 4 SIMD16; every VALU instruction of a wave64 occupies its SIMD for 4 cycles (tools/microbench)
 MADS_PER_KEY = 2_560_000       # once per distinct key: decode + 252 doublings + 43 windows x 32 cached multiples (4 quads x ~14 group operations)
 
