@@ -213,6 +213,36 @@ def test_synthetic_batches(tmx, oracle, kind, n, nb, permille):
     assert all(r["all_ok"] for r in reps)
 
 
+@pytest.mark.parametrize("seed", range(32))
+def test_random_shapes_and_bit_flips(tmx, oracle, seed):
+    """Fuzz: random VALIDATOR_SET_SIZE_MAX (incl. odd sizes), batch size, real set size, signer fraction, rounds, kind, and a few
+    random single-bit flips anywhere in the proof / validator / trusted records of every other proof.  Elements and reports must
+    equal the oracle's bit for bit whatever the verdict is."""
+    from tendermintx_amd.synth import Workload
+    rng = np.random.default_rng(20260928 + seed)
+    kind = int(rng.integers(0, 2))
+    n = int(rng.choice([1, 2, 3, 5, 8, 13, 21, 32, 47, 64, 100]))
+    P = int(rng.integers(1, 40))
+    nb = int(rng.integers(1, n + 1))
+    wl = Workload(kind, n, P, nb, chain_id=b"celestia", seed=int(rng.integers(1, 2**31)), signed_permille=int(rng.integers(500, 1001)),
+                  rounds=(0, int(rng.integers(0, 5))))
+    proofs, targets = bytearray(wl.proofs), bytearray(wl.targets)
+    trusteds = bytearray(wl.trusteds) if kind == 0 else None
+    for p in range(0, P, 2):
+        for _ in range(int(rng.integers(1, 4))):
+            which = int(rng.integers(0, 3 if kind == 0 else 2))
+            if which == 0:
+                off = p * 2336 + int(rng.integers(0, 2336))
+                if (off - p * 2336) in range(56, 64):
+                    continue      # nb_a / nb_b > n is a host-side error (TMX_ERR_SET_TOO_LARGE), covered elsewhere
+                proofs[off] ^= 1 << int(rng.integers(0, 8))
+            elif which == 1:
+                targets[p * n * 256 + int(rng.integers(0, n * 256))] ^= 1 << int(rng.integers(0, 8))
+            else:
+                trusteds[p * n * 48 + int(rng.integers(0, n * 48))] ^= 1 << int(rng.integers(0, 8))
+    _check_vs_oracle(tmx, oracle, kind, n, bytes(proofs), bytes(targets), bytes(trusteds) if trusteds is not None else None, b"celestia")
+
+
 def test_adversarial_mutations(tmx, oracle):
     """Random corruption of every input field: verdicts may flip, parity with the oracle must not."""
     from tendermintx_amd.synth import Workload
