@@ -229,6 +229,11 @@ int32_t tmx_ntt_goldilocks_device(tmx_ctx* ctx, uint32_t log_n, uint32_t n_cols,
 int32_t tmx_lde_goldilocks_device(tmx_ctx* ctx, uint32_t log_n, uint32_t log_blowup, uint32_t n_cols, const uint64_t* d_in,
                                   uint64_t* d_out, void* hip_stream);
 
+/* Self-test hook: k_ed_fin inverts with Bernstein-Yang division steps (inv25519.hpp); this runs that inversion and the Fermat chain
+ * on n caller-provided values (eight little-endian words each, taken mod 2^255 - 19) and returns both results per value:
+ * out_words[16 i .. 16 i + 7] = Fermat, out_words[16 i + 8 .. 16 i + 15] = division steps.  Host buffers, blocking. */
+int32_t tmx_selftest_fe_invert(tmx_ctx* ctx, uint32_t n, const uint32_t* in_words, uint32_t* out_words);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,6 +108,18 @@ class Context:
         check(self._L.tmx_witness_batch_device(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports,
                                                self._stream(stream)), self._h)
 
+    def selftest_fe_invert(self, values):
+        """values: ints; returns [(fermat_inverse, safegcd_inverse)] mod 2^255 - 19 as computed on the GPU (self-test hook)."""
+        n = len(values)
+        inp = np.zeros((n, 8), dtype=np.uint32)
+        for i, v in enumerate(values):
+            for k in range(8):
+                inp[i, k] = (int(v) >> (32 * k)) & 0xFFFFFFFF
+        out = np.zeros((n, 16), dtype=np.uint32)
+        check(self._L.tmx_selftest_fe_invert(self._h, n, inp.ctypes.data, out.ctypes.data), self._h)
+        conv = lambda w: sum(int(w[k]) << (32 * k) for k in range(8))
+        return [(conv(out[i, :8]), conv(out[i, 8:])) for i in range(n)]
+
     # ---- Goldilocks NTT / coset LDE (device pointers; columns of 2**log_n u64, column c at element c << log_n)
     def ntt_device(self, log_n, n_cols, d_in, d_out, inverse=False, stream=None):
         check(self._L.tmx_ntt_goldilocks_device(self._h, log_n, n_cols, d_in, d_out, 1 if inverse else 0, self._stream(stream)), self._h)

@@ -326,7 +326,12 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   c->ev_mul_recorded = false;
   int32_t st = ed_producer(s);
   if (st) return st;
-  if (c->ev_mul_recorded) HIPCK(c, hipStreamWaitEvent(c->side, c->ev_mul, 0));
+  // TMX_PROOFSER_HOLD=1 keeps these launches back until the table walk is done (with the 80 KB 4-bit key tables they doubled its run
+  // time; with the 6-bit tables and the short finish they are better off right behind k_proof: -2 % step at 256 proofs)
+  {
+    const char* hold = std::getenv("TMX_PROOFSER_HOLD");
+    if (c->ev_mul_recorded && hold && hold[0] == '1') HIPCK(c, hipStreamWaitEvent(c->side, c->ev_mul, 0));
+  }
   st0 = c->ser_split ? serialize(prog.mask_proof, c->side) : TMX_OK;
   if (st0) return st0;
   HIPCK(c, hipStreamWaitEvent(c->side, c->ev_join3, 0));  // ev_join = both low-priority streams done
@@ -416,8 +421,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   if ((e = hipStreamWaitEvent(s, c->ev_join2, 0)) != hipSuccess) return (int)e;
   rc = launch_ed_mul_tab(Q, s);
   if (rc) return rc;
-  // the table walk is the one EdDSA kernel that streams from L2 / HBM: run_batch holds the serializer launches of the side stream
-  // back until it is done (beside it they double its run time; beside the latency-bound k_ed_fin they are free)
+  // (run_batch can hold the serializer launches of the side stream back until the walk is done: TMX_PROOFSER_HOLD)
   if ((e = hipEventRecord(c->ev_mul, s)) != hipSuccess) return (int)e;
   c->ev_mul_recorded = true;
   return launch_ed_fin(Q, s);
@@ -954,6 +958,24 @@ int32_t tmx_lde_goldilocks_device(tmx_ctx* c, uint32_t log_n, uint32_t log_blowu
   int rc = launch_lde_expand(coef, log_n, log_m, n_cols, s);           // c_i g^i, zero padding
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_lde_expand launch: ") + hipGetErrorString((hipError_t)rc));
   return ntt_run(c, log_m, n_cols, coef, M, d_out, M, tmp, false, s);
+}
+
+// self-test hook: both inversions mod 2^255 - 19 (the Fermat chain and the safegcd one k_ed_fin uses) on n values of eight LE words
+int32_t tmx_selftest_fe_invert(tmx_ctx* c, uint32_t n, const uint32_t* in_words, uint32_t* out_words) {
+  if (!c || !in_words || !out_words) return TMX_ERR_BAD_ARG;
+  if (n == 0) return TMX_OK;
+  HIPCK(c, hipSetDevice(c->cfg.device));
+  void *d_in = nullptr, *d_out = nullptr;
+  hipError_t e = hipMalloc(&d_in, (size_t)n * 32);
+  if (e == hipSuccess) e = hipMalloc(&d_out, (size_t)n * 64);
+  if (e == hipSuccess) e = hipMemcpy(d_in, in_words, (size_t)n * 32, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = (hipError_t)launch_selftest_invert(n, d_in, d_out, c->side2);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->side2);
+  if (e == hipSuccess) e = hipMemcpy(out_words, d_out, (size_t)n * 64, hipMemcpyDeviceToHost);
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(c, TMX_ERR_HIP, std::string("tmx_selftest_fe_invert: ") + hipGetErrorString(e));
+  return TMX_OK;
 }
 
 }  // extern "C"

@@ -10,6 +10,7 @@ namespace tmx {
 size_t base_table_bytes(uint32_t w_bits);
 // each returns a hipError_t value (0 = success); all launches are asynchronous on `stream` (hipStream_t)
 int launch_init_base(void* d_table, uint32_t w_bits, void* stream);
+int launch_selftest_invert(uint32_t n, const void* d_in, void* d_out, void* stream);
 int launch_eddsa(uint32_t n_lanes, const void* d_target, void* d_ed, uint32_t ed_stride, const void* d_table, void* stream);
 // quad-parallel EdDSA path.  Three launch groups so that api.cpp can run the key pipeline on a side stream:
 //   keys pipeline (dedup -> decode distinct keys -> optional per-key tables)  ||  phase 1 (decode R, SHA-512 mod l, s*B)

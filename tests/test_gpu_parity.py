@@ -213,6 +213,23 @@ def test_synthetic_batches(tmx, oracle, kind, n, nb, permille):
     assert all(r["all_ok"] for r in reps)
 
 
+def test_field_inversions_agree_with_big_int_arithmetic(tmx):
+    """k_ed_fin inverts with Bernstein-Yang division steps; the self-test hook returns that and the Fermat chain for caller values.
+    Edge values (0, +-1, 2^k +- 1, p - small, non-canonical representatives up to 2^256 - 1, limb-boundary patterns) and 4096 random ones
+    against pow(x, p - 2, p)."""
+    p = 2**255 - 19
+    rng = np.random.default_rng(25519)
+    vals = [0, 1, 2, 3, 19, 20, p - 1, p - 2, p - 19, p, p + 1, 2**255 - 1, 2**255, 2**256 - 1, 2**254, 2**252 + 27742317777372353535851937790883648493]
+    vals += [2**k for k in range(0, 256, 5)] + [2**k - 1 for k in range(1, 256, 7)] + [p - 2**k for k in range(0, 255, 9)]
+    vals += [sum(((1 << 30) - 1) << (30 * i) for i in range(0, 9, 2)) % 2**256, sum(1 << (30 * i) for i in range(9)), (1 << 255) - (1 << 30)]
+    vals += [int.from_bytes(rng.bytes(32), "little") for _ in range(4096)]
+    with tmx.Context(4, b"celestia", max_batch=1) as ctx:
+        got = ctx.selftest_fe_invert(vals)
+    for v, (fermat, safegcd) in zip(vals, got):
+        want = pow(v % p, p - 2, p)
+        assert fermat == want and safegcd == want, hex(v)
+
+
 @pytest.mark.parametrize("seed", range(32))
 def test_random_shapes_and_bit_flips(tmx, oracle, seed):
     """Fuzz: random VALIDATOR_SET_SIZE_MAX (incl. odd sizes), batch size, real set size, signer fraction, rounds, kind, and a few
