@@ -225,8 +225,10 @@ struct tmx_ctx {
   hipStream_t side = nullptr;  // k_proof runs here, concurrently with the EdDSA kernels of the caller's stream
   hipEvent_t ev_join = nullptr;
   hipEvent_t ev_side[EV_RING_DECL][4] = {};
-  hipEvent_t ev_tail = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_hash_clean = nullptr, ev_keys = nullptr, ev_mul = nullptr;
+  hipEvent_t ev_tail = nullptr, ev_fork2 = nullptr, ev_hash_clean = nullptr, ev_keys = nullptr, ev_mul = nullptr;
   bool ev_mul_recorded = false;
+  hipEvent_t ev_part[4] = {};
+  uint32_t tab_parts = 2;  // TMX_TAB_PARTS=1|2|4
   bool have_streams = false;
   // ring of HIP-event sets: one set (TMX_N_KERNELS + 1 events) per enqueued batch, so that kernel durations can be
   // averaged over a whole timed region afterwards without synchronising inside it
@@ -408,9 +410,14 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   rc = launch_ed_keys(Q, c->side2);
   if (rc) return rc;
   if ((e = hipEventRecord(c->ev_keys, c->side2)) != hipSuccess) return (int)e;
-  rc = launch_ed_key_tables(Q, c->side2);
-  if (rc) return rc;
-  if ((e = hipEventRecord(c->ev_join2, c->side2)) != hipSuccess) return (int)e;
+  // The anchor chain is cut into `parts` launches on side2; the cached multiples of part p are built on s (idle once phase 1 is
+  // done) while side2 doubles part p+1, so that only the multiples of the last part follow the chain.
+  const uint32_t parts = c->tab_parts;
+  for (uint32_t p = 0; p < parts; p++) {
+    rc = launch_ed_tab_anchor(Q, p, parts, c->side2);
+    if (rc) return rc;
+    if ((e = hipEventRecord(c->ev_part[p], c->side2)) != hipSuccess) return (int)e;
+  }
   if ((e = hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, c->side2)) != hipSuccess) return (int)e;  // for the next launch
   if ((e = hipEventRecord(c->ev_hash_clean, c->side2)) != hipSuccess) return (int)e;
   rc = launch_ed_phase1(Q, s);
@@ -418,7 +425,11 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   if ((e = hipStreamWaitEvent(s, c->ev_keys, 0)) != hipSuccess) return (int)e;
   rc = launch_ed_mul_direct(Q, s);  // empty when the tables are used: enqueued before the wait for them
   if (rc) return rc;
-  if ((e = hipStreamWaitEvent(s, c->ev_join2, 0)) != hipSuccess) return (int)e;
+  for (uint32_t p = 0; p < parts; p++) {
+    if ((e = hipStreamWaitEvent(s, c->ev_part[p], 0)) != hipSuccess) return (int)e;
+    rc = launch_ed_tab_mult(Q, p, parts, s);
+    if (rc) return rc;
+  }
   rc = launch_ed_mul_tab(Q, s);
   if (rc) return rc;
   // (run_batch can hold the serializer launches of the side stream back until the walk is done: TMX_PROOFSER_HOLD)
@@ -538,7 +549,8 @@ void tmx_ctx_destroy(tmx_ctx* c) {
       if (e) (void)hipEventDestroy(e);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
-  if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
+  for (hipEvent_t ev : c->ev_part)
+    if (ev) (void)hipEventDestroy(ev);
   if (c->ev_keys) (void)hipEventDestroy(c->ev_keys);
   if (c->ev_hash_clean) (void)hipEventDestroy(c->ev_hash_clean);
   if (c->ev_mul) (void)hipEventDestroy(c->ev_mul);
@@ -568,7 +580,12 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   HIPCK(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming));
-  HIPCK(c, hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
+  for (auto& ev : c->ev_part) HIPCK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  {
+    const char* tp = std::getenv("TMX_TAB_PARTS");
+    const int v = tp ? std::atoi(tp) : 2;
+    c->tab_parts = (v == 1 || v == 2 || v == 4) ? (uint32_t)v : 2u;
+  }
   HIPCK(c, hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_hash_clean, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_mul, hipEventDisableTiming));

@@ -39,7 +39,8 @@ size_t keytab_bytes_per_key(uint32_t key_w);
 int launch_init_base_quad(const void* d_table, void* d_qtable, uint32_t w_bits, void* stream);
 int launch_ed_dedup(const EdQuad& Q, void* stream);
 int launch_ed_keys(const EdQuad& Q, void* stream);
-int launch_ed_key_tables(const EdQuad& Q, void* stream);
+int launch_ed_tab_anchor(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream);
+int launch_ed_tab_mult(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream);
 int launch_ed_mul_direct(const EdQuad& Q, void* stream);
 int launch_ed_phase1(const EdQuad& Q, void* stream);
 int launch_ed_mul_tab(const EdQuad& Q, void* stream);
