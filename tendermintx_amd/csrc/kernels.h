@@ -43,7 +43,7 @@ int launch_ed_tab_anchor(const EdQuad& Q, uint32_t part, uint32_t parts, void* s
 int launch_ed_tab_mult(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream);
 int launch_ed_mul_direct(const EdQuad& Q, void* stream);
 int launch_ed_phase1(const EdQuad& Q, void* stream);
-int launch_ed_mul_tab(const EdQuad& Q, void* stream);
+int launch_ed_mul_tab(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream);
 int launch_ed_fin(const EdQuad& Q, void* stream);
 int launch_proof(const ProofParams& P, uint32_t n_proofs, const void* d_proofs, const void* d_target, const void* d_trusted, void* d_lt,
                  uint32_t lt_stride, void* d_lr, void* d_pf, void* d_nodes_t, void* d_nodes_r, void* d_reports, void* stream);
