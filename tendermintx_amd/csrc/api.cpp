@@ -416,6 +416,10 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   for (uint32_t p = 0; p < parts; p++) {
     rc = launch_ed_tab_anchor(Q, p, parts, c->side2);
     if (rc) return rc;
+    if (p + 1 == parts) {  // the multiples of the last part stay on the high-priority stream: nothing is left to overlap them with
+      rc = launch_ed_tab_mult(Q, p, parts, c->side2);
+      if (rc) return rc;
+    }
     if ((e = hipEventRecord(c->ev_part[p], c->side2)) != hipSuccess) return (int)e;
   }
   if ((e = hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, c->side2)) != hipSuccess) return (int)e;  // for the next launch
@@ -431,8 +435,10 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   const bool walk_parts = wp ? wp[0] == '1' : n_lanes >= 131072;
   for (uint32_t p = 0; p < parts; p++) {
     if ((e = hipStreamWaitEvent(s, c->ev_part[p], 0)) != hipSuccess) return (int)e;
-    rc = launch_ed_tab_mult(Q, p, parts, s);
-    if (rc) return rc;
+    if (p + 1 < parts) {
+      rc = launch_ed_tab_mult(Q, p, parts, s);
+      if (rc) return rc;
+    }
     if (walk_parts) {
       rc = launch_ed_mul_tab(Q, p, parts, s);
       if (rc) return rc;
