@@ -226,7 +226,8 @@ struct tmx_ctx {
   hipEvent_t ev_join = nullptr;
   hipEvent_t ev_side[EV_RING_DECL][4] = {};
   hipEvent_t ev_tail = nullptr, ev_fork2 = nullptr, ev_hash_clean = nullptr, ev_keys = nullptr, ev_mul = nullptr;
-  bool ev_mul_recorded = false;
+  bool ev_mul_recorded = false, want_ev_mul = false, fin_done_attached = false, ext_events = true;
+  void* fin_done = nullptr;  // set by run_batch around the EdDSA producer: the event k_ed_fin signals
   hipEvent_t ev_part[4] = {};
   uint32_t tab_parts = 2;  // TMX_TAB_PARTS=1|2|4
   bool have_streams = false;
@@ -326,19 +327,25 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   HIPCK(c, hipEventRecord(evs[1], c->side));
 
   c->ev_mul_recorded = false;
+  const char* hold = std::getenv("TMX_PROOFSER_HOLD");
+  c->want_ev_mul = hold && hold[0] == '1';
+  {  // ev[1] rides on the k_ed_fin dispatch itself when the quad path runs (TMX_EXT_EVENTS=0: a record packet behind it)
+    const char* xe = std::getenv("TMX_EXT_EVENTS");
+    c->ext_events = !(xe && xe[0] == '0');
+    c->fin_done = c->ext_events ? ev[1] : nullptr;
+    c->fin_done_attached = false;
+  }
   int32_t st = ed_producer(s);
+  c->fin_done = nullptr;
   if (st) return st;
   // TMX_PROOFSER_HOLD=1 keeps these launches back until the table walk is done (with the 80 KB 4-bit key tables they doubled its run
   // time; with the 6-bit tables and the short finish they are better off right behind k_proof: -2 % step at 256 proofs)
-  {
-    const char* hold = std::getenv("TMX_PROOFSER_HOLD");
-    if (c->ev_mul_recorded && hold && hold[0] == '1') HIPCK(c, hipStreamWaitEvent(c->side, c->ev_mul, 0));
-  }
+  if (c->ev_mul_recorded) HIPCK(c, hipStreamWaitEvent(c->side, c->ev_mul, 0));
   st0 = c->ser_split ? serialize(prog.mask_proof, c->side) : TMX_OK;
   if (st0) return st0;
   HIPCK(c, hipStreamWaitEvent(c->side, c->ev_join3, 0));  // ev_join = both low-priority streams done
   HIPCK(c, hipEventRecord(c->ev_join, c->side));
-  HIPCK(c, hipEventRecord(ev[1], s));
+  if (!c->fin_done_attached) HIPCK(c, hipEventRecord(ev[1], s));
   // (a small batch is pure latency: its tail stays on s, two cross-stream hops cost more than the overlap gains)
   const bool tail_aside = c->ser_split && (uint64_t)n_proofs * n >= 4096;
   if (c->ser_split && !tail_aside) {
@@ -394,6 +401,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   Q.d_mulout = c->d_mulout; Q.d_hash = c->d_hash; Q.hash_mask = c->hash_mask; Q.d_owner_of = c->d_owner_of;
   Q.d_uid_of_owner = c->d_uid_of_owner; Q.d_owners = c->d_owners; Q.d_keyrec = c->d_keyrec; Q.d_anchors = c->d_anchors; Q.d_keytab = c->d_keytab;
   Q.key_cap = c->key_cap; Q.key_w = c->key_w; Q.mode = c->dedup_mode;
+  Q.fin_done = c->fin_done; c->fin_done = nullptr;
   c->last_lanes = n_lanes;
   Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * c->parity;
   Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1);
@@ -402,25 +410,31 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   // dedup on s, then the distinct-key pipeline (decode -> anchors -> table: a latency chain of a few waves) on the high-priority
   // stream side2 beside phase 1 on s; both join before h*A.  (Queue priority also decides which waves issue first on a shared
   // SIMD: with the chain on a normal-priority queue k_ed_keys alone takes 230 us instead of 100.)
-  if ((e = hipStreamWaitEvent(s, c->ev_hash_clean, 0)) != hipSuccess) return (int)e;  // cleared on side2 by the previous launch
-  int rc = launch_ed_dedup(Q, s);
+  // (cleared on side2 by the previous launch.  Skipping this wait when s has already waited for side2's tail was measured: k_proof
+  // 0.45 -> 0.52 ms beside it and the step +2 % at 256 proofs -- the packet stays.)
+  if ((e = hipStreamWaitEvent(s, c->ev_hash_clean, 0)) != hipSuccess) return (int)e;
+  // Events that mark the end of one kernel ride on its dispatch (completion signal) instead of a record packet behind it: on the
+  // chain every packet is latency.  `x` = that is on and the kernel really is launched.
+  const bool x = c->ext_events && n_lanes != 0, xt = x && Q.mode != 0 && Q.key_cap != 0;
+  int rc = launch_ed_dedup(Q, s, x ? c->ev_fork2 : nullptr);
   if (rc) return rc;
-  if ((e = hipEventRecord(c->ev_fork2, s)) != hipSuccess) return (int)e;
+  if (!x && (e = hipEventRecord(c->ev_fork2, s)) != hipSuccess) return (int)e;
   if ((e = hipStreamWaitEvent(c->side2, c->ev_fork2, 0)) != hipSuccess) return (int)e;
-  rc = launch_ed_keys(Q, c->side2);
+  rc = launch_ed_keys(Q, c->side2, x ? c->ev_keys : nullptr);
   if (rc) return rc;
-  if ((e = hipEventRecord(c->ev_keys, c->side2)) != hipSuccess) return (int)e;
+  if (!x && (e = hipEventRecord(c->ev_keys, c->side2)) != hipSuccess) return (int)e;
   // The anchor chain is cut into `parts` launches on side2; the cached multiples of part p are built on s (idle once phase 1 is
   // done) while side2 doubles part p+1, so that only the multiples of the last part follow the chain.
   const uint32_t parts = c->tab_parts;
   for (uint32_t p = 0; p < parts; p++) {
-    rc = launch_ed_tab_anchor(Q, p, parts, c->side2);
+    const bool last = p + 1 == parts;
+    rc = launch_ed_tab_anchor(Q, p, parts, c->side2, xt && !last ? c->ev_part[p] : nullptr);
     if (rc) return rc;
-    if (p + 1 == parts) {  // the multiples of the last part stay on the high-priority stream: nothing is left to overlap them with
-      rc = launch_ed_tab_mult(Q, p, parts, c->side2);
+    if (last) {  // the multiples of the last part stay on the high-priority stream: nothing is left to overlap them with
+      rc = launch_ed_tab_mult(Q, p, parts, c->side2, xt ? c->ev_part[p] : nullptr);
       if (rc) return rc;
     }
-    if ((e = hipEventRecord(c->ev_part[p], c->side2)) != hipSuccess) return (int)e;
+    if (!xt && (e = hipEventRecord(c->ev_part[p], c->side2)) != hipSuccess) return (int)e;
   }
   if ((e = hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, c->side2)) != hipSuccess) return (int)e;  // for the next launch
   if ((e = hipEventRecord(c->ev_hash_clean, c->side2)) != hipSuccess) return (int)e;
@@ -449,9 +463,13 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     if (rc) return rc;
   }
   // (run_batch can hold the serializer launches of the side stream back until the walk is done: TMX_PROOFSER_HOLD)
-  if ((e = hipEventRecord(c->ev_mul, s)) != hipSuccess) return (int)e;
-  c->ev_mul_recorded = true;
-  return launch_ed_fin(Q, s);
+  if (c->want_ev_mul) {
+    if ((e = hipEventRecord(c->ev_mul, s)) != hipSuccess) return (int)e;
+    c->ev_mul_recorded = true;
+  }
+  rc = launch_ed_fin(Q, s);
+  c->fin_done_attached = rc == 0 && Q.fin_done != nullptr && n_lanes != 0;
+  return rc;
 }
 
 extern "C" {

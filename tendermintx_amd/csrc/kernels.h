@@ -29,6 +29,7 @@ struct EdQuad {
   uint32_t key_w;    // window width of the per-key tables (4 or 6 bits)
   uint32_t key_cap;  // keys the table buffers can hold
   uint32_t mode;     // 0 never build tables, 1 automatic (>= 8 lanes per key), 2 whenever they fit
+  void* fin_done;    // event attached to the k_ed_fin dispatch as its completion signal (no separate record packet), or null
 };
 size_t quad_table_bytes(uint32_t w_bits);
 size_t pre_bytes_per_lane();
@@ -37,10 +38,11 @@ size_t key_bytes_per_key();
 size_t anchor_bytes_per_key(uint32_t key_w);
 size_t keytab_bytes_per_key(uint32_t key_w);
 int launch_init_base_quad(const void* d_table, void* d_qtable, uint32_t w_bits, void* stream);
-int launch_ed_dedup(const EdQuad& Q, void* stream);
-int launch_ed_keys(const EdQuad& Q, void* stream);
-int launch_ed_tab_anchor(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream);
-int launch_ed_tab_mult(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream);
+// (`done`: an event signalled by the dispatch itself when the kernel completes -- saves the record packet behind it; may be null)
+int launch_ed_dedup(const EdQuad& Q, void* stream, void* done = nullptr);
+int launch_ed_keys(const EdQuad& Q, void* stream, void* done = nullptr);
+int launch_ed_tab_anchor(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream, void* done = nullptr);
+int launch_ed_tab_mult(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream, void* done = nullptr);
 int launch_ed_mul_direct(const EdQuad& Q, void* stream);
 int launch_ed_phase1(const EdQuad& Q, void* stream);
 int launch_ed_mul_tab(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream);
