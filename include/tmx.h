@@ -234,6 +234,10 @@ int32_t tmx_lde_goldilocks_device(tmx_ctx* ctx, uint32_t log_n, uint32_t log_blo
  * out_words[16 i .. 16 i + 7] = Fermat, out_words[16 i + 8 .. 16 i + 15] = division steps.  Host buffers, blocking. */
 int32_t tmx_selftest_fe_invert(tmx_ctx* ctx, uint32_t n, const uint32_t* in_words, uint32_t* out_words);
 
+/* Self test of the limb-parallel field arithmetic used by the table chain: per item 128 words in (A, B: 4 rows x 16 limbs), 256 words
+ * out (A*B | 2^doublings * A as a point | A in ten limbs | B's ten-limb words in 16-bit limbs).  Test hook, not part of the path. */
+int32_t tmx_selftest_f16(tmx_ctx* ctx, uint32_t n, uint32_t doublings, const uint32_t* in_words, uint32_t* out_words);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,6 +120,14 @@ class Context:
         conv = lambda w: sum(int(w[k]) << (32 * k) for k in range(8))
         return [(conv(out[i, :8]), conv(out[i, 8:])) for i in range(n)]
 
+    def selftest_f16(self, words, doublings):
+        """words: uint32 array (n, 128); returns uint32 (n, 256) -- see tmx_selftest_f16 (self-test hook)."""
+        inp = np.ascontiguousarray(words, dtype=np.uint32)
+        n = inp.shape[0]
+        out = np.zeros((n, 256), dtype=np.uint32)
+        check(self._L.tmx_selftest_f16(self._h, n, doublings, inp.ctypes.data, out.ctypes.data), self._h)
+        return out
+
     # ---- Goldilocks NTT / coset LDE (device pointers; columns of 2**log_n u64, column c at element c << log_n)
     def ntt_device(self, log_n, n_cols, d_in, d_out, inverse=False, stream=None):
         check(self._L.tmx_ntt_goldilocks_device(self._h, log_n, n_cols, d_in, d_out, 1 if inverse else 0, self._stream(stream)), self._h)

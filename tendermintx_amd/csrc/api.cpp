@@ -225,7 +225,7 @@ struct tmx_ctx {
   hipStream_t side = nullptr;  // k_proof runs here, concurrently with the EdDSA kernels of the caller's stream
   hipEvent_t ev_join = nullptr;
   hipEvent_t ev_side[EV_RING_DECL][4] = {};
-  hipEvent_t ev_tail = nullptr, ev_fork2 = nullptr, ev_hash_clean = nullptr, ev_keys = nullptr, ev_mul = nullptr;
+  hipEvent_t ev_p1 = nullptr, ev_tail = nullptr, ev_fork2 = nullptr, ev_hash_clean = nullptr, ev_keys = nullptr, ev_mul = nullptr;
   bool ev_mul_recorded = false, want_ev_mul = false, fin_done_attached = false, ext_events = true;
   void* fin_done = nullptr;  // set by run_batch around the EdDSA producer: the event k_ed_fin signals
   hipEvent_t ev_part[4] = {};
@@ -245,6 +245,8 @@ struct tmx_ctx {
   void *d_qtable = nullptr, *d_pre = nullptr, *d_mulout = nullptr;
   void *d_hash = nullptr, *d_cnt = nullptr, *d_owner_of = nullptr, *d_uid_of_owner = nullptr, *d_owners = nullptr, *d_keyrec = nullptr,
        *d_anchors = nullptr, *d_keytab = nullptr;
+  uint32_t anchor16 = 1, keys16 = 1;
+  uint32_t p1_side = 3;
   uint32_t hash_mask = 0, key_cap = 0, dedup_mode = 1;  // TMX_DEDUP=0|1|2: never / automatic / always build per-key tables
   hipStream_t side2 = nullptr;  // distinct-key pipeline, concurrent with phase 1
   hipStream_t side3 = nullptr;  // early serialization of the input-only sections
@@ -316,9 +318,16 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   HIPCK(c, hipStreamWaitEvent(c->side, ev[0], 0));
   HIPCK(c, hipStreamWaitEvent(c->side3, ev[0], 0));
   // side3: the sections that are a pure expansion of the input records (42 % of a skip row) -- HBM is idle while EdDSA runs
-  int32_t st0 = c->ser_split ? serialize(prog.mask_inputs, c->side3) : TMX_OK;
-  if (st0) return st0;
-  HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
+  // (with phase 1 on side3 these launches are enqueued behind it, after the EdDSA producer)
+  int32_t st0 = TMX_OK;
+  auto inputs_on_side3 = [&]() -> int32_t {
+    const int32_t r = c->ser_split ? serialize(prog.mask_inputs, c->side3) : TMX_OK;
+    if (r) return r;
+    HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
+    return TMX_OK;
+  };
+  const bool inputs_late = c->p1_side == 1 && c->quad;
+  if (!inputs_late && (st0 = inputs_on_side3())) return st0;
   // side: k_proof, then the sections that only need its results
   HIPCK(c, hipEventRecord(evs[0], c->side));
   int rc = launch_proof(proof_params(c, kind), n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf, c->d_nodes_t,
@@ -338,6 +347,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   int32_t st = ed_producer(s);
   c->fin_done = nullptr;
   if (st) return st;
+  if (inputs_late && (st0 = inputs_on_side3())) return st0;
   // TMX_PROOFSER_HOLD=1 keeps these launches back until the table walk is done (with the 80 KB 4-bit key tables they doubled its run
   // time; with the 6-bit tables and the short finish they are better off right behind k_proof: -2 % step at 256 proofs)
   if (c->ev_mul_recorded) HIPCK(c, hipStreamWaitEvent(c->side, c->ev_mul, 0));
@@ -402,6 +412,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   Q.d_uid_of_owner = c->d_uid_of_owner; Q.d_owners = c->d_owners; Q.d_keyrec = c->d_keyrec; Q.d_anchors = c->d_anchors; Q.d_keytab = c->d_keytab;
   Q.key_cap = c->key_cap; Q.key_w = c->key_w; Q.mode = c->dedup_mode;
   Q.fin_done = c->fin_done; c->fin_done = nullptr;
+  Q.anchor16 = c->anchor16; Q.keys16 = c->keys16;
   c->last_lanes = n_lanes;
   Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * c->parity;
   Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1);
@@ -438,8 +449,30 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   }
   if ((e = hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, c->side2)) != hipSuccess) return (int)e;  // for the next launch
   if ((e = hipEventRecord(c->ev_hash_clean, c->side2)) != hipSuccess) return (int)e;
-  rc = launch_ed_phase1(Q, s);
-  if (rc) return rc;
+  // Phase 1 (SHA-512, s*B: throughput work for every lane) goes to the low-priority stream side3: on s it would sit in front of the
+  // table multiples of the first part, which then start when phase 1 ends instead of when their anchors are ready.
+  // (measured at 256 / 1024 proofs x 128: mode 1 +3 % / +8 % step time, mode 2 +0.7 % / -1.3 %: the walk starts 55 us earlier but shares
+  // the SIMDs with s*B -- the span is VALU-throughput-bound either way)
+  const uint32_t p1_side = c->p1_side == 3 ? (n_lanes >= 131072 ? 2u : 0u) : c->p1_side;
+  bool wait_p1_late = false;
+  if (p1_side == 1) {
+    if ((e = hipStreamWaitEvent(c->side3, c->ev_fork2, 0)) != hipSuccess) return (int)e;
+    rc = launch_ed_phase1(Q, c->side3, x ? c->ev_p1 : nullptr);
+    if (rc) return rc;
+    if (!x && (e = hipEventRecord(c->ev_p1, c->side3)) != hipSuccess) return (int)e;
+    if ((e = hipStreamWaitEvent(s, c->ev_p1, 0)) != hipSuccess) return (int)e;
+  } else if (p1_side == 2) {  // hash role on s (the walk needs it), s*B behind the input sections on side3 (only k_ed_fin needs it)
+    rc = launch_ed_phase1(Q, s, nullptr, 1);
+    if (rc) return rc;
+    if ((e = hipStreamWaitEvent(c->side3, c->ev_fork2, 0)) != hipSuccess) return (int)e;
+    rc = launch_ed_phase1(Q, c->side3, x ? c->ev_p1 : nullptr, 2);
+    if (rc) return rc;
+    if (!x && (e = hipEventRecord(c->ev_p1, c->side3)) != hipSuccess) return (int)e;
+    wait_p1_late = true;
+  } else {
+    rc = launch_ed_phase1(Q, s);
+    if (rc) return rc;
+  }
   if ((e = hipStreamWaitEvent(s, c->ev_keys, 0)) != hipSuccess) return (int)e;
   rc = launch_ed_mul_direct(Q, s);  // empty when the tables are used: enqueued before the wait for them
   if (rc) return rc;
@@ -467,6 +500,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     if ((e = hipEventRecord(c->ev_mul, s)) != hipSuccess) return (int)e;
     c->ev_mul_recorded = true;
   }
+  if (wait_p1_late && (e = hipStreamWaitEvent(s, c->ev_p1, 0)) != hipSuccess) return (int)e;
   rc = launch_ed_fin(Q, s);
   c->fin_done_attached = rc == 0 && Q.fin_done != nullptr && n_lanes != 0;
   return rc;
@@ -586,6 +620,7 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   for (hipEvent_t ev : c->ev_part)
     if (ev) (void)hipEventDestroy(ev);
   if (c->ev_keys) (void)hipEventDestroy(c->ev_keys);
+  if (c->ev_p1) (void)hipEventDestroy(c->ev_p1);
   if (c->ev_hash_clean) (void)hipEventDestroy(c->ev_hash_clean);
   if (c->ev_mul) (void)hipEventDestroy(c->ev_mul);
   if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
@@ -621,6 +656,7 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     c->tab_parts = (v == 1 || v == 2 || v == 4) ? (uint32_t)v : 2u;
   }
   HIPCK(c, hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_p1, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_hash_clean, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_mul, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -685,6 +721,14 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     {
       const char* kw = std::getenv("TMX_KEY_W");  // window width of the per-key tables
       c->key_w = (kw && std::atoi(kw) == 4) ? 4u : 6u;
+      const char* a16 = std::getenv("TMX_ANCHOR16");  // 0: the doubling chain of the tables in the quad form (one quad per key)
+      c->anchor16 = (a16 && a16[0] == '0') ? 0u : 1u;
+      const char* p1s = std::getenv("TMX_P1_SIDE");
+      // 0: phase 1 on the caller's stream, 1: on side3 (input sections behind it), 2: its s*B role on side3; default: by batch size
+      c->p1_side = p1s ? (uint32_t)(p1s[0] - '0') : 3u;
+      if (c->p1_side > 3) c->p1_side = 3;
+      const char* k16 = std::getenv("TMX_KEYS16");
+      c->keys16 = (k16 && k16[0] == '0') ? 0u : 1u;
     }
     HIPCK(c, hipMalloc(&c->d_anchors, kc * anchor_bytes_per_key(c->key_w)));
     HIPCK(c, hipMalloc(&c->d_keytab, kc * keytab_bytes_per_key(c->key_w)));
@@ -1012,6 +1056,24 @@ int32_t tmx_lde_goldilocks_device(tmx_ctx* c, uint32_t log_n, uint32_t log_blowu
 }
 
 // self-test hook: both inversions mod 2^255 - 19 (the Fermat chain and the safegcd one k_ed_fin uses) on n values of eight LE words
+int32_t tmx_selftest_f16(tmx_ctx* c, uint32_t n, uint32_t doublings, const uint32_t* in_words, uint32_t* out_words) {
+  if (!c || !in_words || !out_words) return TMX_ERR_BAD_ARG;
+  if (n == 0) return TMX_OK;
+  HIPCK(c, hipSetDevice(c->cfg.device));
+  void *d_in = nullptr, *d_out = nullptr;
+  hipError_t e = hipMalloc(&d_in, (size_t)n * 512);
+  if (e == hipSuccess) e = hipMalloc(&d_out, (size_t)n * 1024);
+  if (e == hipSuccess) e = hipMemcpy(d_in, in_words, (size_t)n * 512, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, (size_t)n * 1024, c->side2);
+  if (e == hipSuccess) e = (hipError_t)launch_selftest_f16(n, doublings, d_in, d_out, c->side2);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->side2);
+  if (e == hipSuccess) e = hipMemcpy(out_words, d_out, (size_t)n * 1024, hipMemcpyDeviceToHost);
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(c, TMX_ERR_HIP, std::string("tmx_selftest_f16: ") + hipGetErrorString(e));
+  return TMX_OK;
+}
+
 int32_t tmx_selftest_fe_invert(tmx_ctx* c, uint32_t n, const uint32_t* in_words, uint32_t* out_words) {
   if (!c || !in_words || !out_words) return TMX_ERR_BAD_ARG;
   if (n == 0) return TMX_OK;

@@ -1,0 +1,165 @@
+// Limb-parallel arithmetic mod p = 2^255 - 19 for the latency-bound chains (key decoding, the 252 doublings behind the per-key
+// tables): ONE field element = sixteen 16-bit limbs in the sixteen lanes of a DPP row, so a wave holds four elements -- the four
+// coordinates of one point -- in a single VGPR and a multiplication is ~60 instructions instead of the ~250 of the limbs-in-registers
+// form (a lone wave issues one VALU instruction per 4-5 cycles whatever it is, so chain latency = instruction count).
+//
+// Bounds: "carried" = every limb <= F16_C (2^16 + 2280); mul() takes limbs up to 441505 (a * 38 must stay below 2^24) and returns
+// carried limbs; add() is plain, sub() adds a multiple of p whose limbs dominate the subtrahend's.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tmx {
+namespace f16 {
+
+constexpr uint32_t F16_C = 65536 + 2280;
+
+template <int S>
+__device__ __forceinline__ uint32_t ror(uint32_t v) {  // lane k of a row <- lane (k - S) mod 16
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x120 + S, 0xf, 0xf, false);
+}
+template <int S>
+__device__ __forceinline__ uint32_t bcast(uint32_t v) {  // every lane of a row <- lane S (row_newbcast)
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x150 + S, 0xf, 0xf, false);
+}
+
+struct Ctx {
+  uint32_t fac[16];  // fac[s] = 38 on the lanes a rotation by s wraps around (2^256 = 38 mod p), else 1
+  uint32_t b4, b8;   // this lane's limb of 4p / 8p, balanced so that every limb is 131070 / 262140 (limb 0: 130996 / 261992)
+  uint32_t k, row;
+};
+__device__ __forceinline__ Ctx make_ctx(int tid) {
+  Ctx c;
+  c.k = tid & 15; c.row = (tid >> 4) & 3;
+#pragma unroll
+  for (int s = 0; s < 16; s++) c.fac[s] = c.k < (uint32_t)s ? 38u : 1u;
+  c.b4 = c.k == 0 ? 130996u : 131070u;
+  c.b8 = c.k == 0 ? 261992u : 262140u;
+  return c;
+}
+
+template <int S>
+__device__ __forceinline__ void mul_step(uint64_t& acc, uint32_t a, uint32_t b, const Ctx& c) {
+  acc += (uint64_t)__umul24(ror<S>(a), c.fac[S]) * bcast<S>(b);  // lane k: a[k - S] * b[S], times 38 where k < S
+}
+// two carry rounds: 2^46 -> carried
+__device__ __forceinline__ uint32_t carry_wide(uint64_t acc, const Ctx& c) {
+  const uint32_t hi = (uint32_t)(acc >> 16);
+  uint32_t r = (uint32_t)acc & 0xffffu;
+  r += __umul24(ror<1>(hi & 0xffffu), c.fac[1]) + __umul24(ror<2>(hi >> 16), c.fac[2]);
+  const uint32_t c2 = r >> 16;
+  return (r & 0xffffu) + __umul24(ror<1>(c2), c.fac[1]);
+}
+// one carry round for a sum of a few loose limbs (< 2^24)
+__device__ __forceinline__ uint32_t carry(uint32_t r, const Ctx& c) { return (r & 0xffffu) + __umul24(ror<1>(r >> 16), c.fac[1]); }
+
+__device__ __forceinline__ uint32_t mul(uint32_t a, uint32_t b, const Ctx& c) {
+  uint64_t acc = (uint64_t)a * bcast<0>(b);
+  mul_step<1>(acc, a, b, c); mul_step<2>(acc, a, b, c); mul_step<3>(acc, a, b, c); mul_step<4>(acc, a, b, c);
+  mul_step<5>(acc, a, b, c); mul_step<6>(acc, a, b, c); mul_step<7>(acc, a, b, c); mul_step<8>(acc, a, b, c);
+  mul_step<9>(acc, a, b, c); mul_step<10>(acc, a, b, c); mul_step<11>(acc, a, b, c); mul_step<12>(acc, a, b, c);
+  mul_step<13>(acc, a, b, c); mul_step<14>(acc, a, b, c); mul_step<15>(acc, a, b, c);
+  return carry_wide(acc, c);
+}
+
+// each row's element in all four rows (v_permlane16_swap / v_permlane32_swap: gfx950)
+struct Rows { uint32_t r0, r1, r2, r3; };
+__device__ __forceinline__ Rows rows(uint32_t v) {
+  const auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);        // (r0 r0 r2 r2), (r1 r1 r3 r3)
+  const auto e = __builtin_amdgcn_permlane32_swap(p[0], p[0], false, false);  // (r0 x 4), (r2 x 4)
+  const auto o = __builtin_amdgcn_permlane32_swap(p[1], p[1], false, false);  // (r1 x 4), (r3 x 4)
+  return {e[0], o[0], e[1], o[1]};
+}
+__device__ __forceinline__ uint32_t row_pick(const Ctx& c, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+  return c.row == 0 ? v0 : (c.row == 1 ? v1 : (c.row == 2 ? v2 : v3));
+}
+
+// Point doubling on rows (X, Y, Z, X+Y) -> Q = rows (X3, Y3, Z3, T3) and the next (X3, Y3, Z3, X3+Y3); ref10's ge_p2_dbl + p1p1
+// conversion: e = (X+Y)^2 - XX - YY, h = YY + XX, g = YY - XX, f = 2ZZ - g; X3 = e f, Y3 = h g, Z3 = g f, T3 = e h.
+__device__ __forceinline__ uint32_t dbl(uint32_t V, uint32_t& Q, const Ctx& c) {
+  const Rows s = rows(mul(V, V, c));  // XX, YY, ZZ, (X+Y)^2: carried
+  const uint32_t h = s.r0 + s.r1;
+  const uint32_t e = s.r3 + c.b8 - h;                // h <= 2 C < limbs of 8p
+  const uint32_t g = s.r1 + c.b4 - s.r0;             // <= C + 131070
+  const uint32_t f = s.r2 + s.r2 + s.r0 + c.b4 - s.r1;  // <= 3 C + 131070 = 334518
+  Q = mul(row_pick(c, e, h, g, e), row_pick(c, f, g, f, h), c);
+  const auto p = __builtin_amdgcn_permlane16_swap(Q, Q, false, false);  // (X X Z Z), (Y Y T T)
+  const uint32_t xy = p[0] + p[1];                                      // (X+Y, X+Y, Z+T, Z+T)
+  const auto t = __builtin_amdgcn_permlane32_swap(xy, xy, false, false);
+  return c.row == 3 ? t[0] : Q;
+}
+
+// radix-2^25.5 limbs (signed, |limb| < 2^26: what the quad kernels store) -> this lane's 16-bit limb (< 2^17; lane 15 keeps the bits
+// above 2^256).  p10 = the ten limbs of this row's coordinate.
+__device__ __forceinline__ uint32_t from_limbs10(const int32_t* __restrict__ p10, const Ctx& c) {
+  uint32_t out = 0;
+  const int lo = 16 * (int)c.k;
+#pragma unroll
+  for (int j = 0; j < 10; j++) {
+    const int off = (51 * j + 1) / 2;                                              // ceil(25.5 j)
+    const uint32_t twop = j == 0 ? 0x7ffffdau : ((j & 1) ? 0x3fffffeu : 0x7fffffeu);  // + 2p: every limb positive, < 2^28
+    const uint32_t f = (uint32_t)(p10[j] + (int32_t)twop);
+    const int sh = off - lo;  // bit position of the limb relative to this lane's window
+    uint32_t v = 0;
+    if (sh >= 0 && sh < 16) v = f << sh;
+    else if (sh < 0 && sh > -28) v = f >> (-sh);
+    out += c.k == 15 ? v : (v & 0xffffu);
+  }
+  return out;
+}
+// sixteen loose limbs (< 2^18 each, all in registers) -> ten radix-2^25.5 limbs, non-negative, in the usual bounds
+__device__ __forceinline__ void to_limbs10(const uint32_t l[16], int32_t out[10]) {
+#pragma unroll
+  for (int j = 0; j < 10; j++) {
+    const int off = (51 * j + 1) / 2, nxt = (51 * (j + 1) + 1) / 2;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int b0 = 16 * k;                        // l[k] covers bits [b0, b0 + 18)
+      const int from = b0 > off ? b0 : off;         // first bit of the overlap with [off, nxt)
+      const int to = (j == 9) ? b0 + 18 : (b0 + 18 < nxt ? b0 + 18 : nxt);
+      if (to > from) {
+        uint32_t v = l[k] >> (from - b0);
+        if (to - from < 18 - (from - b0)) v &= (1u << (to - from)) - 1u;
+        acc += v << (from - off);
+      }
+    }
+    out[j] = (int32_t)acc;
+  }
+  const uint32_t top = (uint32_t)out[9] >> 25;  // 2^255 = 19
+  out[9] &= 0x1ffffff;
+  out[0] += (int32_t)(19u * top);
+}
+
+// constants as 16-bit limbs
+__device__ __forceinline__ uint32_t const_d(uint32_t k) {
+  constexpr uint16_t t[16] = {0x78a3, 0x1359, 0x4dca, 0x75eb, 0xd8ab, 0x4141, 0x0a4d, 0x0070, 0xe898, 0x7779, 0x4079, 0x8cc7, 0xfe73, 0x2b6f, 0x6cee, 0x5203};
+  return t[k];
+}
+__device__ __forceinline__ uint32_t const_sqrtm1(uint32_t k) {
+  constexpr uint16_t t[16] = {0xa0b0, 0x4a0e, 0x1b27, 0xc4ee, 0xe478, 0xad2f, 0x1806, 0x2f43, 0xd7a7, 0x3dfb, 0x0099, 0x2b4d, 0xdf0b, 0x4fc1, 0x2480, 0x2b83};
+  return t[k];
+}
+__device__ __forceinline__ uint32_t sqn(uint32_t a, int n, const Ctx& c) {
+#pragma unroll 1
+  for (int i = 0; i < n; i++) a = mul(a, a, c);
+  return a;
+}
+// z^((p-5)/8) = z^(2^252 - 3): ref10's fe_pow22523 addition chain (252 squarings, 11 multiplications)
+__device__ __forceinline__ uint32_t pow_p58(uint32_t z, const Ctx& c) {
+  uint32_t t0 = mul(z, z, c);                  // 2
+  uint32_t t1 = mul(z, sqn(t0, 2, c), c);      // 9
+  t0 = mul(t0, t1, c);                         // 11
+  t0 = mul(t1, mul(t0, t0, c), c);             // 31 = 2^5 - 1
+  t0 = mul(sqn(t0, 5, c), t0, c);              // 2^10 - 1
+  t1 = mul(sqn(t0, 10, c), t0, c);             // 2^20 - 1
+  t1 = mul(sqn(t1, 20, c), t1, c);             // 2^40 - 1
+  t0 = mul(sqn(t1, 10, c), t0, c);             // 2^50 - 1
+  t1 = mul(sqn(t0, 50, c), t0, c);             // 2^100 - 1
+  t1 = mul(sqn(t1, 100, c), t1, c);            // 2^200 - 1
+  t0 = mul(sqn(t1, 50, c), t0, c);             // 2^250 - 1
+  return mul(sqn(t0, 2, c), z, c);             // 2^252 - 3
+}
+
+}  // namespace f16
+}  // namespace tmx

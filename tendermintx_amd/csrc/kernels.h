@@ -11,6 +11,7 @@ size_t base_table_bytes(uint32_t w_bits);
 // each returns a hipError_t value (0 = success); all launches are asynchronous on `stream` (hipStream_t)
 int launch_init_base(void* d_table, uint32_t w_bits, void* stream);
 int launch_selftest_invert(uint32_t n, const void* d_in, void* d_out, void* stream);
+int launch_selftest_f16(uint32_t n, uint32_t doublings, const void* d_in, void* d_out, void* stream);
 int launch_eddsa(uint32_t n_lanes, const void* d_target, void* d_ed, uint32_t ed_stride, const void* d_table, void* stream);
 // quad-parallel EdDSA path.  Three launch groups so that api.cpp can run the key pipeline on a side stream:
 //   keys pipeline (dedup -> decode distinct keys -> optional per-key tables)  ||  phase 1 (decode R, SHA-512 mod l, s*B)
@@ -29,6 +30,8 @@ struct EdQuad {
   uint32_t key_w;    // window width of the per-key tables (4 or 6 bits)
   uint32_t key_cap;  // keys the table buffers can hold
   uint32_t mode;     // 0 never build tables, 1 automatic (>= 8 lanes per key), 2 whenever they fit
+  uint32_t keys16;   // 1: keys are decoded in the limb-parallel form when there are few enough of them
+  uint32_t anchor16; // 1: the anchor chain runs in the limb-parallel form (one wave per key), 0: one quad per key
   void* fin_done;    // event attached to the k_ed_fin dispatch as its completion signal (no separate record packet), or null
 };
 size_t quad_table_bytes(uint32_t w_bits);
@@ -44,7 +47,8 @@ int launch_ed_keys(const EdQuad& Q, void* stream, void* done = nullptr);
 int launch_ed_tab_anchor(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream, void* done = nullptr);
 int launch_ed_tab_mult(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream, void* done = nullptr);
 int launch_ed_mul_direct(const EdQuad& Q, void* stream);
-int launch_ed_phase1(const EdQuad& Q, void* stream);
+// roles: 0 = both (SHA-512 + mod l, then s*B), 1 = the hash role only, 2 = s*B only
+int launch_ed_phase1(const EdQuad& Q, void* stream, void* done = nullptr, int roles = 0);
 int launch_ed_mul_tab(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream);
 int launch_ed_fin(const EdQuad& Q, void* stream);
 int launch_proof(const ProofParams& P, uint32_t n_proofs, const void* d_proofs, const void* d_target, const void* d_trusted, void* d_lt,

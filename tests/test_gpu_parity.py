@@ -213,6 +213,56 @@ def test_synthetic_batches(tmx, oracle, kind, n, nb, permille):
     assert all(r["all_ok"] for r in reps)
 
 
+def test_limb_parallel_field_arithmetic_agrees_with_big_ints(tmx):
+    """fe16.hpp (the table chain's arithmetic: sixteen 16-bit limbs across a DPP row): products, point doublings and both conversions
+    against Python integers, at the bounds the kernels rely on."""
+    P = 2**255 - 19
+    rng = np.random.default_rng(5)
+    n, d = 64, 7
+    words = np.zeros((n, 128), dtype=np.uint32)
+    words[:, :64] = rng.integers(0, 196609, size=(n, 64))            # A: what from_limbs10 can produce (3 * 2^16)
+    words[:, 64:] = rng.integers(0, 441506, size=(n, 64))            # B: the largest limbs mul() accepts
+    words[0, :64] = 196608; words[0, 64:] = 441505                   # all-maximal
+    words[1, :64] = 0
+    # B's first 40 words double as four signed ten-limb elements for the conversion test
+    l10 = np.zeros((n, 40), dtype=np.int64)
+    for j in range(10):
+        bound = (1 << 26) - 1 if j % 2 == 0 else (1 << 25) - 1
+        l10[:, j::10] = rng.integers(-bound, bound + 1, size=(n, 4))
+    l10[2] = np.tile([(1 << 26) - 1 if j % 2 == 0 else (1 << 25) - 1 for j in range(10)], 4)
+    l10[3] = -l10[2]
+    conv_words = words.copy()
+    conv_words[:, 64:104] = l10.astype(np.int32).view(np.uint32).reshape(n, 40)
+    val16 = lambda l: sum(int(x) << (16 * k) for k, x in enumerate(l))
+    off = [(51 * j + 1) // 2 for j in range(10)]
+    val10 = lambda l: sum(int(x) << off[j] for j, x in enumerate(l))
+    ctx = tmx.Context(4, b"x", max_batch=1)
+    try:
+        out = ctx.selftest_f16(words, d)
+        out2 = ctx.selftest_f16(conv_words, 0)
+    finally:
+        ctx.close()
+    for i in range(n):
+        a = [val16(words[i, 16 * r:16 * r + 16]) for r in range(4)]
+        b = [val16(words[i, 64 + 16 * r:64 + 16 * r + 16]) for r in range(4)]
+        for r in range(4):
+            got = out[i, 16 * r:16 * r + 16]
+            assert got.max() <= 65536 + 2280 and val16(got) % P == a[r] * b[r] % P, (i, r)
+        X, Y, Z = a[0], a[1], a[2]
+        for _ in range(d):
+            xx, yy, zz, s = X * X, Y * Y, Z * Z, (X + Y) ** 2
+            h, e, g = yy + xx, s - xx - yy, yy - xx
+            f = 2 * zz - g
+            X, Y, Z, T = e * f % P, h * g % P, g * f % P, e * h % P
+        got = [val16(out[i, 64 + 16 * r:64 + 16 * r + 16]) % P for r in range(4)]
+        assert got == [X, Y, Z, T], i
+        for r in range(4):
+            t = out[i, 128 + 10 * r:128 + 10 * r + 10].astype(np.int64)
+            assert val10(t) % P == a[r] % P and all(0 <= t[j] < (1 << 27) for j in range(10)), (i, r)  # (fe_carry32 follows)
+            g16 = out2[i, 192 + 16 * r:192 + 16 * r + 16]
+            assert g16.max() < 3 << 16 and val16(g16) % P == val10(l10[i, 10 * r:10 * r + 10]) % P, (i, r)
+
+
 def test_field_inversions_agree_with_big_int_arithmetic(tmx):
     """k_ed_fin inverts with Bernstein-Yang division steps; the self-test hook returns that and the Fermat chain for caller values.
     Edge values (0, +-1, 2^k +- 1, p - small, non-canonical representatives up to 2^256 - 1, limb-boundary patterns) and 4096 random ones
@@ -438,7 +488,8 @@ def test_validator_sharded_single_proof(tmx, oracle):
 
 @pytest.mark.parametrize("knobs", [
     {"TMX_BASE_W": "4"}, {"TMX_BASE_W": "8"}, {"TMX_MUL_SPLIT": "1"}, {"TMX_KEY_W": "4"}, {"TMX_KEY_W": "4", "TMX_MUL_SPLIT": "1"}, {"TMX_WALK_PARTS": "1"}, {"TMX_WALK_PARTS": "1", "TMX_TAB_PARTS": "4"},
-    {"TMX_TAB_PARTS": "1"}, {"TMX_PROOFSER_HOLD": "1"}, {"TMX_EXT_EVENTS": "0"}, {"TMX_DEDUP": "0"}, {"TMX_DEDUP": "2"},
+    {"TMX_TAB_PARTS": "1"}, {"TMX_PROOFSER_HOLD": "1"}, {"TMX_EXT_EVENTS": "0"}, {"TMX_ANCHOR16": "0"}, {"TMX_KEYS16": "0"},
+    {"TMX_P1_SIDE": "1"}, {"TMX_P1_SIDE": "2"}, {"TMX_DEDUP": "0"}, {"TMX_DEDUP": "2"},
     {"TMX_SER_SPLIT": "0"}, {"TMX_SER_SPAN": "128"}, {"TMX_SER_SPAN": "512"}, {"TMX_EDDSA": "mono"}], ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
 def test_schedule_knobs_give_the_same_bits(tmx, oracle, monkeypatch, knobs):
     """Every tuning knob changes a schedule (window widths, table use, launch splitting, the first-generation kernel), never a value:

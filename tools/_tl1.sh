@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-P=1 WARM=5 STEPS=5 rocprofv3 --kernel-trace -d gpurun_out/tl1 -o tl -- python tools/profile_step.py > gpurun_out/tl1.log 2>&1
+P=${P:-1} WARM=5 STEPS=5 rocprofv3 --kernel-trace -d gpurun_out/tl1 -o tl -- python tools/profile_step.py > gpurun_out/tl1.log 2>&1
 python - <<'PY'
 import sqlite3, glob
 db = sqlite3.connect(glob.glob('gpurun_out/tl1/**/*.db', recursive=True)[0])
