@@ -245,7 +245,7 @@ struct tmx_ctx {
   void *d_qtable = nullptr, *d_pre = nullptr, *d_mulout = nullptr;
   void *d_hash = nullptr, *d_cnt = nullptr, *d_owner_of = nullptr, *d_uid_of_owner = nullptr, *d_owners = nullptr, *d_keyrec = nullptr,
        *d_anchors = nullptr, *d_keytab = nullptr;
-  uint32_t anchor16 = 1, keys16 = 1;
+  uint32_t anchor16 = 1, keys16 = 1, mul16 = 1;
   uint32_t p1_side = 3;
   uint32_t hash_mask = 0, key_cap = 0, dedup_mode = 1;  // TMX_DEDUP=0|1|2: never / automatic / always build per-key tables
   hipStream_t side2 = nullptr;  // distinct-key pipeline, concurrent with phase 1
@@ -412,7 +412,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   Q.d_uid_of_owner = c->d_uid_of_owner; Q.d_owners = c->d_owners; Q.d_keyrec = c->d_keyrec; Q.d_anchors = c->d_anchors; Q.d_keytab = c->d_keytab;
   Q.key_cap = c->key_cap; Q.key_w = c->key_w; Q.mode = c->dedup_mode;
   Q.fin_done = c->fin_done; c->fin_done = nullptr;
-  Q.anchor16 = c->anchor16; Q.keys16 = c->keys16;
+  Q.anchor16 = c->anchor16; Q.keys16 = c->keys16; Q.mul16 = c->mul16;
   c->last_lanes = n_lanes;
   Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * c->parity;
   Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1);
@@ -727,6 +727,8 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
       // 0: phase 1 on the caller's stream, 1: on side3 (input sections behind it), 2: its s*B role on side3; default: by batch size
       c->p1_side = p1s ? (uint32_t)(p1s[0] - '0') : 3u;
       if (c->p1_side > 3) c->p1_side = 3;
+      const char* m16 = std::getenv("TMX_MUL16");
+      c->mul16 = (m16 && m16[0] == '0') ? 0u : 1u;
       const char* k16 = std::getenv("TMX_KEYS16");
       c->keys16 = (k16 && k16[0] == '0') ? 0u : 1u;
     }

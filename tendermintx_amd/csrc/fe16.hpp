@@ -161,5 +161,38 @@ __device__ __forceinline__ uint32_t pow_p58(uint32_t z, const Ctx& c) {
   return mul(sqn(t0, 2, c), z, c);             // 2^252 - 3
 }
 
+__device__ __forceinline__ uint32_t const_2d(uint32_t k) {
+  constexpr uint16_t t[16] = {0xf159, 0x26b2, 0x9b94, 0xebd6, 0xb156, 0x8283, 0x149a, 0x00e0, 0xd130, 0xeef3, 0x80f2, 0x198e, 0xfce7, 0x56df, 0xd9dc, 0x2406};
+  return t[k];
+}
+// rows (X, Y, Z, T) -> rows (Y-X, Y+X, T, Z): the left operand of an addition's first level (limbs of P up to 3 * 2^16)
+__device__ __forceinline__ uint32_t add_left(uint32_t P, const Ctx& c) {
+  const Rows s = rows(P);
+  return row_pick(c, s.r1 + c.b4 - s.r0, s.r1 + s.r0, s.r3, s.r2);
+}
+// cached form of a point, rows (Y-X, Y+X, 2dT, Z), carried
+__device__ __forceinline__ uint32_t to_cached(uint32_t P, const Ctx& c) {
+  const uint32_t one = c.k == 0 ? 1u : 0u;
+  return mul(add_left(P, c), c.row == 2 ? const_2d(c.k) : one, c);
+}
+__device__ __forceinline__ uint32_t neg_cached(uint32_t q, const Ctx& c) {  // (Y+X, Y-X, -2dT, Z)
+  const auto p = __builtin_amdgcn_permlane16_swap(q, q, false, false);   // (r0 r0 r2 r2), (r1 r1 r3 r3)
+  return row_pick(c, p[1], p[0], c.b4 - q, q);
+}
+// ref10 ge_add: rows (X, Y, Z, T) + cached rows -> rows (X3, Y3, Z3, T3)
+__device__ __forceinline__ uint32_t add_cached(uint32_t P, uint32_t q, const Ctx& c) {
+  const Rows m = rows(mul(add_left(P, c), q, c));  // A, B, C, ZZ
+  const uint32_t E = m.r1 + c.b4 - m.r0, H = m.r1 + m.r0, zz2 = m.r3 + m.r3;
+  const uint32_t F = zz2 + c.b4 - m.r2, G = zz2 + m.r2;
+  return mul(row_pick(c, E, G, F, E), row_pick(c, F, H, G, H), c);
+}
+// rows (X, Y, Z, T) -> (X, Y, Z, X+Y), what dbl() takes
+__device__ __forceinline__ uint32_t with_xy(uint32_t Q, const Ctx& c) {
+  const auto p = __builtin_amdgcn_permlane16_swap(Q, Q, false, false);
+  const uint32_t xy = p[0] + p[1];
+  const auto t = __builtin_amdgcn_permlane32_swap(xy, xy, false, false);
+  return c.row == 3 ? t[0] : Q;
+}
+
 }  // namespace f16
 }  // namespace tmx

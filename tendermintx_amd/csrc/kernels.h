@@ -30,6 +30,7 @@ struct EdQuad {
   uint32_t key_w;    // window width of the per-key tables (4 or 6 bits)
   uint32_t key_cap;  // keys the table buffers can hold
   uint32_t mode;     // 0 never build tables, 1 automatic (>= 8 lanes per key), 2 whenever they fit
+  uint32_t mul16;    // 1: h*A of small launches without tables in the limb-parallel form (one wave per lane)
   uint32_t keys16;   // 1: keys are decoded in the limb-parallel form when there are few enough of them
   uint32_t anchor16; // 1: the anchor chain runs in the limb-parallel form (one wave per key), 0: one quad per key
   void* fin_done;    // event attached to the k_ed_fin dispatch as its completion signal (no separate record packet), or null
