@@ -436,7 +436,8 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   if (!x && (e = hipEventRecord(c->ev_keys, c->side2)) != hipSuccess) return (int)e;
   // The anchor chain is cut into `parts` launches on side2; the cached multiples of part p are built on s (idle once phase 1 is
   // done) while side2 doubles part p+1, so that only the multiples of the last part follow the chain.
-  const uint32_t parts = c->tab_parts;
+  // (small launches: one part -- nothing to overlap, and without tables every part is one more empty launch on s)
+  const uint32_t parts = n_lanes <= 2048 ? 1u : c->tab_parts;
   for (uint32_t p = 0; p < parts; p++) {
     const bool last = p + 1 == parts;
     rc = launch_ed_tab_anchor(Q, p, parts, c->side2, xt && !last ? c->ev_part[p] : nullptr);

@@ -16,7 +16,8 @@ constexpr uint32_t F16_C = 65536 + 2280;
 
 template <int S>
 __device__ __forceinline__ uint32_t ror(uint32_t v) {  // lane k of a row <- lane (k - S) mod 16
-  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x120 + S, 0xf, 0xf, false);
+  // (update_dpp with a zero "old": the form the compiler folds into the consuming v_mul_u32_u24 as a DPP operand)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + S, 0xf, 0xf, false);
 }
 template <int S>
 __device__ __forceinline__ uint32_t bcast(uint32_t v) {  // every lane of a row <- lane S (row_newbcast)
@@ -71,7 +72,11 @@ __device__ __forceinline__ Rows rows(uint32_t v) {
   return {e[0], o[0], e[1], o[1]};
 }
 __device__ __forceinline__ uint32_t row_pick(const Ctx& c, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
-  return c.row == 0 ? v0 : (c.row == 1 ? v1 : (c.row == 2 ? v2 : v3));
+  uint32_t r = v0;  // (three selects on values that already exist: no branches)
+  r = c.row == 1 ? v1 : r;
+  r = c.row == 2 ? v2 : r;
+  r = c.row == 3 ? v3 : r;
+  return r;
 }
 
 // Point doubling on rows (X, Y, Z, X+Y) -> Q = rows (X3, Y3, Z3, T3) and the next (X3, Y3, Z3, X3+Y3); ref10's ge_p2_dbl + p1p1
