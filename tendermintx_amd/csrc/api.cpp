@@ -320,13 +320,19 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // side3: the sections that are a pure expansion of the input records (42 % of a skip row) -- HBM is idle while EdDSA runs
   // (with phase 1 on side3 these launches are enqueued behind it, after the EdDSA producer)
   int32_t st0 = TMX_OK;
+  // (TMX_INPUTS_ON=side2 puts them behind the key chain on the high-priority stream instead.  At 1024 proofs the low-priority launch
+  // is starved -- it runs from 0 to 1.8 ms and ends the step -- but the step is VALU-bound there (the serializer is 21 % of all VALU
+  // instructions) and the high-priority placement only moves the time around: 1.894 vs 1.895 ms; at 256 proofs it costs 8 %.)
+  const char* ion = std::getenv("TMX_INPUTS_ON");
+  const bool inputs_hi = c->quad && c->ser_split && ion && ion[0] == 's' && ion[4] == '2';
+  hipStream_t in_stream = inputs_hi ? c->side2 : c->side3;
   auto inputs_on_side3 = [&]() -> int32_t {
-    const int32_t r = c->ser_split ? serialize(prog.mask_inputs, c->side3) : TMX_OK;
+    const int32_t r = c->ser_split ? serialize(prog.mask_inputs, in_stream) : TMX_OK;
     if (r) return r;
-    HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
+    HIPCK(c, hipEventRecord(c->ev_join3, in_stream));
     return TMX_OK;
   };
-  const bool inputs_late = c->p1_side == 1 && c->quad;
+  const bool inputs_late = (c->p1_side == 1 || inputs_hi) && c->quad;
   if (!inputs_late && (st0 = inputs_on_side3())) return st0;
   // side: k_proof, then the sections that only need its results
   HIPCK(c, hipEventRecord(evs[0], c->side));
@@ -454,7 +460,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   // table multiples of the first part, which then start when phase 1 ends instead of when their anchors are ready.
   // (measured at 256 / 1024 proofs x 128: mode 1 +3 % / +8 % step time, mode 2 +0.7 % / -1.3 %: the walk starts 55 us earlier but shares
   // the SIMDs with s*B -- the span is VALU-throughput-bound either way)
-  const uint32_t p1_side = c->p1_side == 3 ? (n_lanes >= 131072 ? 2u : 0u) : c->p1_side;
+  const uint32_t p1_side = c->p1_side == 3 ? 0u : c->p1_side;
   bool wait_p1_late = false;
   if (p1_side == 1) {
     if ((e = hipStreamWaitEvent(c->side3, c->ev_fork2, 0)) != hipSuccess) return (int)e;
@@ -480,7 +486,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   // The table walk can follow the table build part by part (partial sums in mulout).  Measured: +4 % step time at 256-512 proofs (the
   // parts sit on the caller's normal-priority queue beside the chain), -2.7 % at 1024, where the walk dominates -> by batch size.
   const char* wp = std::getenv("TMX_WALK_PARTS");
-  const bool walk_parts = wp ? wp[0] == '1' : n_lanes >= 131072;
+  const bool walk_parts = wp ? wp[0] == '1' : n_lanes >= 65536;
   for (uint32_t p = 0; p < parts; p++) {
     if ((e = hipStreamWaitEvent(s, c->ev_part[p], 0)) != hipSuccess) return (int)e;
     if (p + 1 < parts) {
@@ -567,7 +573,9 @@ hipError_t acquire_streams(int device, DeviceStreams** out) {
     if (const char* sp = std::getenv("TMX_SIDE_PRIO")) prio_side = sp[0] == 'h' ? prio_high : (sp[0] == 'l' ? prio_low : prio_side);
     if ((e = hipStreamCreateWithPriority(&d.side, hipStreamNonBlocking, prio_side)) != hipSuccess) return e;
     if ((e = hipStreamCreateWithPriority(&d.side2, hipStreamNonBlocking, prio_high)) != hipSuccess) return e;
-    if ((e = hipStreamCreateWithPriority(&d.side3, hipStreamNonBlocking, prio_low)) != hipSuccess) return e;
+    int prio_side3 = prio_low;
+    if (const char* sp = std::getenv("TMX_SIDE3_PRIO")) prio_side3 = sp[0] == 'h' ? prio_high : (sp[0] == 'n' ? (prio_low + prio_high) / 2 : prio_low);
+    if ((e = hipStreamCreateWithPriority(&d.side3, hipStreamNonBlocking, prio_side3)) != hipSuccess) return e;
   }
   d.refs++;
   *out = &d;

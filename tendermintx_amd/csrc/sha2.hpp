@@ -85,6 +85,33 @@ __device__ __forceinline__ void sha256_short(GetByte get, uint32_t len, uint32_t
   }
 }
 
+// RFC-6962 leaf of a short field held in registers: SHA-256(0x00 || first len bytes of f), f = up to 80 bytes as 20 little-endian
+// words whose bytes from the end of the data on are zero; len <= 79.  Fully unrolled, register-indexed only.
+__device__ __forceinline__ void sha256_leaf80(const uint32_t f[20], uint32_t len, uint32_t dig[8]) {
+  const uint32_t p = len + 1;  // position of the 0x80 marker in the message 00 | data
+  uint32_t m[32];
+#pragma unroll
+  for (int j = 0; j < 32; j++) {
+    const uint32_t prev = (j >= 1 && j <= 20) ? f[j - 1] & 0xff000000u : 0u;
+    const uint32_t cur = j < 20 ? __builtin_bswap32(f[j]) >> 8 : 0u;
+    m[j] = prev | cur;
+    m[j] |= ((uint32_t)j == (p >> 2)) ? (0x80u << (24 - 8 * (p & 3))) : 0u;
+  }
+  const bool two = p + 9 > 64;
+  sha256_init(dig);
+  uint32_t w[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) w[k] = m[k];
+  if (!two) w[15] = p * 8;
+  sha256_compress(dig, w);
+  if (two) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = m[16 + k];
+    w[15] = p * 8;
+    sha256_compress(dig, w);
+  }
+}
+
 // RFC-6962 inner node: SHA-256(0x01 || L || R), L and R as eight big-endian words each (65 bytes, 2 blocks)
 __device__ __forceinline__ void sha256_inner(const uint32_t l[8], const uint32_t r[8], uint32_t dig[8]) {
   uint32_t w[16];
