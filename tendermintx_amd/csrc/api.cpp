@@ -366,10 +366,11 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   const bool tail_aside = c->ser_split && (uint64_t)n_proofs * n >= 4096;
   if (c->ser_split && !tail_aside) {
     HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
-    HIPCK(c, hipEventRecord(evs[2], s));
-    rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, s);
+    const bool xv = c->ext_events && n_proofs != 0;  // the verdict's two timing events ride on its dispatch
+    if (!xv) HIPCK(c, hipEventRecord(evs[2], s));
+    rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, s, xv ? evs[2] : nullptr, xv ? evs[3] : nullptr);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
-    HIPCK(c, hipEventRecord(evs[3], s));
+    if (!xv) HIPCK(c, hipEventRecord(evs[3], s));
     if ((st0 = serialize(prog.mask_final | prog.mask_tail, s))) return st0;
     HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
   } else if (c->ser_split) {

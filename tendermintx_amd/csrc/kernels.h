@@ -56,7 +56,8 @@ int launch_proof(const ProofParams& P, uint32_t n_proofs, const void* d_proofs, 
                  uint32_t lt_stride, void* d_lr, void* d_pf, void* d_nodes_t, void* d_nodes_r, void* d_reports, void* stream);
 int launch_valid_skip(uint32_t n_cand, uint32_t n_max, const void* d_start, uint32_t n_start, const void* d_targets, const void* d_nt, const void* d_sigs,
                       const void* d_ns, void* d_valid, void* d_shared, void* d_total, void* stream);
-int launch_verdict(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_ed, uint32_t ed_stride, void* d_pf, void* d_reports, void* stream);
+int launch_verdict(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_ed, uint32_t ed_stride, void* d_pf, void* d_reports, void* stream,
+                   void* started = nullptr, void* done = nullptr);
 // sec_mask: bit s = section s, bit 31 = waves straddling a section boundary / the row end
 int launch_serialize(const SerializeProgram& S, const SerializeSources& src, const void* d_lut, const void* d_wave_sec, const void* d_seam_waves,
                      uint32_t n_seams, uint32_t n_proofs, void* d_out, uint32_t sec_mask, void* stream);
