@@ -507,6 +507,26 @@ def test_schedule_knobs_give_the_same_bits(tmx, oracle, monkeypatch, knobs):
     assert reps[0]["first_bad_sig"] == lane and not reps[0]["all_ok"] and all(r["first_bad_sig"] == -1 for r in reps[1:])
 
 
+def test_many_distinct_keys_take_the_throughput_forms(tmx, oracle):
+    """More than 8192 distinct keys in one launch: k_ed_keys decodes one key per thread and h*A runs in the quad form (the
+    limb-parallel forms are for the few-keys / few-lanes chains).  Random 32-byte strings as keys (about half decode), random signatures:
+    every lane's record against the oracle's trace of the same triple."""
+    rng = np.random.default_rng(77)
+    n_lanes = 8192 + 320
+    pks = rng.integers(0, 256, (n_lanes, 32), dtype=np.uint8)
+    sigs = rng.integers(0, 256, (n_lanes, 64), dtype=np.uint8)
+    sigs[:, 63] &= 0x0f                                               # s < 2^252: canonical, so the lanes are not all rejected early
+    msgs = rng.integers(0, 256, (n_lanes, 60), dtype=np.uint8)
+    lanes = b"".join(_lane(pks[i].tobytes(), sigs[i].tobytes(), msgs[i].tobytes()) for i in range(n_lanes))
+    with tmx.Context(128, b"celestia", max_batch=(n_lanes + 127) // 128) as ctx:
+        got = ctx.eddsa_lanes(lanes)
+        uniq, tables = ctx.last_dedup()
+    assert uniq == n_lanes and not tables
+    for i in list(range(0, n_lanes, 37)) + [n_lanes - 1]:
+        want = _ed_record(oracle.eddsa_trace(pks[i].tobytes(), sigs[i].tobytes(), msgs[i].tobytes()))
+        assert bytes(got[i]) == want, f"lane {i}"
+
+
 def test_key_dedup_paths(tmx, oracle):
     if os.environ.get("TMX_EDDSA") == "mono":
         pytest.skip("the first-generation kernel has no key deduplication")
