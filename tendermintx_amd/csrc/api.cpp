@@ -246,6 +246,7 @@ struct tmx_ctx {
   void *d_hash = nullptr, *d_cnt = nullptr, *d_owner_of = nullptr, *d_uid_of_owner = nullptr, *d_owners = nullptr, *d_keyrec = nullptr,
        *d_anchors = nullptr, *d_keytab = nullptr;
   uint32_t anchor16 = 1, keys16 = 1, mul16 = 1;
+  bool last_tiny = false;
   uint32_t p1_side = 3;
   uint32_t hash_mask = 0, key_cap = 0, dedup_mode = 1;  // TMX_DEDUP=0|1|2: never / automatic / always build per-key tables
   hipStream_t side2 = nullptr;  // distinct-key pipeline, concurrent with phase 1
@@ -423,8 +424,31 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   c->last_lanes = n_lanes;
   Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * c->parity;
   Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1);
-  c->parity ^= 1;
   hipError_t e;
+  // Tiny launches (a single proof, up to 512 lanes): tables never pay there (measured: direct h*A wins up to ~6 proofs x 128) and the
+  // dedup kernel, its hop to side2 and the empty table launches are 30 us of a 0.31 ms step.  Every lane is its own key: k_ed_keys starts
+  // at once on side2 (it writes the identity maps itself), phase 1 on s, then h*A one wave per lane and the finish.  TMX_TINY=0: off.
+  {
+    const char* tn = std::getenv("TMX_TINY");
+    c->last_tiny = n_lanes != 0 && n_lanes <= 512 && c->keys16 && c->mul16 && !(tn && tn[0] == '0');
+  }
+  if (c->last_tiny) {
+    Q.mode = 0;
+    if ((e = hipEventRecord(c->ev_fork2, s)) != hipSuccess) return (int)e;
+    if ((e = hipStreamWaitEvent(c->side2, c->ev_fork2, 0)) != hipSuccess) return (int)e;
+    int rc = launch_ed_keys(Q, c->side2, c->ext_events ? c->ev_keys : nullptr, n_lanes);
+    if (rc) return rc;
+    if (!c->ext_events && (e = hipEventRecord(c->ev_keys, c->side2)) != hipSuccess) return (int)e;
+    rc = launch_ed_phase1(Q, s);
+    if (rc) return rc;
+    if ((e = hipStreamWaitEvent(s, c->ev_keys, 0)) != hipSuccess) return (int)e;
+    rc = launch_ed_mul_direct(Q, s);
+    if (rc) return rc;
+    rc = launch_ed_fin(Q, s);
+    c->fin_done_attached = rc == 0 && Q.fin_done != nullptr;
+    return rc;
+  }
+  c->parity ^= 1;
   // dedup on s, then the distinct-key pipeline (decode -> anchors -> table: a latency chain of a few waves) on the high-priority
   // stream side2 beside phase 1 on s; both join before h*A.  (Queue priority also decides which waves issue first on a shared
   // SIMD: with the chain on a normal-priority queue k_ed_keys alone takes 230 us instead of 100.)
@@ -768,6 +792,7 @@ int32_t tmx_last_dedup(tmx_ctx* c, uint32_t* n_unique, uint32_t* used_tables) {
   if (!c || !n_unique || !used_tables) return TMX_ERR_BAD_ARG;
   *n_unique = 0; *used_tables = 0;
   if (!c->quad || !c->d_cnt) return TMX_OK;
+  if (c->last_tiny) { *n_unique = c->last_lanes; return TMX_OK; }  // no deduplication in a tiny launch: every lane its own key
   HIPCK(c, hipDeviceSynchronize());
   uint32_t v = 0;
   HIPCK(c, hipMemcpy(&v, reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1), 4, hipMemcpyDeviceToHost));

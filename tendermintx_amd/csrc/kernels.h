@@ -44,7 +44,8 @@ size_t keytab_bytes_per_key(uint32_t key_w);
 int launch_init_base_quad(const void* d_table, void* d_qtable, uint32_t w_bits, void* stream);
 // (`done`: an event signalled by the dispatch itself when the kernel completes -- saves the record packet behind it; may be null)
 int launch_ed_dedup(const EdQuad& Q, void* stream, void* done = nullptr);
-int launch_ed_keys(const EdQuad& Q, void* stream, void* done = nullptr);
+// direct_n != 0: no dedup ran, lanes 0 .. direct_n-1 are their own keys (limb-parallel form only: direct_n <= 8192, Q.keys16 set)
+int launch_ed_keys(const EdQuad& Q, void* stream, void* done = nullptr, uint32_t direct_n = 0);
 int launch_ed_tab_anchor(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream, void* done = nullptr);
 int launch_ed_tab_mult(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream, void* done = nullptr);
 int launch_ed_mul_direct(const EdQuad& Q, void* stream);

@@ -487,7 +487,7 @@ def test_validator_sharded_single_proof(tmx, oracle):
 
 
 @pytest.mark.parametrize("knobs", [
-    {"TMX_BASE_W": "4"}, {"TMX_BASE_W": "8"}, {"TMX_MUL_SPLIT": "1"}, {"TMX_MUL_SPLIT": "4"}, {"TMX_KEY_W": "4"}, {"TMX_KEY_W": "4", "TMX_MUL_SPLIT": "1"}, {"TMX_WALK_PARTS": "1"}, {"TMX_WALK_PARTS": "1", "TMX_TAB_PARTS": "4"},
+    {"TMX_BASE_W": "4"}, {"TMX_BASE_W": "8"}, {"TMX_MUL_SPLIT": "1"}, {"TMX_MUL_SPLIT": "4"}, {"TMX_TINY": "0"}, {"TMX_KEY_W": "4"}, {"TMX_KEY_W": "4", "TMX_MUL_SPLIT": "1"}, {"TMX_WALK_PARTS": "1"}, {"TMX_WALK_PARTS": "1", "TMX_TAB_PARTS": "4"},
     {"TMX_TAB_PARTS": "1"}, {"TMX_PROOFSER_HOLD": "1"}, {"TMX_EXT_EVENTS": "0"}, {"TMX_ANCHOR16": "0"}, {"TMX_KEYS16": "0"}, {"TMX_MUL16": "0"},
     {"TMX_P1_SIDE": "1"}, {"TMX_P1_SIDE": "2"}, {"TMX_DEDUP": "0"}, {"TMX_DEDUP": "2"},
     {"TMX_SER_SPLIT": "0"}, {"TMX_SER_SPAN": "128"}, {"TMX_SER_SPAN": "512"}, {"TMX_EDDSA": "mono"}], ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
@@ -539,14 +539,14 @@ def test_key_dedup_paths(tmx, oracle):
     def cat(wls):
         return b"".join(w.proofs for w in wls), b"".join(w.targets for w in wls), b"".join(w.trusteds for w in wls)
 
-    same = Workload(0, n, 24, 16, chain_id=b"celestia", seed=1, signed_permille=1000)
+    same = Workload(0, n, 40, 16, chain_id=b"celestia", seed=1, signed_permille=1000)  # 640 lanes (launches of <= 512 lanes skip the dedup)
     distinct = [Workload(0, n, 1, 16, chain_id=b"celestia", seed=100 + i, signed_permille=1000) for i in range(24)]
     mixed = [Workload(0, n, 12, 16, chain_id=b"celestia", seed=7, signed_permille=900)] + distinct[:6]
-    with tmx.Context(n, b"celestia", max_batch=24) as ctx:
+    with tmx.Context(n, b"celestia", max_batch=40) as ctx:
         _, reps = _check_vs_oracle(tmx, oracle, 0, n, same.proofs, same.targets, same.trusteds, b"celestia", ctx=ctx)
         assert all(r["all_ok"] for r in reps)
         uniq, tables = ctx.last_dedup()
-        assert uniq == 16 and tables                      # 384 lanes, 16 keys
+        assert uniq == 16 and tables                      # 640 lanes, 16 keys
         p, t, r = cat(distinct)
         _, reps = _check_vs_oracle(tmx, oracle, 0, n, p, t, r, b"celestia", ctx=ctx)
         assert all(x["all_ok"] for x in reps)
