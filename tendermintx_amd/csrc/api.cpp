@@ -442,9 +442,12 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     rc = launch_ed_phase1(Q, s);
     if (rc) return rc;
     if ((e = hipStreamWaitEvent(s, c->ev_keys, 0)) != hipSuccess) return (int)e;
-    rc = launch_ed_mul_direct(Q, s);
+    const char* ff = std::getenv("TMX_FUSE_FIN");
+    // (up to 256 lanes: at 512 the 512 waves of the fused kernel slow k_proof, the longer of the two there, by more than they save)
+    const bool fuse = ff ? ff[0] != '0' : n_lanes <= 256;
+    rc = launch_ed_mul_direct(Q, s, fuse);
     if (rc) return rc;
-    rc = launch_ed_fin(Q, s);
+    if (!fuse) rc = launch_ed_fin(Q, s);
     c->fin_done_attached = rc == 0 && Q.fin_done != nullptr;
     return rc;
   }

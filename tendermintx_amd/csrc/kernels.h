@@ -48,7 +48,8 @@ int launch_ed_dedup(const EdQuad& Q, void* stream, void* done = nullptr);
 int launch_ed_keys(const EdQuad& Q, void* stream, void* done = nullptr, uint32_t direct_n = 0);
 int launch_ed_tab_anchor(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream, void* done = nullptr);
 int launch_ed_tab_mult(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream, void* done = nullptr);
-int launch_ed_mul_direct(const EdQuad& Q, void* stream);
+// fuse_fin (launches of <= MUL16_MAX_LANES lanes with Q.mul16 only): k_ed_fin's work in the same kernel, Q.fin_done on its dispatch
+int launch_ed_mul_direct(const EdQuad& Q, void* stream, bool fuse_fin = false);
 // roles: 0 = both (SHA-512 + mod l, then s*B), 1 = the hash role only, 2 = s*B only
 int launch_ed_phase1(const EdQuad& Q, void* stream, void* done = nullptr, int roles = 0);
 int launch_ed_mul_tab(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream);
