@@ -69,11 +69,47 @@ __device__ __forceinline__ uint64_t twiddle(const uint64_t* __restrict__ W, uint
   return idx < half ? W[idx] : gl_neg(W[idx - half]);
 }
 
+// LDS index with one pad element per 16: the last stage group reads 16 consecutive elements per thread (stride 128 B between threads,
+// a 32-way bank conflict without the skew)
+__device__ __forceinline__ uint32_t lds_pad(uint32_t i) { return i + (i >> 4); }
+
+// R consecutive radix-2 DIF stages (lengths 2^ll .. 2^(ll-R+1)) on 2^R elements per thread held in registers: one LDS round trip and
+// one barrier per group instead of per stage
+template <int R>
+__device__ __forceinline__ void ntt_stage_group(uint64_t* __restrict__ s, const uint64_t* __restrict__ tw, uint32_t log_l, uint32_t ll,
+                                                uint32_t tile) {
+  constexpr int E = 1 << R;
+  const uint32_t sh = ll - R, n_blocks = tile >> R;
+  for (uint32_t b = threadIdx.x; b < n_blocks; b += blockDim.x) {
+    const uint32_t low = b & ((1u << sh) - 1u), base = ((b >> sh) << ll) | low;  // the thread's elements: base + (k << sh)
+    uint64_t x[E];
+#pragma unroll
+    for (int k = 0; k < E; k++) x[k] = s[lds_pad(base + ((uint32_t)k << sh))];
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+      const int hb = R - 1 - st;            // the bit of k that this stage pairs
+      const uint32_t wsh = log_l - (ll - st);  // twiddle index = (index mod half) << wsh
+#pragma unroll
+      for (int k = 0; k < E; k++) {
+        if (k & (1 << hb)) continue;
+        const int k2 = k | (1 << hb);
+        const uint32_t pos = low + ((uint32_t)(k & ((1 << hb) - 1)) << sh);
+        const uint64_t w = tw[pos << wsh];
+        const uint64_t a = x[k], c = x[k2];
+        x[k] = gl_add(a, c);
+        x[k2] = gl_mul(gl_sub(a, c), w);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < E; k++) s[lds_pad(base + ((uint32_t)k << sh))] = x[k];
+  }
+}
+
 __global__ __launch_bounds__(256) void k_ntt_tile(NttPass P, const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
                                                   const uint64_t* __restrict__ W) {
   extern __shared__ uint64_t s[];
   const uint32_t L = 1u << P.log_l, T = 1u << P.log_t, tile = L * T;
-  uint64_t* tw = s + tile;  // omega_L^j, j < L/2: every stage twiddle of the tile (omega_len^pos = omega_L^(pos L / len))
+  uint64_t* tw = s + lds_pad(tile) + 1;  // (behind the padded tile) omega_L^j, j < L/2: every stage twiddle of the tile (omega_len^pos = omega_L^(pos L / len))
   const uint32_t col = blockIdx.x / P.tiles_per_col, tix = blockIdx.x % P.tiles_per_col;
   const uint64_t t0 = (uint64_t)tix * T;  // first sub-transform of this tile within the column
   const uint64_t* src = in + (size_t)col * P.col_stride_in;
@@ -85,41 +121,17 @@ __global__ __launch_bounds__(256) void k_ntt_tile(NttPass P, const uint64_t* __r
     uint32_t t, j;
     if (P.j_stride_in == 1) { j = e & (L - 1); t = e >> P.log_l; } else { t = e & (T - 1); j = e >> P.log_t; }
     const bool live = t0 + t < P.n_sub;
-    s[t * L + j] = live ? gl_canon(src[(t0 + t) * P.t_stride_in + (uint64_t)j * P.j_stride_in]) : 0;
+    s[lds_pad(t * L + j)] = live ? gl_canon(src[(t0 + t) * P.t_stride_in + (uint64_t)j * P.j_stride_in]) : 0;
   }
   __syncthreads();
-  // decimation in frequency: natural order in, bit-reversed order out
-  for (uint32_t ll = P.log_l; ll >= 1; ll--) {
-    const uint32_t half = 1u << (ll - 1);
-    auto indices = [&](uint32_t b, uint32_t& i0, uint32_t& wi) {
-      const uint32_t t = b >> (P.log_l - 1), r = b & ((L >> 1) - 1);
-      const uint32_t pos = r & (half - 1), grp = r >> (ll - 1);
-      i0 = t * L + (grp << ll) + pos;
-      wi = pos << (P.log_l - ll);
-    };
-    if (tile == 4096 && blockDim.x == 256) {  // full tile: 8 butterflies per thread, all LDS reads of a stage issued together
-      uint64_t x[8], y[8], w[8];
-      uint32_t i0[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        uint32_t wi;
-        indices(threadIdx.x + 256 * u, i0[u], wi);
-        x[u] = s[i0[u]]; y[u] = s[i0[u] + half]; w[u] = tw[wi];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        s[i0[u]] = gl_add(x[u], y[u]);
-        s[i0[u] + half] = gl_mul(gl_sub(x[u], y[u]), w[u]);
-      }
-    } else {
-      for (uint32_t b = threadIdx.x; b < tile / 2; b += blockDim.x) {
-        uint32_t i0, wi;
-        indices(b, i0, wi);
-        const uint64_t x = s[i0], y = s[i0 + half];
-        s[i0] = gl_add(x, y);
-        s[i0 + half] = gl_mul(gl_sub(x, y), tw[wi]);
-      }
-    }
+  // decimation in frequency: natural order in, bit-reversed order out; four stages per LDS round trip, the remainder in one group
+  for (uint32_t ll = P.log_l; ll >= 1;) {
+    const uint32_t r = ll >= 4 ? 4u : ll;
+    if (r == 4) ntt_stage_group<4>(s, tw, P.log_l, ll, tile);
+    else if (r == 3) ntt_stage_group<3>(s, tw, P.log_l, ll, tile);
+    else if (r == 2) ntt_stage_group<2>(s, tw, P.log_l, ll, tile);
+    else ntt_stage_group<1>(s, tw, P.log_l, ll, tile);
+    ll -= r;
     __syncthreads();
   }
   // store (output index k of a sub-transform sits at bitrev(k)), with the four-step twiddle / the inverse scale
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(256) void k_ntt_tile(NttPass P, const uint64_t* __r
     if (P.j_stride_out == 1) { k = e & (L - 1); t = e >> P.log_l; } else { t = e & (T - 1); k = e >> P.log_t; }
     if (t0 + t >= P.n_sub) continue;
     const uint32_t kr = P.log_l ? (__brev(k) >> (32 - P.log_l)) : 0u;
-    uint64_t v = s[t * L + kr];
+    uint64_t v = s[lds_pad(t * L + kr)];
     if (P.post_twiddle) v = gl_mul(v, twiddle(W, P.log_n, (t0 + t) * (uint64_t)k, inv));  // omega_N^(n2 k1)
     if (P.scale != 1) v = gl_mul(v, P.scale);
     dst[(t0 + t) * P.t_stride_out + (uint64_t)k * P.j_stride_out] = v;
@@ -151,7 +163,8 @@ int launch_ntt_table(void* d_w, uint32_t log_n, void* stream) {
   return (int)hipGetLastError();
 }
 int launch_ntt_pass(const NttPass& P, uint32_t n_cols, const void* d_in, void* d_out, const void* d_w, void* stream) {
-  const size_t lds = (((size_t)8 << P.log_l) << P.log_t) + ((size_t)8 << P.log_l) / 2;
+  const size_t tile = ((size_t)1 << P.log_l) << P.log_t;
+  const size_t lds = 8 * (tile + (tile >> 4) + 1) + ((size_t)8 << P.log_l) / 2;  // padded tile (lds_pad) + the stage twiddles
   hipLaunchKernelGGL(k_ntt_tile, dim3(n_cols * P.tiles_per_col), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), P,
                      reinterpret_cast<const uint64_t*>(d_in), reinterpret_cast<uint64_t*>(d_out), reinterpret_cast<const uint64_t*>(d_w));
   return (int)hipGetLastError();
