@@ -104,7 +104,11 @@ typedef struct {
   uint32_t gt_target;    /* signed power * 3 > total * 2   (verify.rs:289-303) */
   uint32_t gt_trusted;   /* matched power * 3 > total * 1  (verify.rs:428-436), skip only */
   uint32_t dist_ok;      /* verify_skip_distance (verify.rs:508-526), skip only */
-  uint32_t reserved[2];
+  uint32_t precond;      /* host preconditions of the reference that the circuit itself does not assert: bit 0 nb_a > n_max,
+                            bit 1 nb_b > n_max (input/mod.rs:439-444, 338-342 panic there; in-circuit `idx == nb` never fires and
+                            every lane counts as enabled).  The host entry points refuse such input with TMX_ERR_SET_TOO_LARGE; the
+                            device entry points cannot look at device memory before enqueueing and report it here instead. */
+  uint32_t reserved;
 } tmx_report;
 
 typedef struct {

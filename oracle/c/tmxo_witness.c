@@ -158,8 +158,8 @@ static uint64_t height_from_leaf(const uint8_t* leaf, int len) {
 #define DR 630
 #define PROOF_D 1280
 size_t tmxo_elem_count(int kind, size_t n) {
-  if (kind == TMXO_KIND_SKIP) return 1776 * n + 5320 + n * DT + n * DR + 2 * tmxo_tree_nodes(n) * 256 + (4 * PROOF_D + 88) + 33;
-  return 1517 * n + 6919 + n * DT + tmxo_tree_nodes(n) * 256 + (5 * PROOF_D + 88) + 24;
+  if (kind == TMXO_KIND_SKIP) return 1776 * n + 5320 + n * DT + n * DR + 2 * tmxo_tree_nodes(n) * 256 + (4 * PROOF_D + 88) + 34;
+  return 1517 * n + 6919 + n * DT + tmxo_tree_nodes(n) * 256 + (5 * PROOF_D + 88) + 25;
 }
 
 int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8_t* rrec, uint32_t n,
@@ -220,6 +220,10 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
   uint8_t* leaves = (uint8_t*)malloc(32 * n); uint8_t* nodes = (uint8_t*)malloc(32 * (tmxo_tree_nodes(n) + 1));
   int no_overflow = 1, varint_ok = 1;
   for (uint32_t i = 0; i < n; i++) { const uint8_t* v = trec + (size_t)TMXO_REC_VALIDATOR * i; powers[i] = rd64(v + 224); signedv[i] = v[223] & TMXO_FLAG_SIGNED; if (powers[i] >> 63) varint_ok = 0; }
+  if (height_a >> 63) varint_ok = 0;   /* verify_block_height marshals height_proof.height through the same varint gadget (shared.rs:178, :80) */
+  /* verify_non_negative_round (validator.rs:73-78), asserted once per lane inside verify_validator_signature_data (:141) on the
+   * proof-wide round whether or not the lane signed: bit 7 of the most significant byte of LE64(round) must be 0 */
+  const int round_nonneg = (round >> 63) == 0;
   uint64_t scal_t[4], scal_r[4] = {0, 0, 0, 0};
   int gt_t = tmxo_tally(powers, n, nb, signedv, 2, 3, totp, accp, scal_t, &no_overflow), gt_r = 0;
   int all_eddsa = 1, all_sigdata = 1; int32_t first_bad = -1;
@@ -280,12 +284,17 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
   if (kind == TMXO_KIND_SKIP) e_bytes(&E, nodes_r, 32 * tn);
 
   uint8_t n_cid[4][32], n_h[4][32], n_v[4][32], n_x[4][32], n_y[4][32], hl[96] = {0}, hlh[32], vlh[32], xlh[32], ylh[32];
-  proof_walk(ha.lh[1], 1, a_cid, n_cid);                                  /* verify.rs:189-209 */
+  /* verify.rs:189-202: SHA-256 over 1 + enc_len bytes of 00 | chain_id[52] | zeros, where chain_id is the encoded field resized to
+   * 52 bytes (input/mod.rs:476-478 -- a longer field is truncated there, and its leaf is then not the header's) */
+  uint8_t cid_ext[81] = {0}, cid_lh[32];
+  memcpy(cid_ext + 1, ha.leaf[1], ha.len[1] < 52 ? ha.len[1] : 52);
+  tmxo_sha256(cid_ext, (size_t)(ha.len[1] > 79 ? 79 : ha.len[1]) + 1, cid_lh);
+  proof_walk(cid_lh, 1, a_cid, n_cid);                                    /* verify.rs:203-209 */
   hl[0] = 0x00; hl[1] = 0x08; tmxo_varint9(height_a, hl + 2);             /* shared.rs:158-167 */
   tmxo_leaf_hash(hl + 1, ha.len[2] > 79 ? 79 : ha.len[2], hlh);                                  /* shared.rs:183-194: 1 + enc_len bytes */
   proof_walk(hlh, 2, a_h, n_h);
   tmxo_leaf_hash(leaf34, 34, vlh); proof_walk(vlh, 7, a_v, n_v);
-  emit_proof_d(&E, ha.lh[1], n_cid);
+  emit_proof_d(&E, cid_lh, n_cid);
   e_bytes(&E, hl, 11); emit_proof_d(&E, hlh, n_h);
   emit_proof_d(&E, vlh, n_v);
   uint8_t cid52[52] = {0}; memcpy(cid52, ha.leaf[1], ha.len[1] < 52 ? ha.len[1] : 52);
@@ -309,6 +318,7 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
     checks[nchk++] = memcmp(n_h[3], header, 32) == 0;       /* shared.rs:197-203 */
     checks[nchk++] = height_a == expected_height;           /* shared.rs:206 */
     checks[nchk++] = all_sigdata; checks[nchk++] = all_eddsa; checks[nchk++] = no_overflow; checks[nchk++] = varint_ok;
+    checks[nchk++] = round_nonneg;                          /* validator.rs:73-78 */
     for (int k = 0; k < nchk; k++) { e_bool(&E, checks[k]); all_ok = all_ok && checks[k]; }
     all_ok = all_ok && gt_t && gt_r && dist_gt && dist_le;
     e_bool(&E, all_ok);
@@ -331,6 +341,7 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
     checks[nchk++] = memcmp(leaf72 + 2, pub_hash, 32) == 0; /* verify.rs:150-153 */
     checks[nchk++] = memcmp(n_y[3], pub_hash, 32) == 0;     /* verify.rs:166-170 */
     checks[nchk++] = memcmp(leaf34 + 2, leafb + 2, 32) == 0;/* verify.rs:173-177 */
+    checks[nchk++] = round_nonneg;                          /* validator.rs:73-78 */
     for (int k = 0; k < nchk; k++) { e_bool(&E, checks[k]); all_ok = all_ok && checks[k]; }
     all_ok = all_ok && gt_t;
     e_bool(&E, all_ok);
@@ -341,7 +352,8 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
     rep->all_ok = (uint32_t)all_ok; rep->fail_mask = 0;
     for (int k = 0; k < nchk; k++) if (!checks[k]) rep->fail_mask |= 1u << k;
     rep->first_bad_sig = first_bad; rep->gt_target = (uint32_t)gt_t; rep->gt_trusted = (uint32_t)gt_r;
-    rep->reserved[0] = rep->reserved[1] = 0;
+    rep->reserved[0] = (nb > n ? 1u : 0u) | (kind == TMXO_KIND_SKIP && nbt > n ? 2u : 0u);   /* precond: input/mod.rs:439-444, 338-342 */
+    rep->reserved[1] = 0;
   }
   free(powers); free(signedv); free(totp); free(accp); free(leaves); free(nodes); free(nodes_r);
   return E.n == tmxo_elem_count(kind, n) ? 0 : -2;

@@ -134,7 +134,7 @@ def elem_count(kind, n):
 
 def _rep(r):
     return dict(header=bytes(r.header), all_ok=bool(r.all_ok), fail_mask=r.fail_mask, first_bad_sig=r.first_bad_sig,
-                gt_target=bool(r.gt_target), gt_trusted=bool(r.gt_trusted), dist_ok=bool(r.dist_ok))
+                gt_target=bool(r.gt_target), gt_trusted=bool(r.gt_trusted), dist_ok=bool(r.dist_ok), precond=int(r.reserved[0]))
 
 
 def witness(kind, proof_rec, target_recs, trusted_recs, chain_id, skip_max):

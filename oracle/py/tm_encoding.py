@@ -31,7 +31,7 @@ def varint(n):
 def varint9(n):
     """Fixed 9-byte in-circuit varint (reference circuits/builder/shared.rs:67-156): septet i carries the
     continuation bit iff i < index of the last non-zero septet; trailing bytes are zero."""
-    assert 0 <= n < (1 << 63)
+    assert 0 <= n < (1 << 64)   # bit 63 is not part of any septet; the circuit asserts it is 0 (shared.rs:80) -- a check bit, not an exception
     septets = [(n >> (7 * i)) & 0x7F for i in range(9)]
     last = 0
     for i in range(9):

@@ -218,8 +218,8 @@ PROOF_D = 256 + 4 * 256                   # leaf hash + 4 path nodes
 
 def derived_count(kind, n):
     if kind == KIND_SKIP:
-        return n * DT + n * DR + 2 * tree_nodes_count(n) * 256 + (4 * PROOF_D + 88) + 33
-    return n * DT + tree_nodes_count(n) * 256 + (5 * PROOF_D + 88) + 24
+        return n * DT + n * DR + 2 * tree_nodes_count(n) * 256 + (4 * PROOF_D + 88) + 34
+    return n * DT + tree_nodes_count(n) * 256 + (5 * PROOF_D + 88) + 25
 
 
 def path_bits(index, depth=4):
@@ -309,14 +309,14 @@ def _emit_validator_h(E, v):
 def _emit_hash_proof_h(E, aunts, leaf, leaf_size):
     for a in aunts:
         E.bytes(a)
-    E.bytes(leaf.ljust(leaf_size, b"\0"))
+    E.bytes(leaf[:leaf_size].ljust(leaf_size, b"\0"))
 
 
 def _emit_chain_height_h(E, leaves, proofs, height_value):
     for a in proofs[1]:
         E.bytes(a)
     E.u32(len(leaves[1]))
-    E.bytes(leaves[1].ljust(CHAIN_ID_PB_MAX, b"\0"))
+    E.bytes(leaves[1][:CHAIN_ID_PB_MAX].ljust(CHAIN_ID_PB_MAX, b"\0"))
     for a in proofs[2]:
         E.bytes(a)
     E.u32(len(leaves[2]))
@@ -336,7 +336,6 @@ def _valset_derived(lanes):
     """marshal (validator.rs:185-207) + leaf hash (validator.rs:209-229) per lane."""
     out = []
     for v in lanes:
-        assert v["power"] < (1 << 63)
         m = b"\x0a\x22\x0a\x20" + v["pubkey"] + b"\x10" + tm.varint9(v["power"])
         out.append((m, tm.leaf_hash(m[:min(v["vlen"], VAL_BYTES_MAX)])))
     return out
@@ -392,6 +391,11 @@ def witness(kind, proof_rec, target_recs, trusted_recs, chain_id, skip_max):
     tal_t = tally([v["power"] for v in tgt], nb, signed, 2, 3)
     all_eddsa, all_sigdata = True, True
     first_bad_sig = -1
+    # marshal_int64_varint asserts bit 63 == 0 (shared.rs:80) for every voting power it marshals (validator.rs:200, both sets) and for
+    # height_proof.height (shared.rs:178)
+    varint_ok = all(v["power"] < (1 << 63) for v in tgt) and height_a < (1 << 63)
+    # verify_non_negative_round (validator.rs:73-78; asserted per lane at :141 on the proof-wide round, signed or not)
+    round_nonneg = (round_ >> 63) == 0
     for i, v in enumerate(tgt):
         tr = eddsa_lane(v)
         enabled = i < nb
@@ -420,6 +424,7 @@ def witness(kind, proof_rec, target_recs, trusted_recs, chain_id, skip_max):
     if kind == KIND_SKIP:
         nbt = p["nb_b"]
         rder = _valset_derived(trs)
+        varint_ok = varint_ok and all(t["power"] < (1 << 63) for t in trs)
         # N x N match (verify.rs:398-418)
         matched = [any(signed[i] and tgt[i]["pubkey"] == trs[j]["pubkey"] for i in range(n)) for j in range(n)]
         tal_r = tally([t["power"] for t in trs], nbt, matched, 1, 3)
@@ -440,21 +445,22 @@ def witness(kind, proof_rec, target_recs, trusted_recs, chain_id, skip_max):
                 E.bytes(nd)
 
     # header section
-    cid_leaf_hash = tm.leaf_hash(leaves_a[1])                      # verify.rs:189-202
+    # verify.rs:189-202: SHA-256 over 1 + enc_len bytes of 00 | chain_id[52] | zeros (the field resized to 52 bytes, mod.rs:476-478)
+    cid_leaf_hash = tm.leaf_hash(leaves_a[1][:CHAIN_ID_PB_MAX].ljust(80, b"\0")[:len(leaves_a[1])])
     cid_nodes = proof_walk(cid_leaf_hash, 1, proofs_a[1])
     hl = b"\x00\x08" + tm.varint9(height_a)                        # shared.rs:158-167, 180-181
     h_leaf_hash = tm.leaf_hash(hl[1:].ljust(80, b"\0")[:len(leaves_a[2])])   # SHA256 over 1+len bytes of `00 08 varint9 00..`
     h_nodes = proof_walk(h_leaf_hash, 2, proofs_a[2])
-    v_leaf_hash = tm.leaf_hash(leaves_a[7].ljust(34, b"\0"))
+    v_leaf_hash = tm.leaf_hash(leaves_a[7][:34].ljust(34, b"\0"))
     v_nodes = proof_walk(v_leaf_hash, 7, proofs_a[7])
     _emit_proof_d(E, cid_leaf_hash, cid_nodes)
     E.bytes(hl)
     _emit_proof_d(E, h_leaf_hash, h_nodes)
     _emit_proof_d(E, v_leaf_hash, v_nodes)
-    chain_ok = leaves_a[1].ljust(CHAIN_ID_PB_MAX, b"\0")[2:2 + len(chain_id)] == chain_id   # verify.rs:211-221
+    chain_ok = leaves_a[1][:CHAIN_ID_PB_MAX].ljust(CHAIN_ID_PB_MAX, b"\0")[2:2 + len(chain_id)] == chain_id   # verify.rs:211-221
     checks = []
     if kind == KIND_SKIP:
-        tv_leaf_hash = tm.leaf_hash(leaves_b[7].ljust(34, b"\0"))
+        tv_leaf_hash = tm.leaf_hash(leaves_b[7][:34].ljust(34, b"\0"))
         tv_nodes = proof_walk(tv_leaf_hash, 7, proofs_b[7])
         _emit_proof_d(E, tv_leaf_hash, tv_nodes)
         for tl in (tal_t, tal_r):
@@ -465,8 +471,8 @@ def witness(kind, proof_rec, target_recs, trusted_recs, chain_id, skip_max):
         E.bool(dist_gt); E.bool(dist_le)
         checks = [
             tv_nodes[-1] == p["hash"],                                      # verify.rs:374-379
-            root_r == leaves_b[7].ljust(34, b"\0")[2:34],                   # verify.rs:382-389
-            root_t == leaves_a[7].ljust(34, b"\0")[2:34],                   # verify.rs:279-280
+            root_r == leaves_b[7][:34].ljust(34, b"\0")[2:34],                   # verify.rs:382-389
+            root_t == leaves_a[7][:34].ljust(34, b"\0")[2:34],                   # verify.rs:279-280
             v_nodes[-1] == header,                                          # verify.rs:283-286
             cid_nodes[-1] == header,                                        # verify.rs:205-209
             chain_ok,
@@ -475,25 +481,26 @@ def witness(kind, proof_rec, target_recs, trusted_recs, chain_id, skip_max):
             all_sigdata,
             all_eddsa,
             tal_t["no_overflow"] and tal_r["no_overflow"],
-            True,                                                           # varint msb (asserted at pack time)
+            varint_ok,                                                      # shared.rs:80
+            round_nonneg,                                                   # validator.rs:73-78
         ]
         for c in checks:
             E.bool(c)
         all_ok = all(checks) and tal_t["gt"] and tal_r["gt"] and dist_gt and dist_le
         E.bool(all_ok)
     else:
-        lb_leaf = leaves_a[4].ljust(72, b"\0")
+        lb_leaf = leaves_a[4][:72].ljust(72, b"\0")
         lb_leaf_hash = tm.leaf_hash(lb_leaf)
         lb_nodes = proof_walk(lb_leaf_hash, 4, proofs_a[4])
         _emit_proof_d(E, lb_leaf_hash, lb_nodes)
-        nv_leaf = leaves_b[8].ljust(34, b"\0")
+        nv_leaf = leaves_b[8][:34].ljust(34, b"\0")
         nv_leaf_hash = tm.leaf_hash(nv_leaf)
         nv_nodes = proof_walk(nv_leaf_hash, 8, proofs_b[8])
         _emit_proof_d(E, nv_leaf_hash, nv_nodes)
         tl = tal_t
         E.u64(tl["total"]); E.u64(tl["acc"]); E.u64(tl["scaled_acc"]); E.u64(tl["scaled_total"]); E.bool(tl["gt"])
         checks = [
-            root_t == leaves_a[7].ljust(34, b"\0")[2:34],
+            root_t == leaves_a[7][:34].ljust(34, b"\0")[2:34],
             v_nodes[-1] == header,
             cid_nodes[-1] == header,
             chain_ok,
@@ -502,11 +509,12 @@ def witness(kind, proof_rec, target_recs, trusted_recs, chain_id, skip_max):
             all_sigdata,
             all_eddsa,
             tl["no_overflow"],
-            True,
+            varint_ok,
             lb_nodes[-1] == header,                                         # verify.rs:144-147
             lb_leaf[2:34] == p["hash"],                                     # verify.rs:150-153
             nv_nodes[-1] == p["hash"],                                      # verify.rs:166-170
-            leaves_a[7].ljust(34, b"\0")[2:34] == nv_leaf[2:34],            # verify.rs:173-177
+            leaves_a[7][:34].ljust(34, b"\0")[2:34] == nv_leaf[2:34],            # verify.rs:173-177
+            round_nonneg,                                                   # validator.rs:73-78
         ]
         for c in checks:
             E.bool(c)

@@ -44,7 +44,7 @@ class Report(C.Structure):
     def as_dict(self):
         return dict(header=bytes(self.header), all_ok=bool(self.all_ok), fail_mask=self.fail_mask,
                     first_bad_sig=self.first_bad_sig, gt_target=bool(self.gt_target),
-                    gt_trusted=bool(self.gt_trusted), dist_ok=bool(self.dist_ok))
+                    gt_trusted=bool(self.gt_trusted), dist_ok=bool(self.dist_ok), precond=int(self.reserved[0]))
 
 
 class AddrRec(C.Structure):

@@ -186,7 +186,7 @@ Program build_program(int kind, uint32_t n) {
     L.u32(PF_OFF_VERDICTS + 8);
     L.u32(PF_OFF_VERDICTS + 12);
   }
-  const int n_checks = skip ? 12 : 14;
+  const int n_checks = skip ? 13 : 15;
   for (int k = 0; k < n_checks; k++) L.u32(PF_OFF_CHECKS + 4 * k);
   L.u32(PF_OFF_ALLOK);
   add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT, SRC_PF, 3);
@@ -561,8 +561,8 @@ const char* tmx_status_str(int32_t s) {
 uint64_t tmx_elem_count(int32_t kind, uint32_t n) {
   if ((kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP) || n == 0 || n > TMX_N_MAX_LIMIT) return 0;
   const uint64_t tn = tree_nodes(n);
-  if (kind == TMX_KIND_SKIP) return 1776ull * n + 5320 + 1235ull * n + 630ull * n + 2 * tn * 256 + (4 * 1280 + 88) + 33;
-  return 1517ull * n + 6919 + 1235ull * n + tn * 256 + (5 * 1280 + 88) + 24;
+  if (kind == TMX_KIND_SKIP) return 1776ull * n + 5320 + 1235ull * n + 630ull * n + 2 * tn * 256 + (4 * 1280 + 88) + 34;
+  return 1517ull * n + 6919 + 1235ull * n + tn * 256 + (5 * 1280 + 88) + 25;
 }
 uint64_t tmx_elem_stride(int32_t kind, uint32_t n) { return (tmx_elem_count(kind, n) + 1) & ~1ull; }
 uint64_t tmx_hint_elem_count(int32_t kind, uint32_t n) {

@@ -459,6 +459,31 @@ def test_set_too_large_and_capacity_errors(tmx):
         assert e.value.status == -2
 
 
+def test_device_path_flags_nb_above_n(tmx, oracle):
+    """The device entry points cannot refuse nb > N before enqueueing (the records are in HBM): tmx_report.precond carries the host
+    assert of input/mod.rs:439-444 / 338-342 instead, and the values follow the circuit (every lane enabled)."""
+    import torch
+    from tendermintx_amd.synth import Workload
+    n, P = 8, 3
+    wl = Workload(0, n, P, 8, chain_id=b"celestia", seed=99, signed_permille=1000)
+    proofs = bytearray(wl.proofs)
+    proofs[1 * 2336 + 56:1 * 2336 + 60] = struct.pack("<I", n + 1)       # proof 1: nb_a > N
+    proofs[2 * 2336 + 60:2 * 2336 + 64] = struct.pack("<I", 4 * n)        # proof 2: nb_b > N
+    dev = torch.device("cuda", 0)
+    d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) for b in (bytes(proofs), wl.targets, wl.trusteds)]
+    with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+        out = torch.zeros((P, ctx.elem_stride(0)), dtype=torch.int64, device=dev)
+        rep = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
+        ctx.witness_batch_device(0, P, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), out.data_ptr(), rep.data_ptr(), 0)
+        torch.cuda.synchronize(dev)
+        count = ctx.elem_count(0)
+    reps = np.frombuffer(rep.cpu().numpy().tobytes(), dtype=np.uint32).reshape(P, 16)
+    assert [int(r[14]) for r in reps] == [0, 1, 2]
+    want, oreps = oracle.witness_batch(0, P, bytes(proofs), wl.targets, wl.trusteds, n, b"celestia", 100800)
+    assert np.array_equal(out[:, :count].cpu().numpy().view(np.uint64), want)
+    assert [r["precond"] for r in oreps] == [0, 1, 2] and all(r["all_ok"] for r in oreps)   # in-circuit: all enabled, same verdict
+
+
 def test_validator_sharded_single_proof(tmx, oracle):
     """BASELINE config 5 path (lanes sharded, one all-gather of the EdDSA lane records, replicated finish) on the ranks
     available here (world_size 1 over RCCL); the 2-rank exchange logic is covered on CPU by tests/test_sharding_gloo.py."""
