@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark: skip-circuit witness generation at VALIDATOR_SET_SIZE_MAX=128 on N MI355X (one rank per GPU).
 
-A "step" = one pass of the whole hot path (k_eddsa -> k_proof -> k_serialize) over one batch of synthetic skip
-proofs whose packed input records are already resident in HBM; outputs (Goldilocks elements + reports) stay in HBM.
-Weak scaling: every rank processes `--proofs` proofs (default 256, BASELINE configs[3]'s batch); proofs are
-independent, so there is no data-path collective -- only the timing barrier / max-over-ranks go through RCCL.
+A "step" = one pass of the whole hot path (EdDSA kernels, k_proof, k_serialize) over one batch of synthetic skip proofs whose packed
+input records are already resident in HBM; outputs (Goldilocks elements + reports) stay in HBM.  `python bench.py --gpus N` spawns its
+own N ranks (torch.distributed.run, RCCL) when it was not started by a launcher; under a launcher it reads RANK / WORLD_SIZE.
 
-Prints ONE JSON line on rank 0 (contract: task description "bench.py"), with two extra objects:
-  roofline      dominant kernel (k_eddsa): algorithmic bytes / HIP-event duration vs 8 TB/s (it is VALU-bound; the
-                integer-issue fraction is given beside it), plus the same figures for k_serialize (HBM-write bound)
-                and for the whole pass
-  cpu_baseline  oracle/c (plain-C port of the same witness) timed on this box's host cores on a bounded sample,
-                single thread ("cores": 1) and all cores
+  --scaling weak    (default) every rank processes --proofs proofs (256 = BASELINE configs[3]'s batch); no data-path collective
+  --scaling strong  --proofs proofs in total, split over the ranks (configs[3] as written: 256 proofs sharded across 8);
+                    --gather adds the all-gather of the witness rows (RCCL over xGMI) to the step and times it separately
+  --mode c5         BASELINE configs[4]: ONE proof at N = 512, validator lanes sharded across the ranks, one all-gather of the
+                    448-byte EdDSA lane records, replicated finish (tendermintx_amd/sharding.py)
+  --workload survey8d (default) SURVEY 8(d)'s measured workload: 100 validators in 128 lanes, four distinct validator sets per batch,
+                    Bernoulli(0.9) signing re-drawn until > 2/3, rounds {0,0,0,3}; `best_case` (one set, 128 of 128, everybody signs --
+                    round 1's headline) is timed beside it and reported in the same line
+
+Prints ONE JSON line on rank 0 (contract: task description "bench.py").  Beside the contract's fields:
+  single_proof   BASELINE configs[2]: device-resident latency of one proof and its host-to-host time (SURVEY 8(d)'s metric definition)
+  host_to_host   the batch through the host-buffer entry point (H2D + step + D2H), full rows and hint-only rows
+  roofline       the step against HBM (algorithmic bytes / HIP-event time of the launch sequence), k_serialize alone, VALU issue
+  cpu_baseline   oracle/c on this box's host cores: one thread, and a persistent pool on all cores (>= 16 proofs per thread) with its
+                 scaling efficiency; OpenSSL's EVP_DigestVerify per signature as an independent datapoint
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,24 +33,50 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-MAD_PEAK_GOPS = 39321.6        # v_mad_i64_i32: 4 cycles / wave64 (tools/microbench) -> 1024 SIMDs * 64 / 4 * 2.4 GHz
-MADS_PER_LANE = 250_300        # 1658 fe-mul x 100 + 1538 fe-sq x 55 v_mad_i64_i32 per lane (direct h*A: 252 doublings + 64 additions; s*B: 32; no R decode)
-MADS_PER_LANE_TABLES = 75_900  # per-key tables: 619 fe-mul + 255 fe-sq per lane (s*B 26 additions, h*A 43 + 1 merge, finish with one inversion)
 SIMDS, CLOCK_GHZ, CYCLES_PER_VALU = 1024, 2.4, 4   # 256 CUs x 4 SIMD16; every VALU instruction of a wave64 occupies its SIMD for 4 cycles (tools/microbench)
-MADS_PER_KEY = 2_560_000       # once per distinct key: decode + 252 doublings + 43 windows x 32 cached multiples (4 quads x ~14 group operations)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--proofs", type=int, default=256, help="proofs per GPU per step")
-    ap.add_argument("--n-max", type=int, default=128)
-    ap.add_argument("--nb", type=int, default=None, help="real validators per set (default n_max)")
-    ap.add_argument("--signed-permille", type=int, default=1000)
+    ap.add_argument("--proofs", type=int, default=256, help="proofs per GPU per step (weak) / in total (strong)")
+    ap.add_argument("--n-max", type=int, default=None, help="VALIDATOR_SET_SIZE_MAX (default 128; 512 in --mode c5)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--gather", action="store_true", help="strong scaling: all-gather the witness rows on every rank inside the step")
+    ap.add_argument("--mode", choices=("batch", "c5"), default="batch")
+    ap.add_argument("--workload", choices=("survey8d", "one_set"), default="survey8d")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region (profiling runs)")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script the way the driver does."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def gbs(nbytes, ms):
+    return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args)
 
     import torch  # first: libtmx must share PyTorch's HIP runtime (tendermintx_amd/_lib.py)
     import torch.distributed as dist
@@ -52,39 +88,117 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.mode == "c5"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     import numpy as np
-    from tendermintx_amd import KIND_SKIP, Context
-    from tendermintx_amd.synth import Workload
-
-    n, P = args.n_max, args.proofs
-    nb = args.nb or n
-    wl = Workload(KIND_SKIP, n, P, nb, chain_id=b"celestia", seed=0x544D58 + rank, signed_permille=args.signed_permille)
-    ctx = Context(n, b"celestia", 100800, device=local_rank, max_batch=P)
-    stride, count = ctx.elem_stride(KIND_SKIP), ctx.elem_count(KIND_SKIP)
-
-    def dev_bytes(b):
-        return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
-
-    d_proofs, d_targets, d_trusteds = dev_bytes(wl.proofs), dev_bytes(wl.targets), dev_bytes(wl.trusteds)
-    d_out = torch.empty(P * stride, dtype=torch.int64, device=dev)
-    d_rep = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream(dev)
-
-    def step():
-        ctx.witness_batch_device(KIND_SKIP, P, d_proofs.data_ptr(), d_targets.data_ptr(), d_trusteds.data_ptr(), d_out.data_ptr(),
-                                 d_rep.data_ptr(), stream.cuda_stream)
+    from tendermintx_amd import KIND_SKIP, Context, sharding
+    from tendermintx_amd.synth import bench_workload
 
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize(dev)
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def dev_bytes(b):
+        return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+
+    stream = torch.cuda.current_stream(dev)
+
+    # ------------------------------------------------------------------------------------------------ configs[4]: one proof, lanes sharded
+    if args.mode == "c5":
+        n = args.n_max or 512
+        wl = bench_workload("survey8d", n, 1, seed=0x544D58)      # identical on every rank (nb = N at C5)
+        d_p, d_t, d_r = dev_bytes(wl.proofs), dev_bytes(wl.targets), dev_bytes(wl.trusteds)
+        ctx = Context(n, b"celestia", 100800, device=local_rank, max_batch=1)
+
+        def step():
+            return sharding.validator_sharded_skip(ctx, KIND_SKIP, d_p, d_t, d_r)
+
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            elems, rep = step()
+        barrier()
+        ms_per_step = 1e3 * max_over_ranks(time.perf_counter() - t0) / args.steps
+        # the exchange alone: all-gather of the padded 448-byte lane records
+        lo, hi = sharding.shard_range(n, rank, world)
+        local = torch.zeros((hi - lo, 448), dtype=torch.uint8, device=dev)
+        for _ in range(5):
+            sharding.gather_rows(local, n)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sharding.gather_rows(local, n)
+        barrier()
+        gather_ms = 1e3 * max_over_ranks(time.perf_counter() - t0) / args.steps
+        ok = int(rep.cpu().numpy()[32:36].view(np.uint32)[0])
+        if rank == 0:
+            out_bytes = ctx.elem_stride(KIND_SKIP) * 8
+            print(json.dumps({
+                "metric": "skip-circuit witness-gen ms at VALIDATOR_SET_SIZE_MAX=512, one proof, validator-sharded", "value": round(ms_per_step, 5),
+                "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+                "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+                "config": {"workload": f"BASELINE configs[4]: SkipCircuit VALIDATOR_SET_SIZE_MAX={n}, ONE proof, {wl.nb} validators, lanes sharded over "
+                                       f"{world} GPU(s), one all-gather of {n} x 448 B EdDSA lane records, finish replicated on every rank",
+                           "n_max": n, "parallelism": f"validator-sharded x{world}"},
+                "all_gather_ms": round(gather_ms, 5), "all_proofs_ok": bool(ok),
+                "roofline": {"kernel": "step", "bound": "hbm", "achieved": round(gbs(out_bytes, ms_per_step), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(gbs(out_bytes, ms_per_step) / HBM_PEAK_GBS, 5), "traffic": None,
+                             "note": "a single proof is latency-bound (dependent EdDSA chain), not bandwidth-bound: DESIGN.md section 6"}}), flush=True)
+        barrier()
+        ctx.close()
+        if use_dist:
+            dist.destroy_process_group()
+        return 0
+
+    # ------------------------------------------------------------------------------------------------ batch of independent proofs
+    n = args.n_max or 128
+    if args.scaling == "weak":
+        P_total, lo, hi = args.proofs * world, rank * args.proofs, (rank + 1) * args.proofs
+    else:
+        P_total = args.proofs
+        lo, hi = sharding.shard_range(P_total, rank, world)
+    P = hi - lo
+    seed = 0x544D58 + (rank if args.scaling == "weak" else 0)
+    wl_all = bench_workload(args.workload, n, P_total if args.scaling == "strong" else P, seed=seed)
+    if args.scaling == "strong":  # every rank builds the same batch and keeps its slice
+        proofs, targets, trusteds = (wl_all.proofs[lo * 2336:hi * 2336], wl_all.targets[lo * n * 256:hi * n * 256],
+                                     wl_all.trusteds[lo * n * 48:hi * n * 48])
+    else:
+        proofs, targets, trusteds = wl_all.proofs, wl_all.targets, wl_all.trusteds
+    ctx = Context(n, b"celestia", 100800, device=local_rank, max_batch=max(P, 1))
+    stride, count = ctx.elem_stride(KIND_SKIP), ctx.elem_count(KIND_SKIP)
+    d_proofs, d_targets, d_trusteds = dev_bytes(proofs), dev_bytes(targets), dev_bytes(trusteds)
+    d_out = torch.empty((max(P, 1), stride), dtype=torch.int64, device=dev)
+    d_rep = torch.zeros(max(P, 1) * 64, dtype=torch.uint8, device=dev)
+    gather = args.gather and world > 1
+
+    def run(c, k, bufs=None, n_proofs=None):
+        dp, dt, dr = bufs or (d_proofs, d_targets, d_trusteds)
+        for _ in range(k):
+            c.witness_batch_device(KIND_SKIP, P if n_proofs is None else n_proofs, dp.data_ptr(), dt.data_ptr(), dr.data_ptr(), d_out.data_ptr(),
+                                   d_rep.data_ptr(), stream.cuda_stream)
+
+    def step():
+        run(ctx, 1)
+        if gather:
+            return sharding.gather_rows(d_out[:P], P_total)
 
     for _ in range(args.warmup):
         step()
@@ -93,168 +207,279 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    ms_per_step = 1e3 * elapsed / args.steps
     kms = ctx.kernel_ms_mean(min(args.steps, 128))  # HIP events recorded on the launch stream inside the timed region
     n_unique, used_tables = ctx.last_dedup()
 
+    gather_ms = None
+    if gather:
+        for _ in range(3):
+            sharding.gather_rows(d_out[:P], P_total)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            sharding.gather_rows(d_out[:P], P_total)
+        barrier()
+        gather_ms = 1e3 * max_over_ranks(time.perf_counter() - t0) / 10
+
     # every proof of this rank must have verified (synthetic inputs are well-formed)
-    rep = d_rep.cpu().numpy().reshape(P, 64)
+    rep = d_rep.cpu().numpy().reshape(-1, 64)[:P]
     all_ok = int(rep[:, 32:36].copy().view(np.uint32).sum())
     ok_flag = torch.tensor([1 if all_ok == P else 0], device=dev)
     if world > 1:
         dist.all_reduce(ok_flag, op=dist.ReduceOp.MIN)
 
-    result = None
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        total_proofs = P * world
         lanes = P * n
         in_bytes = P * (2336 + n * (256 + 48))
         out_bytes = P * stride * 8
-        eddsa_bytes = lanes * (256 + 448)
-        ser_bytes = out_bytes + P * (n * (448 + 2 * 112 + 256 + 48) + 1920 + 2336)
-        k_e, k_p, k_s = kms["k_eddsa"], kms["k_proof"], kms["k_serialize"]
-        ed_mads = lanes * MADS_PER_LANE_TABLES + n_unique * MADS_PER_KEY if used_tables else lanes * MADS_PER_LANE
-        # k_serialize on its own (the step spreads it over three overlapped launches): a second context with the split disabled
-        os.environ["TMX_SER_SPLIT"] = "0"
-        ctx1 = Context(n, b"celestia", 100800, device=local_rank, max_batch=P)
-        del os.environ["TMX_SER_SPLIT"]
-        for _ in range(30):  # (the first launches after a context creation run at ramping clocks)
-            ctx1.witness_batch_device(KIND_SKIP, P, d_proofs.data_ptr(), d_targets.data_ptr(), d_trusteds.data_ptr(), d_out.data_ptr(),
-                                      d_rep.data_ptr(), stream.cuda_stream)
-        torch.cuda.synchronize(dev)
-        k_s = ctx1.kernel_ms_mean(20)["k_serialize"]
-        ctx1.close()
-        # transparency: the same step with the per-key tables switched off (every lane does its own 252 doublings for h*A)
-        os.environ["TMX_DEDUP"] = "0"
-        ctx0 = Context(n, b"celestia", 100800, device=local_rank, max_batch=P)
-        del os.environ["TMX_DEDUP"]
-        for _ in range(3):
-            ctx0.witness_batch_device(KIND_SKIP, P, d_proofs.data_ptr(), d_targets.data_ptr(), d_trusteds.data_ptr(), d_out.data_ptr(),
-                                      d_rep.data_ptr(), stream.cuda_stream)
-        torch.cuda.synchronize(dev)
-        a0 = time.perf_counter()
-        for _ in range(10):
-            ctx0.witness_batch_device(KIND_SKIP, P, d_proofs.data_ptr(), d_targets.data_ptr(), d_trusteds.data_ptr(), d_out.data_ptr(),
-                                      d_rep.data_ptr(), stream.cuda_stream)
-        torch.cuda.synchronize(dev)
-        ms_no_tables = 1e3 * (time.perf_counter() - a0) / 10
-        k_e_no_tables = ctx0.kernel_ms_mean(10)["k_eddsa"]
-        ctx0.close()
-
-        traffic, traffic_ser, issue = None, None, None
-        try:  # per-batch PMC figures from the committed rocprofv3 passes (profiles/), only if they were taken on this configuration
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            if pmc["config"] == {"n_max": n, "proofs_per_gpu": P}:
-                pk = pmc["kernels"]
-                traffic = int((pk["k_eddsa"]["fetch_kb"] + pk["k_eddsa"]["write_kb"]) * 1024)
-                traffic_ser = int((pk["k_serialize"]["fetch_kb"] + pk["k_serialize"]["write_kb"]) * 1024)
-                if used_tables and "valu_insts" in pk["k_eddsa"]:
-                    # VALU issue: wave-level instructions x 4 cycles against SIMD-cycles available in the measured time
-                    def frac(insts, ms):
-                        return round(insts * CYCLES_PER_VALU / (SIMDS * ms * 1e-3 * CLOCK_GHZ * 1e9), 4)
-                    step_insts = sum(pk[g].get("valu_insts", 0) for g in pk)
-                    issue = {"unit": "wave-level VALU instructions per batch (SQ_INSTS_VALU)", "cycles_per_instruction": CYCLES_PER_VALU,
-                             "k_eddsa": {"insts": int(pk["k_eddsa"]["valu_insts"]), "frac_of_issue_slots": frac(pk["k_eddsa"]["valu_insts"], k_e)},
-                             "step": {"insts": int(step_insts), "frac_of_issue_slots": frac(step_insts, ms_per_step)},
-                             "note": "fraction of the 1024 SIMDs' issue cycles (2.4 GHz) that the step's VALU instructions occupy; per kernel in DESIGN.md"}
-        except (OSError, KeyError, ValueError):
-            pass
-
-        def gbs(nbytes, ms):
-            return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-
-        roofline = {"kernel": "k_eddsa", "bound": "hbm", "achieved": round(gbs(eddsa_bytes, k_e), 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs(eddsa_bytes, k_e) / HBM_PEAK_GBS, 6), "traffic": traffic, "algorithmic_bytes": eddsa_bytes,
-                    "note": "EdDSA kernels are integer-VALU / dependent-chain bound (v_mad_i64_i32), not HBM bound: see valu; k_serialize is the HBM-bound kernel",
-                    "valu": {"achieved": round(ed_mads / (k_e * 1e-3) / 1e9, 1), "peak": MAD_PEAK_GOPS, "unit": "Gmad/s",
-                             "frac": round(ed_mads / (k_e * 1e-3) / 1e9 / MAD_PEAK_GOPS, 4), "algorithmic_mads": ed_mads,
-                             "note": "multiply-adds the chosen algorithm needs, not the instructions issued"},
-                    "valu_issue": issue,
-                    "dedup": {"lanes": lanes, "distinct_keys": n_unique, "per_key_tables": used_tables,
-                              "without_key_tables": {"ms_per_step": round(ms_no_tables, 4), "k_eddsa_ms": round(k_e_no_tables, 4),
-                                                     "valu_frac": round(lanes * MADS_PER_LANE / (k_e_no_tables * 1e-3) / 1e9 / MAD_PEAK_GOPS, 4)}},
-                    "k_serialize": {"bound": "hbm", "ms_alone": round(k_s, 4), "achieved": round(gbs(ser_bytes, k_s), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(gbs(ser_bytes, k_s) / HBM_PEAK_GBS, 4), "traffic": traffic_ser, "algorithmic_bytes": ser_bytes},
-                    "pass": {"bound": "hbm", "achieved": round(gbs(in_bytes + out_bytes, ms_per_step), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(gbs(in_bytes + out_bytes, ms_per_step) / HBM_PEAK_GBS, 4),
-                             "note": "whole step (k_proof overlaps the EdDSA kernels on a side stream)"}}
+        alg_bytes = in_bytes + out_bytes      # 33 504 B per lane + 42.6 KB per proof (1.109 GB at 256 x 128), counted exactly
+        step_ms_events = kms["k_eddsa"] + kms["k_serialize"]   # ev0 -> ev3 of the launch sequence on the caller's stream
         result = {
-            "metric": "skip-circuit witness-gen ms at VALIDATOR_SET_SIZE_MAX=128", "value": round(ms_per_step / total_proofs, 6), "unit": "ms",
+            "metric": "skip-circuit witness-gen ms at VALIDATOR_SET_SIZE_MAX=128", "value": round(ms_per_step / P_total, 6), "unit": "ms",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": False,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-            "config": {"workload": f"SkipCircuit VALIDATOR_SET_SIZE_MAX={n}, batch of {P} proofs per GPU (BASELINE configs[3] batch, weak-scaled), "
-                                   f"{nb} validators per set, {args.signed_permille / 10:.0f}% signing, inputs resident in HBM",
-                       "n_max": n, "proofs_per_gpu": P, "parallelism": f"proof-sharded x{world}, no data-path collective"},
-            "value_note": "ms per proof = ms_per_step / (proofs_per_gpu * n_gpus)",
-            "throughput": {"proofs_per_s": round(total_proofs / (ms_per_step * 1e-3), 1), "lanes_per_s": round(total_proofs * n / (ms_per_step * 1e-3), 1)},
-            "kernels_ms": {k: round(v, 4) for k, v in kms.items()},
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"SkipCircuit VALIDATOR_SET_SIZE_MAX={n}, batch of {P_total} proofs over {world} GPU(s) "
+                                   f"({'BASELINE configs[3] batch per GPU, weak-scaled' if args.scaling == 'weak' else 'BASELINE configs[3]: one batch sharded'}), "
+                                   f"{wl_all.describe}; inputs resident in HBM, witness rows stay in HBM",
+                       "n_max": n, "proofs_total": P_total, "proofs_per_gpu": P, "workload_name": args.workload,
+                       "parallelism": f"proof-sharded x{world}, " + ("all-gather of the witness rows inside the step" if gather else "no data-path collective")},
+            "value_note": "ms per proof = ms_per_step / proofs_total (device-resident, batch-amortised); the single-proof and host-to-host figures "
+                          "of SURVEY 8(d)'s metric definition are in `single_proof` and `host_to_host`",
+            "throughput": {"proofs_per_s": round(P_total / (ms_per_step * 1e-3), 1), "lanes_per_s": round(P_total * n / (ms_per_step * 1e-3), 1)},
+            "kernels_ms": dict({k: round(v, 4) for k, v in kms.items()}, step_events=round(step_ms_events, 4)),
             "all_proofs_ok": bool(int(ok_flag.item())),
-            "roofline": roofline,
+            "dedup": {"lanes": lanes, "distinct_keys": n_unique, "per_key_tables": used_tables},
         }
+        if gather_ms is not None:
+            result["gather_rows"] = {"ms": round(gather_ms, 4), "bytes_per_rank_out": P_total * stride * 8,
+                                     "note": "RCCL all-gather of the padded row blocks alone (10 repetitions), every rank ends with all rows"}
+        roofline = {"kernel": "step", "kernel_note": "the whole launch sequence of one batch (EdDSA kernels, k_proof, k_serialize on four streams), "
+                    "timed by HIP events on the caller's stream", "bound": "hbm", "achieved": round(gbs(alg_bytes, step_ms_events), 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(gbs(alg_bytes, step_ms_events) / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": alg_bytes,
+                    "host_clock": {"achieved": round(gbs(alg_bytes, ms_per_step), 1), "frac": round(gbs(alg_bytes, ms_per_step) / HBM_PEAK_GBS, 4)},
+                    "note": "the step is bounded by VALU issue and by the dependent EdDSA chain (valu_issue), k_serialize by HBM writes; "
+                            "nothing on this path is a dense contraction (no MFMA)"}
+        result["roofline"] = roofline
 
-        # single-proof latency (BASELINE configs[2]) on the same context, host wall clock around one device call
-        lat = []
-        for _ in range(20):
-            torch.cuda.synchronize(dev)
-            a = time.perf_counter()
-            ctx.witness_batch_device(KIND_SKIP, 1, d_proofs.data_ptr(), d_targets.data_ptr(), d_trusteds.data_ptr(), d_out.data_ptr(),
-                                     d_rep.data_ptr(), stream.cuda_stream)
-            torch.cuda.synchronize(dev)
-            lat.append(1e3 * (time.perf_counter() - a))
-        result["latency_single_proof_ms"] = round(sorted(lat)[len(lat) // 2], 4)
-
-        # SURVEY 8(d)'s host-to-host variant (never `value`): pageable host buffers in, witness rows + reports back in host memory,
-        # through the host-buffer entry point tmx_witness_batch (H2D + the same step + D2H of 1.2 GB)
-        if world == 1:
-            pinned = torch.empty(P * stride, dtype=torch.int64, pin_memory=True)
-            host_out = pinned.numpy().view(np.uint64)
-            hh = []
-            for _ in range(3):
-                a = time.perf_counter()
-                ctx.witness_batch(KIND_SKIP, wl.proofs, wl.targets, wl.trusteds, out=host_out)
-                hh.append(1e3 * (time.perf_counter() - a))
-            hb = in_bytes + out_bytes + P * 64
-            result["host_to_host"] = {"ms_per_step": round(min(hh), 3), "ms_per_proof": round(min(hh) / P, 5), "bytes_over_pcie": hb,
-                                      "effective_gbs": round(hb / (min(hh) * 1e-3) / 1e9, 1),
-                                      "note": "pageable inputs, page-locked output rows; PCIe-bound, reported for completeness"}
-            del pinned, host_out
-
-        if world == 1 and not args.no_cpu_baseline:
-            sys.path.insert(0, os.path.join(ROOT, "oracle", "py"))
-            import oracle_c as oc  # checker + reported CPU baseline only
-            S = min(P, 256)
-            sl_p, sl_t, sl_r = wl.proofs[:S * 2336], wl.targets[:S * n * 256], wl.trusteds[:S * n * 48]
-            a = time.perf_counter()
-            o_elems, o_reps = oc.witness_batch(KIND_SKIP, S, sl_p, sl_t, sl_r, n, b"celestia", 100800, n_threads=1)
-            t1 = time.perf_counter() - a
-            cores = os.cpu_count() or 1
-            passes = 0
-            a = time.perf_counter()
-            while time.perf_counter() - a < 4.0 and passes < 50:
-                oc.witness_batch(KIND_SKIP, S, sl_p, sl_t, sl_r, n, b"celestia", 100800, n_threads=min(cores, S), want_out=False)
-                passes += 1
-            tn = (time.perf_counter() - a) / passes
-            # parity of the timed GPU output against the oracle on the same sample
-            ctx.witness_batch_device(KIND_SKIP, P, d_proofs.data_ptr(), d_targets.data_ptr(), d_trusteds.data_ptr(), d_out.data_ptr(),
-                                     d_rep.data_ptr(), stream.cuda_stream)
-            torch.cuda.synchronize(dev)
-            g = d_out.view(P, stride)[:S, :count].cpu().numpy().view(np.uint64)
-            result["parity_vs_oracle"] = {"proofs_checked": S, "bit_exact": bool(np.array_equal(g, o_elems))}
-            result["cpu_baseline"] = {"value": round(1e3 * t1 / S, 4), "unit": "ms", "cores": 1, "kind": "port",
-                                      "sample": f"{S} proofs x N={n} ({S * n} validator lanes), 1 pass, oracle/c single thread, full witness",
-                                      "all_cores": {"value": round(1e3 * tn / S, 5), "unit": "ms", "cores": min(cores, S),
-                                                    "sample": f"{S} proofs, {passes} passes, pthreads, compute only (no element output)"}}
+        if not args.no_extras and world == 1:
+            extras(args, result, roofline, ctx, run, wl_all, n, P, stride, count, dev, stream, d_out, d_rep, dev_bytes, kms, ms_per_step, alg_bytes)
         print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
+    barrier()
+    if use_dist:
         dist.destroy_process_group()
     ctx.close()
     return 0
+
+
+def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, stream, d_out, d_rep, dev_bytes, kms, ms_per_step, alg_bytes):
+    """Everything beside the timed region (rank 0, one GPU): secondary workload, single proof, host-to-host, kernel-alone figures,
+    PMC-derived figures from profiles/, CPU baseline."""
+    import numpy as np
+    import torch
+    from tendermintx_amd import KIND_SKIP, Context
+    from tendermintx_amd.synth import bench_workload
+
+    def timed(c, k, bufs=None, n_proofs=None):
+        torch.cuda.synchronize(dev)
+        a = time.perf_counter()
+        run(c, k, bufs, n_proofs)
+        torch.cuda.synchronize(dev)
+        return 1e3 * (time.perf_counter() - a) / k
+
+    # ---- the other workload (best case <-> SURVEY 8(d)) through the same context
+    other_name = "one_set" if args.workload == "survey8d" else "survey8d"
+    wo = bench_workload(other_name, n, P, seed=0x544D58)
+    bo = tuple(dev_bytes(b) for b in (wo.proofs, wo.targets, wo.trusteds))
+    timed(ctx, 10, bo)
+    ms_other = timed(ctx, 30, bo)
+    uo, to = ctx.last_dedup()
+    ok_o = int(d_rep.cpu().numpy().reshape(-1, 64)[:P, 32:36].copy().view(np.uint32).sum()) == P
+    result["best_case" if other_name == "one_set" else "survey8d"] = {
+        "workload": wo.describe, "ms_per_step": round(ms_other, 4), "value": round(ms_other / P, 6), "distinct_keys": uo, "per_key_tables": to,
+        "all_proofs_ok": ok_o, "note": "same context, 30 steps after 10 warm-up, host clock around the enqueue + synchronize"}
+
+    # ---- BASELINE configs[2]: ONE proof.  Device-resident latency (host clock around one call) and host-to-host (host buffers in,
+    # witness row in page-locked host memory out: SURVEY 8(d)'s metric definition)
+    run(ctx, 3, None, 1)
+    lat = []
+    for _ in range(30):
+        lat.append(timed(ctx, 1, None, 1))
+    pinned = torch.empty(P * stride, dtype=torch.int64, pin_memory=True)
+    host_out = pinned.numpy().view(np.uint64)
+    p1 = (wl.proofs[:2336], wl.targets[:n * 256], wl.trusteds[:n * 48])
+    hh1, hh1_hint = [], []
+    for _ in range(3):
+        ctx.witness_batch(KIND_SKIP, *p1, out=host_out)
+    for _ in range(20):
+        a = time.perf_counter()
+        ctx.witness_batch(KIND_SKIP, *p1, out=host_out)
+        hh1.append(1e3 * (time.perf_counter() - a))
+    hint = getattr(ctx, "witness_batch_hint", None)
+    if hint is not None:
+        for _ in range(3):
+            hint(KIND_SKIP, *p1, out=host_out)
+        for _ in range(20):
+            a = time.perf_counter()
+            hint(KIND_SKIP, *p1, out=host_out)
+            hh1_hint.append(1e3 * (time.perf_counter() - a))
+    result["single_proof"] = {"device_ms": round(median(lat), 4), "host_to_host_ms": round(median(hh1), 4),
+                              "host_to_host_hint_only_ms": round(median(hh1_hint), 4) if hh1_hint else None,
+                              "row_bytes": stride * 8, "workload": "proof 0 of the batch above (BASELINE configs[2])"}
+    result["latency_single_proof_ms"] = result["single_proof"]["device_ms"]
+
+    # ---- the batch, host to host (PCIe-bound; never `value`)
+    hh = []
+    for _ in range(3):
+        a = time.perf_counter()
+        ctx.witness_batch(KIND_SKIP, wl.proofs, wl.targets, wl.trusteds, out=host_out)
+        hh.append(1e3 * (time.perf_counter() - a))
+    in_bytes = P * (2336 + n * (256 + 48))
+    hb = in_bytes + P * stride * 8 + P * 64
+    h2h = {"ms_per_step": round(min(hh), 3), "ms_per_proof": round(min(hh) / P, 5), "bytes_over_pcie": hb,
+           "effective_gbs": round(hb / (min(hh) * 1e-3) / 1e9, 1), "note": "pageable inputs, page-locked output rows; PCIe-bound"}
+    if hint is not None:
+        hq = []
+        for _ in range(3):
+            a = time.perf_counter()
+            hint(KIND_SKIP, wl.proofs, wl.targets, wl.trusteds, out=host_out)
+            hq.append(1e3 * (time.perf_counter() - a))
+        hbh = in_bytes + P * ctx.hint_elem_count(KIND_SKIP) * 8 + P * 64
+        h2h["hint_only"] = {"ms_per_step": round(min(hq), 3), "ms_per_proof": round(min(hq) / P, 5), "bytes_over_pcie": hbh,
+                            "note": "only the hint section H of every row (what SkipOffchainInputs::hint writes, skip.rs:85-100) leaves the device"}
+    result["host_to_host"] = h2h
+    del pinned, host_out
+
+    # ---- k_serialize on its own (the step spreads it over overlapped launches): a second context with the split disabled
+    os.environ["TMX_SER_SPLIT"] = "0"
+    ctx1 = Context(n, b"celestia", 100800, device=dev.index, max_batch=P)
+    del os.environ["TMX_SER_SPLIT"]
+    run(ctx1, 30)  # (the first launches after a context creation run at ramping clocks)
+    torch.cuda.synchronize(dev)
+    k_s = ctx1.kernel_ms_mean(20)["k_serialize"]
+    ctx1.close()
+    ser_bytes = P * stride * 8 + P * (n * (448 + 2 * 112 + 256 + 48) + 1920 + 2336)
+    roofline["k_serialize"] = {"bound": "hbm", "ms_alone": round(k_s, 4), "achieved": round(gbs(ser_bytes, k_s), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(gbs(ser_bytes, k_s) / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": ser_bytes,
+                               "note": "one unsplit launch over the whole batch, HIP events around it (TMX_SER_SPLIT=0)"}
+    # ---- transparency: the same step with the per-key tables switched off (every lane does its own 252 doublings for h*A)
+    os.environ["TMX_DEDUP"] = "0"
+    ctx0 = Context(n, b"celestia", 100800, device=dev.index, max_batch=P)
+    del os.environ["TMX_DEDUP"]
+    timed(ctx0, 3)
+    result["dedup"]["without_key_tables"] = {"ms_per_step": round(timed(ctx0, 10), 4), "k_eddsa_ms": round(ctx0.kernel_ms_mean(10)["k_eddsa"], 4)}
+    ctx0.close()
+
+    # ---- PMC figures of the committed rocprofv3 passes (profiles/pmc_latest.json), only if they were taken on this configuration
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        if pmc["config"] == {"n_max": n, "proofs_per_gpu": P, "workload": args.workload}:
+            pk = pmc["kernels"]
+            roofline["traffic"] = int(sum(pk[g].get("fetch_kb", 0) + pk[g].get("write_kb", 0) for g in pk) * 1024)
+            roofline["k_serialize"]["traffic"] = int((pk["k_serialize"]["fetch_kb"] + pk["k_serialize"]["write_kb"]) * 1024)
+
+            def frac(insts, ms):  # wave-level VALU instructions x 4 cycles against the SIMD-cycles of the measured time
+                return round(insts * CYCLES_PER_VALU / (SIMDS * ms * 1e-3 * CLOCK_GHZ * 1e9), 4)
+            step_insts = sum(pk[g].get("valu_insts", 0) for g in pk)
+            roofline["valu_issue"] = {
+                "unit": "wave-level VALU instructions per batch (SQ_INSTS_VALU)", "cycles_per_instruction": CYCLES_PER_VALU,
+                "step": {"insts": int(step_insts), "frac_of_issue_slots": frac(step_insts, kms["k_eddsa"] + kms["k_serialize"])},
+                "k_eddsa": {"insts": int(pk["k_eddsa"]["valu_insts"]), "frac_of_issue_slots": frac(pk["k_eddsa"]["valu_insts"], kms["k_eddsa"])},
+                "k_proof": {"insts": int(pk["k_proof"]["valu_insts"])}, "k_serialize": {"insts": int(pk["k_serialize"]["valu_insts"])},
+                "note": "fraction of the 1024 SIMDs' issue cycles (2.4 GHz) that the VALU instructions occupy over the event-timed interval; "
+                        "the EdDSA kernels move 23 MB per batch (0.6 % of HBM peak): their roof is this one"}
+    except (OSError, KeyError, ValueError):
+        pass
+
+    if args.no_cpu_baseline:
+        return
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "py"))
+    import oracle_c as oc  # checker + reported CPU baseline only
+    S = min(P, 64)
+    sl_p, sl_t, sl_r = wl.proofs[:S * 2336], wl.targets[:S * n * 256], wl.trusteds[:S * n * 48]
+    a = time.perf_counter()
+    o_elems, o_reps = oc.witness_batch(KIND_SKIP, S, sl_p, sl_t, sl_r, n, b"celestia", 100800, n_threads=1)
+    t1 = time.perf_counter() - a
+    t1c = oc.witness_pool_seconds(KIND_SKIP, S, sl_p, sl_t, sl_r, n, b"celestia", 100800, 1, 1)   # compute only, like the pool
+    cores, cores_note = usable_cores()
+    rep_all = max(1, (16 * cores + P - 1) // P)            # >= 16 proofs per thread
+    tn = min(oc.witness_pool_seconds(KIND_SKIP, P, wl.proofs, wl.targets, wl.trusteds, n, b"celestia", 100800, rep_all, cores) for _ in range(2))
+    per_proof_1, per_proof_n = t1c / S, tn / (P * rep_all)
+    # parity of the timed GPU output against the oracle on the same sample
+    run(ctx, 1)
+    torch.cuda.synchronize(dev)
+    g = d_out[:S, :count].cpu().numpy().view(np.uint64)
+    result["parity_vs_oracle"] = {"proofs_checked": S, "bit_exact": bool(np.array_equal(g, o_elems))}
+    result["cpu_baseline"] = {
+        "value": round(1e3 * t1 / S, 4), "unit": "ms", "cores": 1, "kind": "port",
+        "sample": f"{S} proofs x N={n} ({S * n} validator lanes) of the timed workload, 1 pass, oracle/c single thread, full witness rows written",
+        "compute_only_ms": round(1e3 * per_proof_1, 4),
+        "all_cores": {"value": round(1e3 * per_proof_n, 5), "unit": "ms", "cores": cores, "cores_note": cores_note,
+                      "sample": f"{P * rep_all} proofs ({rep_all} x the batch) dealt round-robin to a persistent pool of {cores} threads "
+                                f"({P * rep_all // cores} proofs per thread), compute only, best of 2",
+                      "speedup_vs_1_thread": round(per_proof_1 / per_proof_n, 1), "scaling_efficiency": round(per_proof_1 / per_proof_n / cores, 3)}}
+    ossl = openssl_verify_us(wl, n)
+    if ossl is not None:
+        result["cpu_baseline"]["openssl_evp_digestverify"] = ossl
+
+
+def usable_cores():
+    """Host threads this process can really run at once: the smaller of the affinity mask and the cgroup CPU quota (the GPU boxes report
+    256 logical CPUs and grant 16 of them: beyond the quota more threads only get throttled -- measured 15.9x at 16 threads, 11x at 256)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"os.cpu_count() = {os.cpu_count()}, affinity = {n}"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(quota) // int(period))
+            note += f", cgroup cpu.max = {quota}/{period} -> {q} CPUs"
+            n = min(n, q)
+    except (OSError, ValueError):
+        try:
+            q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                note += f", cfs quota {q}/{per} -> {max(1, q // per)} CPUs"
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n, note
+
+
+def openssl_verify_us(wl, n, budget_s=2.0):
+    """SURVEY 8(d)'s optional independent datapoint: OpenSSL's Ed25519 verification (EVP_DigestVerify) of the signed lanes of the
+    workload, one thread.  Verification only -- none of the witness values -- so it is a lower bound for any host path."""
+    try:
+        import ctypes as C
+        from tendermintx_amd import synth
+        L = synth._libcrypto()
+        L.EVP_PKEY_new_raw_public_key.restype = C.c_void_p
+        L.EVP_PKEY_new_raw_public_key.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_size_t]
+        L.EVP_DigestVerifyInit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.EVP_DigestVerify.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        lanes = []
+        for i in range(min(len(wl.targets) // 256, 4 * n)):
+            r = wl.targets[256 * i:256 * (i + 1)]
+            if r[223] & 1:
+                lanes.append((r[:32], r[32:96], r[96:96 + int.from_bytes(r[220:222], "little")]))
+        keys = [L.EVP_PKEY_new_raw_public_key(synth.EVP_PKEY_ED25519, None, pk, 32) for pk, _, _ in lanes]
+        done, ok, a = 0, 0, time.perf_counter()
+        while time.perf_counter() - a < budget_s:
+            for k, (_, sig, msg) in zip(keys, lanes):
+                c = L.EVP_MD_CTX_new()
+                L.EVP_DigestVerifyInit(c, None, None, None, k)
+                ok += L.EVP_DigestVerify(c, sig, 64, msg, len(msg)) == 1
+                L.EVP_MD_CTX_free(c)
+            done += len(lanes)
+        dt = time.perf_counter() - a
+        for k in keys:
+            L.EVP_PKEY_free(k)
+        if ok != done:
+            return None
+        return {"us_per_verify": round(1e6 * dt / done, 2), "ms_per_proof_equivalent": round(1e3 * dt / done * n, 3), "cores": 1, "verifies": done,
+                "note": "signature verification only, through ctypes (a few hundred ns of call overhead per verify); not a witness"}
+    except Exception:  # no libcrypto, or an API mismatch: the datapoint is optional
+        return None
 
 
 if __name__ == "__main__":

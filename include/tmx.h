@@ -16,7 +16,10 @@
  *
  * Conventions: every function returns 0 on success or a negative tmx_status; nothing throws across the ABI;
  * the caller owns all buffers passed in; the library never keeps caller pointers after returning; a tmx_ctx is
- * not thread-safe (use one per thread, they are independent: one HIP stream each).
+ * not thread-safe (use one per thread).  Contexts of one device share three internal side streams (the GPU runs four hardware queues:
+ * DESIGN.md section 3) and each context owns ONE set of scratch buffers and join events, reused by every call: consecutive *_device calls
+ * on one context must be stream-ordered -- the same stream, or an explicit dependency from the end of one call to the start of the next.
+ * The host-buffer entry points block until their results are in host memory, so they are ordered by construction.
  */
 #ifndef TMX_H
 #define TMX_H
@@ -124,7 +127,7 @@ typedef struct tmx_ctx tmx_ctx;
 
 /* names of the kernels timed by tmx_last_kernel_ms, in launch order */
 #define TMX_N_KERNELS 4
-#define TMX_K_EDDSA 0     /* per-validator Ed25519 (k_ed_pre, k_ed_mul, k_ed_fin): SHA-512, decode, s*B, h*A, R+hA, affine */
+#define TMX_K_EDDSA 0     /* per-validator Ed25519 (k_ed_dedup, k_ed_keys, k_ed_tab_x, k_ed_phase1, k_ed_mul_x, k_ed_fin): SHA-512, decode, s*B, h*A, R+hA, affine */
 #define TMX_K_PROOF 1     /* k_proof on the context's side stream, concurrent with the EdDSA kernels: marshal + SHA-256 leaves +
                              Merkle trees + header proofs + NxN match + tallies */
 #define TMX_K_VERDICT 2   /* join: wait for k_proof, merge the per-lane EdDSA verdicts (k_verdict) */
@@ -155,12 +158,30 @@ int32_t tmx_witness_batch(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const t
                           const tmx_hashfield_rec* trusteds /*[n_proofs][n_max], NULL for step*/, uint64_t* out_elems,
                           uint64_t cap_elems, tmx_report* reports);
 
+/* ---- host-buffer entry point with a section selection and a transfer format.  A hint body only needs H (43 % of a skip row at
+ * N = 128: what SkipOffchainInputs::hint writes to its output stream, skip.rs:85-100), and every element of this witness is < 2^32
+ * (a bit, a byte, a u32 limb), so a PCIe-bound caller can fetch it as u32 and widen with F::from_canonical_u32 on its side.
+ * out receives n_proofs DENSE rows of tmx_out_row_elems(kind, n_max, sections) elements of 8 (TMX_OUT_U64) or 4 (TMX_OUT_U32) bytes;
+ * with both sections selected a row is H then D.  Sections that are not selected are not serialized on the device either. */
+#define TMX_SEC_HINT 1u
+#define TMX_SEC_DERIVED 2u
+#define TMX_SEC_ALL 3u
+#define TMX_OUT_U64 0u
+#define TMX_OUT_U32 1u
+uint64_t tmx_out_row_elems(int32_t kind, uint32_t n_max, uint32_t sections);
+int32_t tmx_witness_batch_opts(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const tmx_proof_rec* proofs,
+                               const tmx_validator_rec* targets, const tmx_hashfield_rec* trusteds /*NULL for step*/, uint32_t sections,
+                               uint32_t format, void* out, uint64_t cap_bytes, tmx_report* reports);
+
 /* ---- device-resident entry point: inputs already in HBM, outputs stay in HBM.  All pointers are device
  * pointers of the context's device; `hip_stream` is the hipStream_t to enqueue on, used exactly as passed (NULL = the HIP
  * default stream; tmx_ctx_stream() = the context's own stream).  Asynchronous: returns after enqueueing. */
 void* tmx_ctx_stream(tmx_ctx* ctx);
 int32_t tmx_witness_batch_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
                                  const void* d_trusteds, void* d_out_elems, void* d_reports, void* hip_stream);
+/* the same with a section selection: rows keep tmx_elem_stride(), sections that are not selected are left unwritten */
+int32_t tmx_witness_batch_device_sections(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
+                                          const void* d_trusteds, void* d_out_elems, void* d_reports, void* hip_stream, uint32_t sections);
 /* The two halves of the call above, for the validator-sharded single-proof mode (BASELINE config 5): each GPU runs
  * k_eddsa on its slice of lanes, the 448-B lane records are exchanged (one RCCL all-gather), then k_proof + k_serialize
  * run on the reassembled records.  d_ed_out / d_ed: TMX ED records, 448 B per lane (layout at tmx_eddsa_lanes). */

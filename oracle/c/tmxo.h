@@ -80,6 +80,10 @@ int tmxo_witness_batch(int kind, uint32_t n_proofs, const uint8_t* proof_recs, c
                        const uint8_t* trusted_recs, uint32_t n, const uint8_t* chain_id, uint32_t chain_id_len,
                        uint64_t skip_max, uint64_t* out, tmxo_report* reps, uint32_t n_threads);
 
+/* CPU baseline: persistent pool of n_threads workers over a virtual batch of n_proofs * repeat proofs, compute only; wall seconds */
+double tmxo_witness_pool_seconds(int kind, uint32_t n_proofs, const uint8_t* proof_recs, const uint8_t* target_recs, const uint8_t* trusted_recs,
+                                 uint32_t n, const uint8_t* chain_id, uint32_t chain_id_len, uint64_t skip_max, uint32_t repeat, uint32_t n_threads);
+
 /* ---- Goldilocks NTT / coset LDE (tmxo_ntt.c; parity unpinned against plonky2, see the file header) */
 uint64_t tmxo_gl_pow(uint64_t b, uint64_t e);
 uint64_t tmxo_gl_root(uint32_t log_n);

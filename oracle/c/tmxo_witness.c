@@ -13,10 +13,12 @@
  *   chain id / height verify.rs:180-222, shared.rs:169-207     header proofs    circuits/input/tendermint_utils.rs:214-393
  * Layout of D and of the check bits: DESIGN.md "Witness layout".
  */
+#define _POSIX_C_SOURCE 200809L /* pthread barriers, clock_gettime (the CPU-baseline pool) */
 #include "tmxo.h"
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------ encodings + Merkle */
 void tmxo_varint9(uint64_t v, uint8_t out[9]) {
@@ -412,4 +414,42 @@ int tmxo_witness_batch(int kind, uint32_t n_proofs, const uint8_t* proof_recs, c
   for (uint32_t k = 0; k < n_threads; k++) { if (n_threads > 1) pthread_join(th[k], NULL); if (jobs[k].rc) rc = jobs[k].rc; }
   free(th); free(jobs);
   return rc;
+}
+
+/* CPU baseline with a persistent pool (bench.py `cpu_baseline.all_cores`): n_threads workers are created once, meet at a barrier, and
+ * worker k then computes proofs k, k + T, k + 2T, ... of a virtual batch of n_proofs * repeat proofs (record index modulo n_proofs),
+ * compute only (no element output).  Returns the wall seconds from the barrier to the last worker's end; thread creation is outside. */
+typedef struct {
+  int kind; uint32_t k, T, n_proofs, total, n; const uint8_t *p, *t, *r, *cid; uint32_t cid_len; uint64_t skip_max; pthread_barrier_t* bar; int rc;
+} pjob;
+static void* pool_worker(void* arg) {
+  pjob* j = (pjob*)arg;
+  pthread_barrier_wait(j->bar);
+  for (uint32_t v = j->k; v < j->total; v += j->T) {
+    const uint32_t i = v % j->n_proofs;
+    int rc = tmxo_witness(j->kind, j->p + (size_t)TMXO_REC_PROOF * i, j->t + (size_t)TMXO_REC_VALIDATOR * j->n * i,
+                          j->r ? j->r + (size_t)TMXO_REC_HASHFIELD * j->n * i : NULL, j->n, j->cid, j->cid_len, j->skip_max, NULL, NULL);
+    if (rc) j->rc = rc;
+  }
+  return NULL;
+}
+double tmxo_witness_pool_seconds(int kind, uint32_t n_proofs, const uint8_t* proof_recs, const uint8_t* target_recs, const uint8_t* trusted_recs,
+                                 uint32_t n, const uint8_t* chain_id, uint32_t chain_id_len, uint64_t skip_max, uint32_t repeat, uint32_t n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads); pjob* jobs = (pjob*)malloc(sizeof(pjob) * n_threads);
+  pthread_barrier_t bar;
+  pthread_barrier_init(&bar, NULL, n_threads + 1);
+  for (uint32_t k = 0; k < n_threads; k++) {
+    jobs[k] = (pjob){kind, k, n_threads, n_proofs, n_proofs * repeat, n, proof_recs, target_recs, trusted_recs, chain_id, chain_id_len, skip_max, &bar, 0};
+    pthread_create(&th[k], NULL, pool_worker, &jobs[k]);
+  }
+  struct timespec a, b;
+  pthread_barrier_wait(&bar);
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  int rc = 0;
+  for (uint32_t k = 0; k < n_threads; k++) { pthread_join(th[k], NULL); if (jobs[k].rc) rc = jobs[k].rc; }
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  pthread_barrier_destroy(&bar);
+  free(th); free(jobs);
+  return rc ? -1.0 : (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
 }

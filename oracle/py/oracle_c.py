@@ -163,6 +163,18 @@ def witness_batch(kind, n_proofs, proof_recs, target_recs, trusted_recs, n, chai
     return (out.reshape(n_proofs, ec) if want_out else None), [_rep(r) for r in reps]
 
 
+def witness_pool_seconds(kind, n_proofs, proof_recs, target_recs, trusted_recs, n, chain_id, skip_max, repeat, n_threads):
+    """CPU baseline: persistent pthread pool, proofs dealt round-robin, compute only; returns wall seconds for n_proofs * repeat proofs."""
+    L = lib()
+    L.tmxo_witness_pool_seconds.restype = C.c_double
+    t = L.tmxo_witness_pool_seconds(kind, C.c_uint32(n_proofs), bytes(proof_recs), bytes(target_recs), bytes(trusted_recs) if trusted_recs else None,
+                                    C.c_uint32(n), bytes(chain_id), C.c_uint32(len(chain_id)), C.c_uint64(skip_max), C.c_uint32(repeat),
+                                    C.c_uint32(n_threads))
+    if t < 0:
+        raise RuntimeError("tmxo_witness_pool_seconds failed")
+    return float(t)
+
+
 # ---- Goldilocks NTT / coset LDE (oracle/c/tmxo_ntt.c)
 GL_P = 2**64 - 2**32 + 1
 

@@ -14,6 +14,7 @@ FLAG_SIGNED, FLAG_PRESENT = 1, 2
 N_KERNELS = 4
 KERNEL_NAMES = ("k_eddsa", "k_proof", "k_verdict", "k_serialize")
 ED_STRIDE = 448
+SEC_HINT, SEC_DERIVED, SEC_ALL = 1, 2, 3   # TMX_SEC_*
 
 
 class ValidatorRec(C.Structure):
@@ -122,6 +123,12 @@ def lib():
         f.argtypes = [C.c_int32, C.c_uint32]
     L.tmx_witness_batch.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_uint64, C.c_void_p]
+    L.tmx_out_row_elems.restype = C.c_uint64
+    L.tmx_out_row_elems.argtypes = [C.c_int32, C.c_uint32, C.c_uint32]
+    L.tmx_witness_batch_opts.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                         C.c_void_p, C.c_uint64, C.c_void_p]
+    L.tmx_witness_batch_device_sections.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_uint32]
     L.tmx_witness_batch_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]
     L.tmx_ntt_goldilocks_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]

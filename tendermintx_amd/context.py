@@ -82,6 +82,34 @@ class Context:
         elems = out.reshape(n, stride)[:, :count] if want_elems else None
         return elems, [r.as_dict() for r in reps]
 
+    def witness_batch_opts(self, kind, proofs, targets, trusteds=None, sections=_lib.SEC_ALL, fmt="u64", out=None):
+        """tmx_witness_batch_opts: DENSE rows of the selected sections (_lib.SEC_HINT / SEC_DERIVED / SEC_ALL) as np.uint64 ("u64") or
+        np.uint32 ("u32": every element of this witness is < 2^32).  Returns (array [n, row_elems], [report dict])."""
+        n = len(proofs) // 2336
+        assert len(proofs) == n * 2336 and len(targets) == n * self.n_max * 256
+        if kind == KIND_SKIP:
+            assert trusteds is not None and len(trusteds) == n * self.n_max * 48
+        dt = np.uint32 if fmt == "u32" else np.uint64
+        row = int(self._L.tmx_out_row_elems(kind, self.n_max, sections))
+        if out is None:
+            out = np.zeros(n * row, dtype=dt)
+        else:
+            assert out.flags["C_CONTIGUOUS"] and out.nbytes >= n * row * np.dtype(dt).itemsize
+            out = out.reshape(-1).view(dt)[:n * row]
+        reps = (Report * n)()
+        st = self._L.tmx_witness_batch_opts(self._h, kind, n, bytes(proofs), bytes(targets), bytes(trusteds) if trusteds else None, sections,
+                                            1 if fmt == "u32" else 0, out.ctypes.data, out.nbytes, reps)
+        check(st, self._h)
+        return out.reshape(n, row), [r.as_dict() for r in reps]
+
+    def witness_batch_hint(self, kind, proofs, targets, trusteds=None, out=None, fmt="u32"):
+        """Only the hint section H of every row (what the reference's hint writes to its output stream), narrowed to u32 by default."""
+        return self.witness_batch_opts(kind, proofs, targets, trusteds, _lib.SEC_HINT, fmt, out)
+
+    def witness_batch_device_sections(self, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports, sections, stream=None):
+        check(self._L.tmx_witness_batch_device_sections(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports,
+                                                        self._stream(stream), sections), self._h)
+
     def valid_skip_batch(self, start, n_start, targets, n_targets, sigs, n_sigs):
         """is_valid_skip for len(n_targets) candidates.  start: bytes [n_max x 32]; targets, sigs: bytes [n_cand x n_max x 32].
         Returns (valid [bool], shared power [int], total power [int])."""

@@ -72,6 +72,7 @@ struct Program {
   std::vector<uint32_t> seam_waves;  // indices of the spans that straddle a boundary (0xff entries of wave_sec)
   std::vector<uint8_t> wave_sec;  // per sp.span-element span of a row: its section, or 0xff if it straddles a boundary / the row end
   uint32_t hint_elems;
+  uint32_t mask_hint = 0, mask_derived = 0;  // sections of H / of D (tmx_witness_batch_opts: a caller may ask for one of them only)
 };
 
 Program build_program(int kind, uint32_t n) {
@@ -191,6 +192,7 @@ Program build_program(int kind, uint32_t n) {
   L.u32(PF_OFF_ALLOK);
   add_section((uint32_t)L.v.size() - mark, 1, mark, SEC_LUT, SRC_PF, 3);
   P.mask_tail |= 1u << 31;  // boundary waves are written last, when every source is ready
+  for (uint32_t k = 0; k < P.sp.n_sections; k++) (P.sp.sec[k].elem_start < P.hint_elems ? P.mask_hint : P.mask_derived) |= 1u << k;
 
   P.sp.elem_count = elem;
   P.sp.elem_stride = (elem + 1) & ~1u;
@@ -261,6 +263,9 @@ struct tmx_ctx {
   // staging for the host-buffer entry points
   void *d_in_proofs = nullptr, *d_in_targets = nullptr, *d_in_trusteds = nullptr, *d_out = nullptr;
   uint64_t d_out_elems = 0;
+  void* d_pack = nullptr;  // dense / narrowed rows for tmx_witness_batch_opts (allocated on first use)
+  uint64_t d_pack_bytes = 0;
+  uint32_t sections = 3;  // TMX_SEC_* of the batch being enqueued
   // Goldilocks NTT: twiddle tables per transform size (built on first use), scratch for the four-step split / LDE
   void* d_ntt_w[TMX_NTT_MAX_LOG + 1] = {};
   void* d_ntt_tmp = nullptr;
@@ -308,6 +313,8 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   const Program& prog = c->prog[kind];
   auto serialize = [&](uint32_t mask, hipStream_t on) -> int32_t {
     if (!d_out_elems) return TMX_OK;
+    // (sections the caller did not ask for are not written; the seam spans are few and always written)
+    mask &= ((c->sections & TMX_SEC_HINT) ? prog.mask_hint : 0u) | ((c->sections & TMX_SEC_DERIVED) ? prog.mask_derived : 0u) | (1u << 31);
     int r = launch_serialize(prog.sp, src, c->d_lut[kind], c->d_wave_sec[kind], c->d_seams[kind], (uint32_t)prog.seam_waves.size(), n_proofs,
                              d_out_elems, mask, on);
     if (r) return fail(c, TMX_ERR_HIP, std::string("k_serialize launch: ") + hipGetErrorString((hipError_t)r));
@@ -644,7 +651,7 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   }
   void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_owner_of, c->d_uid_of_owner, c->d_owners, c->d_keyrec,
                   c->d_anchors, c->d_keytab, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
-                  c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out};
+                  c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out, c->d_pack};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (void* w : c->d_ntt_w)
@@ -885,15 +892,24 @@ static int32_t ensure_staging(tmx_ctx* c) {
   return TMX_OK;
 }
 
-int32_t tmx_witness_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const tmx_proof_rec* proofs, const tmx_validator_rec* targets,
-                          const tmx_hashfield_rec* trusteds, uint64_t* out_elems, uint64_t cap_elems, tmx_report* reports) {
+// Host-buffer path shared by tmx_witness_batch (full rows of tmx_elem_stride u64) and tmx_witness_batch_opts (dense rows of the selected
+// sections, u64 or u32): H2D of the records, the batch on the context's stream, D2H of what the caller asked for.
+static int32_t witness_batch_host(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const tmx_proof_rec* proofs, const tmx_validator_rec* targets,
+                                  const tmx_hashfield_rec* trusteds, bool opts, uint32_t sections, uint32_t format, void* out, uint64_t cap_bytes,
+                                  tmx_report* reports) {
   if (!c || !proofs || !targets || (kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP)) return TMX_ERR_BAD_ARG;
   if (kind == TMX_KIND_SKIP && !trusteds) return fail(c, TMX_ERR_BAD_ARG, "skip needs the trusted hash fields");
+  if (opts && ((sections & ~(uint32_t)TMX_SEC_ALL) || sections == 0 || (format != TMX_OUT_U64 && format != TMX_OUT_U32)))
+    return fail(c, TMX_ERR_BAD_ARG, "sections must be a non-empty subset of TMX_SEC_ALL and format TMX_OUT_U64 or TMX_OUT_U32");
   if (n_proofs == 0) return TMX_OK;
   if (n_proofs > c->cfg.max_batch) return fail(c, TMX_ERR_CAPACITY, "n_proofs exceeds the context's max_batch");
   const uint32_t n = c->cfg.n_max;
-  const uint64_t stride = tmx_elem_stride(kind, n), count = tmx_elem_count(kind, n);
-  if (out_elems && cap_elems < (uint64_t)(n_proofs - 1) * stride + count) return fail(c, TMX_ERR_CAPACITY, "out_elems too small");
+  const uint64_t stride = tmx_elem_stride(kind, n), count = tmx_elem_count(kind, n), hint = tmx_hint_elem_count(kind, n);
+  const uint64_t first = opts && sections == TMX_SEC_DERIVED ? hint : 0;
+  const uint64_t row_elems = opts ? tmx_out_row_elems(kind, n, sections) : count;
+  const uint64_t esz = opts && format == TMX_OUT_U32 ? 4 : 8;
+  if (out && opts && cap_bytes < (uint64_t)n_proofs * row_elems * esz) return fail(c, TMX_ERR_CAPACITY, "out buffer too small");
+  if (out && !opts && cap_bytes < ((uint64_t)(n_proofs - 1) * stride + count) * 8) return fail(c, TMX_ERR_CAPACITY, "out_elems too small");
   for (uint32_t p = 0; p < n_proofs; p++)  // reference input/mod.rs:439-444, 338-342
     if (proofs[p].nb_a > n || proofs[p].nb_b > n) return fail(c, TMX_ERR_SET_TOO_LARGE, "validator set larger than VALIDATOR_SET_SIZE_MAX");
   int32_t st = ensure_staging(c);
@@ -903,17 +919,60 @@ int32_t tmx_witness_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const tmx
   HIPCK(c, hipMemcpyAsync(c->d_in_targets, targets, lanes * sizeof(tmx_validator_rec), hipMemcpyHostToDevice, c->stream));
   if (kind == TMX_KIND_SKIP)
     HIPCK(c, hipMemcpyAsync(c->d_in_trusteds, trusteds, lanes * sizeof(tmx_hashfield_rec), hipMemcpyHostToDevice, c->stream));
+  c->sections = opts ? sections : (uint32_t)TMX_SEC_ALL;
   st = tmx_witness_batch_device(c, kind, n_proofs, c->d_in_proofs, c->d_in_targets, kind == TMX_KIND_SKIP ? c->d_in_trusteds : nullptr,
-                                out_elems ? c->d_out : nullptr, c->d_reports, c->stream);
+                                out ? c->d_out : nullptr, c->d_reports, c->stream);
+  c->sections = TMX_SEC_ALL;
   if (st) return st;
-  if (out_elems) {
+  if (out && !opts) {
     // rows are stride apart on the device; the last row is copied without its pad element
     const size_t bytes = ((size_t)(n_proofs - 1) * stride + count) * 8;
-    HIPCK(c, hipMemcpyAsync(out_elems, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+  } else if (out) {
+    const size_t bytes = (size_t)n_proofs * row_elems * esz;
+    const void* src = c->d_out;
+    if (!(first == 0 && row_elems == stride && esz == 8)) {  // dense rows of the selection, u64 or narrowed to u32, then ONE contiguous copy
+      if (c->d_pack_bytes < bytes) {
+        if (c->d_pack) { HIPCK(c, hipStreamSynchronize(c->stream)); HIPCK(c, hipFree(c->d_pack)); c->d_pack = nullptr; c->d_pack_bytes = 0; }
+        const size_t want = (size_t)c->cfg.max_batch * (size_t)(tmx_elem_count(TMX_KIND_SKIP, n) > tmx_elem_count(TMX_KIND_STEP, n) ? tmx_elem_count(TMX_KIND_SKIP, n) : tmx_elem_count(TMX_KIND_STEP, n)) * 8;
+        HIPCK(c, hipMalloc(&c->d_pack, want));
+        c->d_pack_bytes = want;
+      }
+      int rc = launch_pack_rows(c->d_out, c->d_pack, (uint32_t)stride, (uint32_t)first, (uint32_t)row_elems, n_proofs, esz == 4, c->stream);
+      if (rc) return fail(c, TMX_ERR_HIP, std::string("k_pack_rows launch: ") + hipGetErrorString((hipError_t)rc));
+      src = c->d_pack;
+    }
+    HIPCK(c, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->stream));
   }
   if (reports) HIPCK(c, hipMemcpyAsync(reports, c->d_reports, (size_t)n_proofs * sizeof(tmx_report), hipMemcpyDeviceToHost, c->stream));
   HIPCK(c, hipStreamSynchronize(c->stream));
   return TMX_OK;
+}
+
+int32_t tmx_witness_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const tmx_proof_rec* proofs, const tmx_validator_rec* targets,
+                          const tmx_hashfield_rec* trusteds, uint64_t* out_elems, uint64_t cap_elems, tmx_report* reports) {
+  return witness_batch_host(c, kind, n_proofs, proofs, targets, trusteds, false, TMX_SEC_ALL, TMX_OUT_U64, out_elems, cap_elems * 8, reports);
+}
+
+int32_t tmx_witness_batch_opts(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const tmx_proof_rec* proofs, const tmx_validator_rec* targets,
+                               const tmx_hashfield_rec* trusteds, uint32_t sections, uint32_t format, void* out, uint64_t cap_bytes,
+                               tmx_report* reports) {
+  return witness_batch_host(c, kind, n_proofs, proofs, targets, trusteds, true, sections, format, out, cap_bytes, reports);
+}
+
+uint64_t tmx_out_row_elems(int32_t kind, uint32_t n, uint32_t sections) {
+  const uint64_t count = tmx_elem_count(kind, n), hint = tmx_hint_elem_count(kind, n);
+  if (count == 0) return 0;
+  return (sections & TMX_SEC_ALL) == TMX_SEC_ALL ? count : (sections & TMX_SEC_HINT) ? hint : (sections & TMX_SEC_DERIVED) ? count - hint : 0;
+}
+
+int32_t tmx_witness_batch_device_sections(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
+                                          const void* d_trusteds, void* d_out_elems, void* d_reports, void* hip_stream, uint32_t sections) {
+  if (!c || (sections & ~(uint32_t)TMX_SEC_ALL) || sections == 0) return TMX_ERR_BAD_ARG;
+  c->sections = sections;
+  const int32_t st = tmx_witness_batch_device(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out_elems, d_reports, hip_stream);
+  c->sections = TMX_SEC_ALL;
+  return st;
 }
 
 int32_t tmx_skip_witness(tmx_ctx* c, const tmx_proof_rec* proof, const tmx_validator_rec* target, const tmx_hashfield_rec* trusted,

@@ -137,28 +137,38 @@ def _sign_bytes(chain_id, height, round_, block_hash, psh, secs, nanos):
     return _varint(len(body)) + body
 
 
-class Workload:
-    """n_proofs independent skip (kind 0) or step (kind 1) inputs over one synthetic validator set."""
+class _ValidatorSet:
+    """One synthetic validator set: keys, mocha-like powers (descending), its RFC-6962 root, and the trusted set derived from it
+    (rotation by 3, every 10th validator replaced by a fresh key)."""
 
-    def __init__(self, kind, n_max, n_proofs, nb_validators=None, chain_id=b"celestia", seed=0x544D58, signed_permille=1000,
-                 rounds=(0, 0, 0, 3), skip_distance=1000):
-        nb = n_max if nb_validators is None else nb_validators
-        assert 1 <= nb <= n_max and len(chain_id) <= 13
-        dpk, dsig = dummy_lane()
-        keys = [_Key(_h(b"tmx-key", seed, i)) for i in range(nb)]
+    def __init__(self, nb, seed):
+        self.keys = [_Key(_h(b"tmx-key", seed, i)) for i in range(nb)]
         fresh = [_Key(_h(b"tmx-new", seed, i)) for i in range(nb)]
         step = max(1, 29_000_000 // nb)
-        powers = [30_000_000 - i * step - (int.from_bytes(_h(b"tmx-pow", seed, i)[:4], "little") % min(step, 1000)) for i in range(nb)]
-        # target set (CometBFT order: power descending)
-        tgt_leaf = [_leaf(_validator_bytes(keys[i].pub, powers[i])) for i in range(nb)]
-        tgt_root = _root(tgt_leaf)
-        # trusted set: rotation of the target set, every 10th validator replaced by a fresh key
+        self.powers = [30_000_000 - i * step - (int.from_bytes(_h(b"tmx-pow", seed, i)[:4], "little") % min(step, 1000)) for i in range(nb)]
+        self.root = _root([_leaf(_validator_bytes(self.keys[i].pub, self.powers[i])) for i in range(nb)])
         tr_idx = [(j + 3) % nb for j in range(nb)]
-        tr_pk = [fresh[j].pub if j % 10 == 9 else keys[tr_idx[j]].pub for j in range(nb)]
-        tr_pow = [powers[tr_idx[j]] for j in range(nb)]
-        tr_root = _root([_leaf(_validator_bytes(tr_pk[j], tr_pow[j])) for j in range(nb)])
+        self.tr_pk = [fresh[j].pub if j % 10 == 9 else self.keys[tr_idx[j]].pub for j in range(nb)]
+        self.tr_pow = [self.powers[tr_idx[j]] for j in range(nb)]
+        self.tr_root = _root([_leaf(_validator_bytes(self.tr_pk[j], self.tr_pow[j])) for j in range(nb)])
+
+
+class Workload:
+    """n_proofs independent skip (kind 0) or step (kind 1) inputs over `n_sets` synthetic validator sets (proof p uses set p % n_sets).
+
+    signed_permille: every present validator signs with that probability; `ensure_two_thirds` re-draws a proof's mask (next nonce)
+    until the signers hold more than 2/3 of the power, as SURVEY 8(d) prescribes for the measured workloads."""
+
+    def __init__(self, kind, n_max, n_proofs, nb_validators=None, chain_id=b"celestia", seed=0x544D58, signed_permille=1000,
+                 rounds=(0, 0, 0, 3), skip_distance=1000, n_sets=1, ensure_two_thirds=False):
+        nb = n_max if nb_validators is None else nb_validators
+        assert 1 <= nb <= n_max and len(chain_id) <= 13 and n_sets >= 1
+        dpk, dsig = dummy_lane()
+        sets = [_ValidatorSet(nb, seed if k == 0 else seed + 7919 * k) for k in range(min(n_sets, n_proofs))]
         proofs, targets, trusteds = [], [], []
         for p in range(n_proofs):
+            vs = sets[p % len(sets)]
+            keys, powers, tgt_root, tr_root, tr_pk, tr_pow = vs.keys, vs.powers, vs.root, vs.tr_root, vs.tr_pk, vs.tr_pow
             round_ = rounds[p % len(rounds)]
             block_a = 2_000_000 + 10 * p
             block_b = block_a + (skip_distance if kind == 0 else 1)
@@ -174,16 +184,24 @@ class Workload:
             hash_a = _root([_leaf(l) for l in ha])
             psh = _h(b"tmx-psh", seed, block_b)
             proofs.append(struct.pack("<QQ32sQII", block_a, block_b, hash_b, round_, nb, nb if kind == 0 else 0) + _pack_header(ha) + _pack_header(hb))
+            nonce = 0
+            while True:
+                if nonce == 0:
+                    mask = [(int.from_bytes(_h(b"tmx-sgn", seed, p, i)[:4], "little") % 1000) < signed_permille for i in range(nb)]
+                else:
+                    mask = [(int.from_bytes(_h(b"tmx-sgn", seed, p, i, nonce)[:4], "little") % 1000) < signed_permille for i in range(nb)]
+                if not ensure_two_thirds or 3 * sum(pw for pw, m in zip(powers, mask) if m) > 2 * sum(powers):
+                    break
+                nonce += 1
             lanes = []
             for i in range(n_max):
                 if i < nb:
-                    signs = (int.from_bytes(_h(b"tmx-sgn", seed, p, i)[:4], "little") % 1000) < signed_permille
                     vlen = len(_validator_bytes(keys[i].pub, powers[i]))
-                    if signs:
+                    if mask[i]:
                         msg = _sign_bytes(chain_id, block_b, round_, hash_a, psh, secs + 13, 1 + (i * 7919 + p * 104729) % 999_999_999)
                         assert len(msg) <= 124
                         lanes.append(struct.pack("<32s64s124sHBBQ24x", keys[i].pub, keys[i].sign(msg), msg.ljust(124, b"\0"), len(msg), vlen, 3, powers[i]))
-                    else:
+                    else:  # BlockIDFlag absent or nil: the lane keeps key and power, carries the dummy signature (conversion.rs:98-114)
                         lanes.append(struct.pack("<32s64s124sHBBQ24x", keys[i].pub, dsig, bytes(124), 32, vlen, 2, powers[i]))
                 else:
                     lanes.append(struct.pack("<32s64s124sHBBQ24x", dpk, dsig, bytes(124), 32, 46, 0, 0))
@@ -196,7 +214,24 @@ class Workload:
                     else:
                         tl.append(struct.pack("<32sQBB6x", dpk, 0, 46, 0))
                 trusteds.append(b"".join(tl))
-        self.kind, self.n_max, self.n_proofs, self.nb, self.chain_id = kind, n_max, n_proofs, nb, chain_id
+        self.kind, self.n_max, self.n_proofs, self.nb, self.chain_id, self.n_sets = kind, n_max, n_proofs, nb, chain_id, len(sets)
         self.proofs, self.targets = b"".join(proofs), b"".join(targets)
         self.trusteds = b"".join(trusteds) if kind == 0 else None
-        self.expected_headers = [hashlib.sha256(b"").digest()] * 0  # filled lazily by callers that need it
+        self.describe = (f"{nb} validators in {n_max} lanes, {len(sets)} distinct validator set(s) per batch, "
+                         f"{signed_permille / 10:.0f}% signing" + (" (re-drawn until > 2/3)" if ensure_two_thirds else "") +
+                         f", rounds {{{','.join(str(r) for r in rounds)}}} cycling")
+
+
+def bench_workload(name, n_max, n_proofs, seed=0x544D58):
+    """The two measured skip workloads (bench.py, tools/profile_step.py).
+    survey8d: SURVEY 8(d) -- 100 validators in the 128 lanes (Celestia-real; N of N at other sizes), four distinct validator sets per
+              batch, Bernoulli(0.9) signing re-drawn until > 2/3 of the power signed, rounds {0,0,0,3}, trusted set = target set
+              rotated with 10 % of the keys replaced.
+    one_set:  the most deduplication-friendly batch (round 1's headline): ONE validator set for every proof, N of N, everybody signs."""
+    if name == "survey8d":
+        nb = 100 if n_max == 128 else n_max
+        return Workload(0, n_max, n_proofs, nb, chain_id=b"celestia", seed=seed, signed_permille=900, rounds=(0, 0, 0, 3), n_sets=4,
+                        ensure_two_thirds=True)
+    if name == "one_set":
+        return Workload(0, n_max, n_proofs, n_max, chain_id=b"celestia", seed=seed, signed_permille=1000, rounds=(0, 0, 0, 3))
+    raise ValueError(name)

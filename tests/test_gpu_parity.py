@@ -459,6 +459,41 @@ def test_set_too_large_and_capacity_errors(tmx):
         assert e.value.status == -2
 
 
+def test_section_selection_and_u32_transfer_format(tmx, oracle):
+    """tmx_witness_batch_opts: hint-only / derived-only / full rows, as u64 and narrowed to u32, are the same values as the full row
+    (every element of this witness is < 2^32); the device entry point with a section selection leaves the other section unwritten."""
+    import torch
+    from tendermintx_amd import _lib
+    from tendermintx_amd.synth import Workload
+    for kind, n, P in ((0, 32, 9), (1, 5, 3), (0, 128, 12)):
+        wl = Workload(kind, n, P, max(1, n - 3), chain_id=b"celestia", seed=31 + n, signed_permille=900)
+        want, oreps = oracle.witness_batch(kind, P, wl.proofs, wl.targets, wl.trusteds, n, b"celestia", 100800, n_threads=8)
+        assert int(want.max()) < 2**32
+        with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+            hint = ctx.hint_elem_count(kind)
+            for sections, lo, hi in ((_lib.SEC_HINT, 0, hint), (_lib.SEC_DERIVED, hint, want.shape[1]), (_lib.SEC_ALL, 0, want.shape[1])):
+                for fmt in ("u64", "u32"):
+                    got, reps = ctx.witness_batch_opts(kind, wl.proofs, wl.targets, wl.trusteds, sections, fmt)
+                    assert got.dtype == (np.uint32 if fmt == "u32" else np.uint64) and got.shape == (P, hi - lo)
+                    assert np.array_equal(got.astype(np.uint64), want[:, lo:hi]), (kind, n, sections, fmt)
+                    assert reps == oreps
+            got, _ = ctx.witness_batch_hint(kind, wl.proofs, wl.targets, wl.trusteds)
+            assert got.dtype == np.uint32 and np.array_equal(got.astype(np.uint64), want[:, :hint])
+            # device entry point, hint only: H is written, D keeps the caller's fill (apart from the few seam spans)
+            dev = torch.device("cuda", 0)
+            d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) if b else None for b in (wl.proofs, wl.targets, wl.trusteds)]
+            out = torch.full((P, ctx.elem_stride(kind)), -1, dtype=torch.int64, device=dev)
+            rep = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
+            ctx.witness_batch_device_sections(kind, P, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr() if d[2] is not None else None,
+                                              out.data_ptr(), rep.data_ptr(), _lib.SEC_HINT, 0)
+            torch.cuda.synchronize(dev)
+            o = out.cpu().numpy()
+            assert np.array_equal(o[:, :hint].view(np.uint64), want[:, :hint])
+            assert (o[:, hint:] == -1).mean() > 0.9
+            with pytest.raises(tmx.TmxError):
+                ctx.witness_batch_opts(kind, wl.proofs, wl.targets, wl.trusteds, 4, "u64")
+
+
 def test_device_path_flags_nb_above_n(tmx, oracle):
     """The device entry points cannot refuse nb > N before enqueueing (the records are in HBM): tmx_report.precond carries the host
     assert of input/mod.rs:439-444 / 338-342 instead, and the values follow the circuit (every lane enabled)."""

@@ -24,7 +24,7 @@ def group(name):
 
 
 res = {"source": f"tools/collect_profiles.sh: rocprofv3 --pmc passes (separate runs) over tools/profile_step.py, {nb} full batches each; per-batch = sum / {nb}",
-       "config": {"n_max": int(os.environ.get("N", "128")), "proofs_per_gpu": int(os.environ.get("P", "256"))},
+       "config": {"n_max": int(os.environ.get("N", "128")), "proofs_per_gpu": int(os.environ.get("P", "256")), "workload": os.environ.get("WORKLOAD", "survey8d")},
        "unit_note": "fetch_kb / write_kb: FETCH_SIZE / WRITE_SIZE (KB) per batch, uncorrected (MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by 2x; "
                     "the reads here are mostly 1- and 4-byte accesses).  valu_insts / salu_insts: wave-level instructions per batch.",
        "kernels": {}, "per_kernel": {}}

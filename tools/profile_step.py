@@ -10,11 +10,12 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from tendermintx_amd import Context  # noqa: E402
 from tendermintx_amd.context import KIND_SKIP  # noqa: E402
-from tendermintx_amd.synth import Workload  # noqa: E402
+from tendermintx_amd.synth import bench_workload  # noqa: E402
 
 P, n = int(os.environ.get("P", "256")), int(os.environ.get("N", "128"))
 WARM, STEPS = int(os.environ.get("WARM", "2")), int(os.environ.get("STEPS", "6"))
-w = Workload(KIND_SKIP, n, P, n, chain_id=b"celestia", seed=0x544D58)
+WORKLOAD = os.environ.get("WORKLOAD", "survey8d")  # bench.py's default workload
+w = bench_workload(WORKLOAD, n, P, seed=0x544D58)
 dev = torch.device("cuda:0")
 d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) for b in (w.proofs, w.targets, w.trusteds)]
 ctx = Context(n, b"celestia", 100800, device=0, max_batch=P)
@@ -29,5 +30,5 @@ def run(k):
 run(WARM)
 t0 = time.perf_counter()
 run(STEPS)
-print(f"profile_step: {1e3 * (time.perf_counter() - t0) / STEPS:.4f} ms/step over {STEPS} steps (+{WARM} warm), P={P} N={n}")
+print(f"profile_step: {1e3 * (time.perf_counter() - t0) / STEPS:.4f} ms/step over {STEPS} steps (+{WARM} warm), P={P} N={n} workload={WORKLOAD}")
 ctx.close()
