@@ -140,7 +140,8 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out);
 void tmx_ctx_destroy(tmx_ctx* ctx);
 const char* tmx_last_error(const tmx_ctx* ctx);
 
-/* number of Goldilocks elements of one witness, and the (even) row stride used in batched output */
+/* number of Goldilocks elements of one witness, and the row stride used in batched output (a multiple of 16 elements: rows start on a
+ * 128-byte line; the pad elements are written as zeros) */
 uint64_t tmx_elem_count(int32_t kind, uint32_t n_max);
 uint64_t tmx_elem_stride(int32_t kind, uint32_t n_max);
 /* offset and length of the hint section H (= VerifySkipVariable<N> / VerifyStepVariable<N> elements) in a row */
