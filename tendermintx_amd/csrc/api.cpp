@@ -73,11 +73,6 @@ struct Program {
   std::vector<uint8_t> wave_sec;  // per sp.span-element span of a row: its section, or 0xff if it straddles a boundary / the row end
   uint32_t hint_elems;
   uint32_t mask_hint = 0, mask_derived = 0;  // sections of H / of D (tmx_witness_batch_opts: a caller may ask for one of them only)
-  // second-generation serializer (layout.h): one descriptor per group of eight elements, slow groups listed per readiness class
-  bool v2 = true;
-  std::vector<uint32_t> gdesc;
-  std::vector<uint32_t> slow;  // group indices, class 0 (inputs) first ... class 3 (tail) last
-  uint32_t slow_off[5] = {0, 0, 0, 0, 0};
 };
 
 Program build_program(int kind, uint32_t n) {
@@ -204,10 +199,8 @@ Program build_program(int kind, uint32_t n) {
   P.sp.n = n;
   P.sp.tree_nodes = tn;
   P.lut = std::move(L.v);
-  const char* v1 = std::getenv("TMX_SER_V1");  // 1: the first-generation serializer (one LUT word and one source load per element)
-  P.v2 = !(v1 && v1[0] == '1');
-  const char* sp_env = std::getenv("TMX_SER_SPAN");  // first generation only; 256 measured best on MI355X
-  const uint32_t span = P.v2 ? SER2_SPAN : (sp_env && (std::atoi(sp_env) == 128 || std::atoi(sp_env) == 512) ? (uint32_t)std::atoi(sp_env) : 256u);
+  const char* sp_env = std::getenv("TMX_SER_SPAN");  // tuning knob; 256 measured best on MI355X
+  const uint32_t span = sp_env && (std::atoi(sp_env) == 128 || std::atoi(sp_env) == 512) ? (uint32_t)std::atoi(sp_env) : 256u;
   P.sp.span = span;
   for (uint32_t w = 0; w * span < P.sp.elem_stride; w++) {
     const uint32_t first = w * span, last = first + span - 1;
@@ -220,47 +213,6 @@ Program build_program(int kind, uint32_t n) {
     if (sec == 0xff) P.seam_waves.push_back(w);
     P.wave_sec.push_back(sec);
   }
-  if (!P.v2) return P;
-  P.seam_waves.clear();  // (second generation: the groups of those spans are on the slow lists)
-  // ---- group descriptors and slow lists
-  struct ESrc { int sec; bool bit; uint32_t rec, pos; };  // pos: bit position inside the record, most significant bit of byte 0 first
-  auto esrc = [&](uint32_t e) -> ESrc {
-    int si = 0;
-    for (uint32_t k = 1; k < P.sp.n_sections; k++) if (e >= P.sp.sec[k].elem_start) si = (int)k;
-    const Section& sc = P.sp.sec[si];
-    const uint32_t rel = e - sc.elem_start;
-    if (sc.kind != SEC_LUT) return {si, true, 0u, rel};  // tree nodes: plain bytes, eight big-endian bits each
-    const uint32_t lane = sc.n_lanes > 1 ? rel / sc.lane_elems : 0u, r = rel - lane * sc.lane_elems;
-    const uint32_t ent = P.lut[sc.lut_off + r], width = ent >> 27, fb = (ent >> 22) & 31u, aoff = ent & LUT_OFF_MASK;
-    if (width != W_BIT) return {si, false, lane, 0u};
-    return {si, true, lane, 8u * (aoff + (fb >> 3)) + (7u - (fb & 7u))};
-  };
-  const uint32_t cls_masks[4] = {P.mask_inputs, P.mask_proof, P.mask_final, P.mask_tail};
-  auto cls_of_sec = [&](int si) { for (int c = 0; c < 4; c++) if ((cls_masks[c] >> si) & 1u) return c; return 3; };
-  const uint32_t n_groups = P.sp.elem_stride / 8;
-  std::vector<uint32_t> slow_by_cls[4];
-  P.gdesc.assign(n_groups, 0u);
-  for (uint32_t g = 0; g < n_groups; g++) {
-    const uint32_t e0 = 8 * g;
-    bool fast = e0 + 7 < P.sp.elem_count && P.wave_sec[e0 / span] != 0xff;
-    int cls = -1;
-    ESrc first{};
-    for (uint32_t k = 0; k < 8 && e0 + k < P.sp.elem_count; k++) {
-      const ESrc x = esrc(e0 + k);
-      const int c = cls_of_sec(x.sec);
-      cls = cls < 0 ? c : (cls == c ? c : 3);  // a group over two readiness classes is written with the tail
-      if (k == 0) first = x;
-      if (!x.bit || x.sec != first.sec || x.rec != first.rec || x.pos != first.pos + k) fast = false;
-    }
-    if (fast && ((first.pos >> 3) > 0x7fffu || first.rec > 0x3ffu)) fast = false;
-    if (fast) P.gdesc[g] = gd_make(first.pos & 7u, first.rec, first.pos >> 3);
-    else slow_by_cls[cls < 0 ? 3 : cls].push_back(g);  // (cls < 0: a group of row padding only)
-  }
-  for (int c = 0; c < 4; c++) {
-    P.slow_off[c] = (uint32_t)P.slow.size();
-    P.slow.insert(P.slow.end(), slow_by_cls[c].begin(), slow_by_cls[c].end());
-  }
-  P.slow_off[4] = (uint32_t)P.slow.size();
   return P;
 }
 
@@ -290,8 +242,6 @@ struct tmx_ctx {
   void* d_lut[2] = {nullptr, nullptr};
   void* d_wave_sec[2] = {nullptr, nullptr};
   void* d_seams[2] = {nullptr, nullptr};
-  void* d_gdesc[2] = {nullptr, nullptr};
-  void* d_slow[2] = {nullptr, nullptr};
   void* d_table = nullptr;
   uint32_t base_w = 10, key_w = 6;
   void *d_qtable = nullptr, *d_pre = nullptr, *d_mulout = nullptr;
@@ -364,17 +314,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   auto serialize = [&](uint32_t mask, hipStream_t on) -> int32_t {
     if (!d_out_elems) return TMX_OK;
     // (sections the caller did not ask for are not written; the seam spans are few and always written)
-    const uint32_t sel = ((c->sections & TMX_SEC_HINT) ? prog.mask_hint : 0u) | ((c->sections & TMX_SEC_DERIVED) ? prog.mask_derived : 0u);
-    if (prog.v2) {
-      const uint32_t cls_masks[4] = {prog.mask_inputs, prog.mask_proof, prog.mask_final, prog.mask_tail};
-      uint32_t cls_bits = 0;
-      for (int k = 0; k < 4; k++) if (cls_masks[k] && (mask & cls_masks[k]) == cls_masks[k]) cls_bits |= 1u << k;
-      int r2 = launch_serialize2(prog.sp, src, c->d_gdesc[kind], c->d_wave_sec[kind], c->d_lut[kind], c->d_slow[kind], prog.slow_off, cls_bits, n_proofs,
-                                 d_out_elems, mask & sel, sel, on);
-      if (r2) return fail(c, TMX_ERR_HIP, std::string("k_serialize launch: ") + hipGetErrorString((hipError_t)r2));
-      return TMX_OK;
-    }
-    mask &= sel | (1u << 31);
+    mask &= ((c->sections & TMX_SEC_HINT) ? prog.mask_hint : 0u) | ((c->sections & TMX_SEC_DERIVED) ? prog.mask_derived : 0u) | (1u << 31);
     int r = launch_serialize(prog.sp, src, c->d_lut[kind], c->d_wave_sec[kind], c->d_seams[kind], (uint32_t)prog.seam_waves.size(), n_proofs,
                              d_out_elems, mask, on);
     if (r) return fail(c, TMX_ERR_HIP, std::string("k_serialize launch: ") + hipGetErrorString((hipError_t)r));
@@ -709,7 +649,7 @@ void tmx_ctx_destroy(tmx_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipDeviceSynchronize();
   }
-  void* bufs[] = {c->d_gdesc[0], c->d_gdesc[1], c->d_slow[0], c->d_slow[1], c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_owner_of, c->d_uid_of_owner, c->d_owners, c->d_keyrec,
+  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_owner_of, c->d_uid_of_owner, c->d_owners, c->d_keyrec,
                   c->d_anchors, c->d_keytab, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
                   c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out, c->d_pack};
   for (void* b : bufs)
@@ -781,18 +721,6 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     HIPCK(c, hipMemcpyAsync(c->d_lut[k], c->prog[k].lut.data(), c->prog[k].lut.size() * 4, hipMemcpyHostToDevice, c->side2));
     HIPCK(c, hipMalloc(&c->d_wave_sec[k], c->prog[k].wave_sec.size()));
     HIPCK(c, hipMemcpyAsync(c->d_wave_sec[k], c->prog[k].wave_sec.data(), c->prog[k].wave_sec.size(), hipMemcpyHostToDevice, c->side2));
-    if (c->prog[k].v2 && std::getenv("TMX_SER_STATS")) {
-      const Program& pr = c->prog[k];
-      std::fprintf(stderr, "tmx serializer kind %d n %u: %u elements, stride %u, %zu groups, slow groups by class %u/%u/%u/%u = %.2f %%\n", k, n,
-                   pr.sp.elem_count, pr.sp.elem_stride, pr.gdesc.size(), pr.slow_off[1] - pr.slow_off[0], pr.slow_off[2] - pr.slow_off[1],
-                   pr.slow_off[3] - pr.slow_off[2], pr.slow_off[4] - pr.slow_off[3], 100.0 * pr.slow.size() / pr.gdesc.size());
-    }
-    if (c->prog[k].v2) {
-      HIPCK(c, hipMalloc(&c->d_gdesc[k], c->prog[k].gdesc.size() * 4));
-      HIPCK(c, hipMemcpyAsync(c->d_gdesc[k], c->prog[k].gdesc.data(), c->prog[k].gdesc.size() * 4, hipMemcpyHostToDevice, c->side2));
-      HIPCK(c, hipMalloc(&c->d_slow[k], c->prog[k].slow.size() * 4 + 4));
-      HIPCK(c, hipMemcpyAsync(c->d_slow[k], c->prog[k].slow.data(), c->prog[k].slow.size() * 4, hipMemcpyHostToDevice, c->side2));
-    }
     HIPCK(c, hipMalloc(&c->d_seams[k], c->prog[k].seam_waves.size() * 4 + 4));
     HIPCK(c, hipMemcpyAsync(c->d_seams[k], c->prog[k].seam_waves.data(), c->prog[k].seam_waves.size() * 4, hipMemcpyHostToDevice, c->side2));
   }

@@ -63,10 +63,6 @@ int launch_verdict(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_e
 // sec_mask: bit s = section s, bit 31 = waves straddling a section boundary / the row end
 int launch_serialize(const SerializeProgram& S, const SerializeSources& src, const void* d_lut, const void* d_wave_sec, const void* d_seam_waves,
                      uint32_t n_seams, uint32_t n_proofs, void* d_out, uint32_t sec_mask, void* stream);
-// second-generation serializer (layout.h): cls_bits = readiness classes whose slow-group lists are written by this launch
-int launch_serialize2(const SerializeProgram& S, const SerializeSources& src, const void* d_gdesc, const void* d_wave_sec, const void* d_lut,
-                      const void* d_slow, const uint32_t slow_off[5], uint32_t cls_bits, uint32_t n_proofs, void* d_out, uint32_t sec_mask,
-                      uint32_t sel_mask, void* stream);
 // packs elements [first, first + row_elems) of every row densely into d_out as u64 or u32 (transfer formats of the host entry point)
 int launch_pack_rows(const void* d_rows, void* d_out, uint32_t elem_stride, uint32_t first, uint32_t row_elems, uint32_t n_proofs, bool as_u32,
                      void* stream);

@@ -83,17 +83,6 @@ struct SerializeProgram {
   uint32_t tree_nodes;   // nodes per validator tree
   uint32_t span;         // elements one wave serializes (128, 256 or 512): SPAN/128 coalesced 16-byte stores per thread, all loads in flight together
 };
-// ---- serializer, second generation (k_serialize_bits): one descriptor word per GROUP of eight consecutive row elements.
-// A group whose eight elements are eight consecutive bits (most significant first) of one source record is "fast":
-//   [31] fast | [30:28] phase = position of element 0 inside its byte, counted from the most significant bit | [24:15] record index
-//   (lane) within the proof | [14:0] byte offset of that byte inside the record
-// and one thread turns it into 64 output bytes from two source bytes.  Every other group (u32 / u16 / u8 / flag elements, groups that
-// cross a field or lane boundary, the groups of the spans that straddle a section boundary, the row tail) is on a per-row list and goes
-// through the per-element LUT in k_serialize_slow: about 6 % of a skip row at N = 128.
-constexpr uint32_t GD_FAST = 1u << 31;
-constexpr uint32_t SER2_SPAN = 512;  // elements per wave: 64 groups, four coalesced 16-byte stores per thread
-constexpr uint32_t gd_make(uint32_t phase, uint32_t rec, uint32_t off) { return GD_FAST | (phase << 28) | (rec << 15) | off; }
-
 struct SerializeSources {
   const uint8_t* base[SRC_COUNT];
   const uint8_t* nodes_t;

@@ -11,13 +11,13 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from tendermintx_amd import Context, _lib  # noqa: E402
 from tendermintx_amd.context import KIND_SKIP  # noqa: E402
-from tendermintx_amd.synth import Workload  # noqa: E402
+from tendermintx_amd.synth import bench_workload  # noqa: E402
 
 reps = int(sys.argv[1])
 key, vals = sys.argv[2].split("=")
 vals = vals.split(",")
 P, n = int(os.environ.get("P", "256")), int(os.environ.get("N", "128"))
-w = Workload(KIND_SKIP, n, P, n, chain_id=b"celestia", seed=7)
+w = bench_workload(os.environ.get("WORKLOAD", "survey8d"), n, P, seed=7)
 dev = torch.device("cuda:0")
 d_proofs = torch.frombuffer(bytearray(w.proofs), dtype=torch.uint8).to(dev)
 d_targets = torch.frombuffer(bytearray(w.targets), dtype=torch.uint8).to(dev)

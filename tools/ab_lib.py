@@ -13,9 +13,9 @@ sys.path.insert(0, %r)
 import torch
 from tendermintx_amd import Context, _lib
 from tendermintx_amd.context import KIND_SKIP
-from tendermintx_amd.synth import Workload
+from tendermintx_amd.synth import bench_workload
 P, n = int(os.environ.get("P", "256")), int(os.environ.get("N", "128"))
-w = Workload(KIND_SKIP, n, P, n, chain_id=b"celestia", seed=7)
+w = bench_workload(os.environ.get("WORKLOAD", "survey8d"), n, P, seed=7)
 dev = torch.device("cuda:0")
 d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) for b in (w.proofs, w.targets, w.trusteds)]
 stride = int(_lib.lib().tmx_elem_stride(KIND_SKIP, n))
