@@ -494,7 +494,9 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   // Phase 1 (SHA-512, s*B: throughput work for every lane) goes to the low-priority stream side3: on s it would sit in front of the
   // table multiples of the first part, which then start when phase 1 ends instead of when their anchors are ready.
   // (measured at 256 / 1024 proofs x 128: mode 1 +3 % / +8 % step time, mode 2 +0.7 % / -1.3 %: the walk starts 55 us earlier but shares
-  // the SIMDs with s*B -- the span is VALU-throughput-bound either way)
+  // the SIMDs with s*B -- the span is VALU-throughput-bound either way.  Round 2, with the two roles as kernels of their own (s*B then
+  // runs at 73 instead of 186 VGPRs): s*B on s + hash in front of the input sections on side3 +4 % / +4 %, both on s one after the other
+  // +-0 % / -0.3 % at 256 / 1024 proofs and +11 % on the one-validator-set batch and at 32 proofs; the combined launch stays)
   const uint32_t p1_side = c->p1_side == 3 ? 0u : c->p1_side;
   bool wait_p1_late = false;
   if (p1_side == 1) {
