@@ -199,6 +199,27 @@ int32_t tmx_sync(tmx_ctx* ctx);
  * per-key fixed-base tables (>= 8 lanes per key on average; TMX_DEDUP=0|1|2 forces never / automatic / always).  Blocks. */
 int32_t tmx_last_dedup(tmx_ctx* ctx, uint32_t* n_unique, uint32_t* used_tables);
 
+/* ---- Level-2 trace rows (SURVEY 8a "Level-2", 8f rank 2): the row-level execution trace behind the Level-1 values -- what the reference
+ * produces inside Curta's trace generators for `curta_eddsa_verify_sigs_conditional` (reference circuits/builder/verify.rs:248-259) and
+ * `curta_sha256_variable` (validator.rs:228).  Those sources are absent, so the row layout is this build's own specification (DESIGN.md
+ * "Level-2 trace rows"), validated row by row by the constraint checker oracle/c/tmxo_trace.c -- NOT claimed equal to Curta's columns.
+ * Per proof tmx_trace_elem_count() elements (u64, every value < 2^32):
+ *   ladders   lane i, ladder k (0: s*B, 1: h*A), 256 rows x 65: bit | acc | dbl = 2 acc | add = dbl + P | nxt = bit ? add : dbl,
+ *             points as canonical affine (x, y) in eight little-endian u32 limbs each; acc_0 = (0, 1), acc_{r+1} = nxt_r, nxt_255 = k * P
+ *   SHA-512   lane i, block b < 2, 80 rounds x 18: W_t and a..h after the round (64-bit words as lo, hi)
+ *   SHA-256   validator leaf hashes of the target (and, for skip, trusted) set: 64 rounds x 9
+ *   N x N     skip: signed[i] & (target pubkey i == trusted pubkey j)
+ * tmx_trace_rows_device reads the Level-1 lane records the context holds: call it after tmx_witness_batch_device of the SAME batch, on the
+ * same stream.  d_trace_out: n_proofs * tmx_trace_elem_count() u64.  38 MB per proof at N = 128: this launch is HBM-write work. */
+#define TMX_TRACE_LADDERS 1u
+#define TMX_TRACE_SHA512 2u
+#define TMX_TRACE_SHA256 4u
+#define TMX_TRACE_MATCH 8u
+#define TMX_TRACE_ALL 15u
+uint64_t tmx_trace_elem_count(int32_t kind, uint32_t n_max);
+int32_t tmx_trace_rows_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const void* d_targets, const void* d_trusteds, void* d_trace_out,
+                              uint32_t sections, void* hip_stream);
+
 /* ---- per-lane Level-1 EdDSA values only (unit-test / profiling hook of the dominant kernel).
  * d_out: 448 B per lane = digest[64] | h[32] | A.x A.y R.x R.y sB.x sB.y hA.x hA.y sum.x sum.y [10][32] | ok u32 |
  * decode_ok u32 | pad.  Host variant copies in/out. */

@@ -350,3 +350,93 @@ void tmxo_dummy(uint8_t pk[32], uint8_t sig[64]) {
   memset(seed, 1, 32); memset(msg, 0, 32);
   tmxo_ed25519_pubkey(seed, pk); tmxo_ed25519_sign(seed, msg, 32, sig);
 }
+
+/* ================================================================================================ Level-2 ladder rows
+ * TEST INFRASTRUCTURE.  DESIGN.md "Level-2 trace rows" (this build's own specification: the reference's Curta AIR is not observable).
+ * One ladder = 256 rows of 65 elements for k * P, most significant bit first:
+ *   [0] bit b_r = bit (255 - r) of k | [1..16] acc_r | [17..32] dbl_r = 2 acc_r | [33..48] add_r = dbl_r + P | [49..64] nxt_r = b_r ? add_r : dbl_r
+ * every point as canonical affine (x, y), eight little-endian u32 limbs each; acc_0 = (0, 1), acc_{r+1} = nxt_r, nxt_255 = k * P.
+ * Generator: affine twisted-Edwards formulas with one field inversion per operation (slow and independent of the HIP path, which keeps
+ * projective coordinates and inverts in batches).  Checker: the same laws cross-multiplied, no inversion. */
+static void fe_words(uint64_t out[8], const fe a) {
+  uint8_t b[32]; fe_tobytes(b, a);
+  for (int k = 0; k < 8; k++) out[k] = (uint64_t)b[4 * k] | ((uint64_t)b[4 * k + 1] << 8) | ((uint64_t)b[4 * k + 2] << 16) | ((uint64_t)b[4 * k + 3] << 24);
+}
+static int fe_from_limbs_checked(fe o, const uint64_t w[8]) { /* 0 if a limb is not a u32 or the value is not canonical */
+  uint8_t b[32], c[32];
+  for (int k = 0; k < 8; k++) { if (w[k] >> 32) return 0; for (int j = 0; j < 4; j++) b[4 * k + j] = (uint8_t)(w[k] >> (8 * j)); }
+  if (b[31] & 0x80) return 0;
+  fe_frombytes(o, b); fe_tobytes(c, o);
+  return memcmp(b, c, 32) == 0;
+}
+/* affine addition law of -x^2 + y^2 = 1 + d x^2 y^2 (complete: d is not a square) */
+static void aff_add(fe x3, fe y3, const fe x1, const fe y1, const fe x2, const fe y2) {
+  fe a, b, c, t, one, den;
+  fe_set(one, 1);
+  fe_mul(a, x1, y2); fe_mul(b, y1, x2); fe_mul(c, a, b); fe_mul(c, c, FE_D);      /* c = d x1 x2 y1 y2 */
+  fe_add(t, a, b); fe_add(den, one, c); fe_invert(den, den); fe_mul(x3, t, den);
+  fe_mul(a, y1, y2); fe_mul(b, x1, x2); fe_add(t, a, b); fe_sub(den, one, c); fe_invert(den, den); fe_mul(y3, t, den);
+}
+void tmxo_trace_ladder(const uint8_t k[32], const uint8_t px[32], const uint8_t py[32], uint64_t* rows /* 256 * 65 */) {
+  pthread_once(&once, init_tables);
+  fe x, y, Px, Py, dx, dy, ax, ay;
+  fe_set(x, 0); fe_set(y, 1);
+  fe_frombytes(Px, px); fe_frombytes(Py, py);
+  for (int r = 0; r < 256; r++) {
+    uint64_t* row = rows + 65 * r;
+    const int bit = (k[(255 - r) / 8] >> ((255 - r) & 7)) & 1;
+    row[0] = (uint64_t)bit;
+    fe_words(row + 1, x); fe_words(row + 9, y);
+    aff_add(dx, dy, x, y, x, y);
+    fe_words(row + 17, dx); fe_words(row + 25, dy);
+    aff_add(ax, ay, dx, dy, Px, Py);
+    fe_words(row + 33, ax); fe_words(row + 41, ay);
+    if (bit) { fe_copy(x, ax); fe_copy(y, ay); } else { fe_copy(x, dx); fe_copy(y, dy); }
+    fe_words(row + 49, x); fe_words(row + 57, y);
+  }
+}
+/* x3 (1 + d x1 x2 y1 y2) == x1 y2 + y1 x2  and  y3 (1 - d x1 x2 y1 y2) == y1 y2 + x1 x2 */
+static int aff_add_holds(const fe x3, const fe y3, const fe x1, const fe y1, const fe x2, const fe y2) {
+  fe a, b, c, l, r, one;
+  fe_set(one, 1);
+  fe_mul(a, x1, y2); fe_mul(b, y1, x2); fe_mul(c, a, b); fe_mul(c, c, FE_D);
+  fe_add(r, a, b); fe_add(l, one, c); fe_mul(l, l, x3); fe_sub(l, l, r);
+  if (!fe_iszero(l)) return 0;
+  fe_mul(a, y1, y2); fe_mul(b, x1, x2); fe_add(r, a, b); fe_sub(l, one, c); fe_mul(l, l, y3); fe_sub(l, l, r);
+  return fe_iszero(l);
+}
+/* 0 = every constraint holds; otherwise 1000 * (row + 1) + the number of the violated constraint */
+int tmxo_trace_ladder_check(const uint64_t* rows, const uint8_t k[32], const uint8_t px[32], const uint8_t py[32], const uint8_t rx[32],
+                            const uint8_t ry[32]) {
+  pthread_once(&once, init_tables);
+  fe P[2], acc[2], dbl[2], add[2], nxt[2], prev[2];
+  fe_frombytes(P[0], px); fe_frombytes(P[1], py);
+  fe_set(prev[0], 0); fe_set(prev[1], 1);
+  for (int r = 0; r < 256; r++) {
+    const uint64_t* row = rows + 65 * r;
+    const int e = 1000 * (r + 1);
+    if (row[0] > 1) return e + 1;
+    if (row[0] != (uint64_t)((k[(255 - r) / 8] >> ((255 - r) & 7)) & 1)) return e + 2;            /* the bits compose the scalar */
+    if (!fe_from_limbs_checked(acc[0], row + 1) || !fe_from_limbs_checked(acc[1], row + 9) || !fe_from_limbs_checked(dbl[0], row + 17) ||
+        !fe_from_limbs_checked(dbl[1], row + 25) || !fe_from_limbs_checked(add[0], row + 33) || !fe_from_limbs_checked(add[1], row + 41) ||
+        !fe_from_limbs_checked(nxt[0], row + 49) || !fe_from_limbs_checked(nxt[1], row + 57)) return e + 3;   /* canonical u32 limbs */
+    fe t;
+    fe_sub(t, acc[0], prev[0]); if (!fe_iszero(t)) return e + 4;                                    /* acc_0 = O, acc_r = nxt_{r-1} */
+    fe_sub(t, acc[1], prev[1]); if (!fe_iszero(t)) return e + 4;
+    if (!aff_add_holds(dbl[0], dbl[1], acc[0], acc[1], acc[0], acc[1])) return e + 5;              /* dbl = 2 acc */
+    if (!aff_add_holds(add[0], add[1], dbl[0], dbl[1], P[0], P[1])) return e + 6;                  /* add = dbl + P */
+    const fe* sel = row[0] ? add : dbl;
+    fe_sub(t, nxt[0], sel[0]); if (!fe_iszero(t)) return e + 7;                                    /* nxt = bit ? add : dbl */
+    fe_sub(t, nxt[1], sel[1]); if (!fe_iszero(t)) return e + 7;
+    fe_copy(prev[0], nxt[0]); fe_copy(prev[1], nxt[1]);
+  }
+  fe R[2], t;
+  fe_frombytes(R[0], rx); fe_frombytes(R[1], ry);
+  fe_sub(t, prev[0], R[0]); if (!fe_iszero(t)) return 257000 + 8;                                  /* nxt_255 = the Level-1 point */
+  fe_sub(t, prev[1], R[1]); if (!fe_iszero(t)) return 257000 + 8;
+  return 0;
+}
+void tmxo_base_point(uint8_t x[32], uint8_t y[32]) {
+  pthread_once(&once, init_tables);
+  ge_affine_bytes(&GE_B, x, y);
+}

@@ -131,3 +131,122 @@ void tmxo_sha512_3(const uint8_t* p0, size_t l0, const uint8_t* p1, size_t l1, c
 }
 
 void tmxo_sha512(const uint8_t* msg, size_t len, uint8_t out[64]) { tmxo_sha512_3(msg, len, 0, 0, 0, 0, out); }
+
+/* ================================================================================================ Level-2 SHA round rows
+ * TEST INFRASTRUCTURE.  DESIGN.md "Level-2 trace rows".  SHA-512 (the EdDSA hash, at most two blocks): per block 80 rows of 18 elements
+ * [W_t lo, W_t hi, a lo, a hi, ..., h lo, h hi] = the schedule word and the eight working variables AFTER round t, 32-bit limbs, low limb
+ * first; the rows of an unused second block are zero.  SHA-256 (validator leaf hash, one block): 64 rows of 9 elements [W_t, a .. h]. */
+static const uint64_t IV512[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                  0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+static const uint32_t IV256[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+
+static size_t pad512(const uint8_t* msg, size_t len, uint8_t buf[256]) { /* returns the number of blocks (1 or 2), len <= 239 */
+  const size_t nb = (len + 17 > 128) ? 2 : 1;
+  memset(buf, 0, 256); memcpy(buf, msg, len); buf[len] = 0x80;
+  const uint64_t bits = (uint64_t)len * 8;
+  for (int i = 0; i < 8; i++) buf[128 * nb - 1 - i] = (uint8_t)(bits >> (8 * i));
+  return nb;
+}
+static void put64(uint64_t* o, uint64_t v) { o[0] = v & 0xffffffffu; o[1] = v >> 32; }
+static int get64(const uint64_t* p, uint64_t* v) { if ((p[0] >> 32) || (p[1] >> 32)) return 0; *v = p[0] | (p[1] << 32); return 1; }
+
+void tmxo_trace_sha512(const uint8_t* msg, size_t len, uint64_t* rows) {
+  uint8_t buf[256];
+  const size_t nb = pad512(msg, len, buf);
+  memset(rows, 0, sizeof(uint64_t) * 2 * 80 * 18);
+  uint64_t st[8];
+  memcpy(st, IV512, sizeof st);
+  for (size_t b = 0; b < nb; b++) {
+    uint64_t w[80], v[8];
+    for (int i = 0; i < 16; i++) { w[i] = 0; for (int k = 0; k < 8; k++) w[i] = (w[i] << 8) | buf[128 * b + 8 * i + k]; }
+    for (int i = 16; i < 80; i++)
+      w[i] = w[i - 16] + (ror64(w[i - 15], 1) ^ ror64(w[i - 15], 8) ^ (w[i - 15] >> 7)) + w[i - 7] + (ror64(w[i - 2], 19) ^ ror64(w[i - 2], 61) ^ (w[i - 2] >> 6));
+    memcpy(v, st, sizeof v);
+    for (int t = 0; t < 80; t++) {
+      const uint64_t t1 = v[7] + (ror64(v[4], 14) ^ ror64(v[4], 18) ^ ror64(v[4], 41)) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + K512[t] + w[t];
+      const uint64_t t2 = (ror64(v[0], 28) ^ ror64(v[0], 34) ^ ror64(v[0], 39)) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
+      v[7] = v[6]; v[6] = v[5]; v[5] = v[4]; v[4] = v[3] + t1; v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = t1 + t2;
+      uint64_t* row = rows + (b * 80 + t) * 18;
+      put64(row, w[t]);
+      for (int k = 0; k < 8; k++) put64(row + 2 + 2 * k, v[k]);
+    }
+    for (int k = 0; k < 8; k++) st[k] += v[k];
+  }
+}
+/* 0 = holds; else 100 * (block * 80 + round + 1) + constraint number */
+int tmxo_trace_sha512_check(const uint64_t* rows, const uint8_t* msg, size_t len, const uint8_t digest[64]) {
+  uint8_t buf[256];
+  const size_t nb = pad512(msg, len, buf);
+  uint64_t st[8], prev[8], w[80];
+  memcpy(st, IV512, sizeof st);
+  for (size_t b = 0; b < 2; b++) {
+    if (b >= nb) { for (int i = 0; i < 80 * 18; i++) if (rows[b * 80 * 18 + i]) return 100 * (int)(b * 80 + 1) + 9; continue; }   /* unused block: zeros */
+    memcpy(prev, st, sizeof prev);
+    for (int t = 0; t < 80; t++) {
+      const uint64_t* row = rows + (b * 80 + t) * 18;
+      const int e = 100 * (int)(b * 80 + t + 1);
+      uint64_t v[8];
+      if (!get64(row, &w[t])) return e + 1;                                                        /* u32 limbs */
+      for (int k = 0; k < 8; k++) if (!get64(row + 2 + 2 * k, &v[k])) return e + 1;
+      uint64_t want;
+      if (t < 16) { want = 0; for (int k = 0; k < 8; k++) want = (want << 8) | buf[128 * b + 8 * t + k]; }   /* the padded message */
+      else want = w[t - 16] + (ror64(w[t - 15], 1) ^ ror64(w[t - 15], 8) ^ (w[t - 15] >> 7)) + w[t - 7] + (ror64(w[t - 2], 19) ^ ror64(w[t - 2], 61) ^ (w[t - 2] >> 6));
+      if (w[t] != want) return e + 2;
+      const uint64_t t1 = prev[7] + (ror64(prev[4], 14) ^ ror64(prev[4], 18) ^ ror64(prev[4], 41)) + ((prev[4] & prev[5]) ^ (~prev[4] & prev[6])) + K512[t] + w[t];
+      const uint64_t t2 = (ror64(prev[0], 28) ^ ror64(prev[0], 34) ^ ror64(prev[0], 39)) + ((prev[0] & prev[1]) ^ (prev[0] & prev[2]) ^ (prev[1] & prev[2]));
+      if (v[0] != t1 + t2 || v[1] != prev[0] || v[2] != prev[1] || v[3] != prev[2] || v[4] != prev[3] + t1 || v[5] != prev[4] || v[6] != prev[5] ||
+          v[7] != prev[6]) return e + 3;                                                             /* the round function */
+      memcpy(prev, v, sizeof prev);
+    }
+    for (int k = 0; k < 8; k++) st[k] += prev[k];
+  }
+  for (int i = 0; i < 8; i++) for (int k = 0; k < 8; k++) if (digest[8 * i + k] != (uint8_t)(st[i] >> (56 - 8 * k))) return 4;   /* = the Level-1 digest */
+  return 0;
+}
+
+void tmxo_trace_sha256_1(const uint8_t* msg, size_t len, uint64_t* rows) { /* one block: len <= 55 */
+  uint8_t buf[64];
+  memset(buf, 0, 64); memcpy(buf, msg, len); buf[len] = 0x80;
+  const uint64_t bits = (uint64_t)len * 8;
+  for (int i = 0; i < 8; i++) buf[63 - i] = (uint8_t)(bits >> (8 * i));
+  uint32_t w[64], v[8];
+  for (int i = 0; i < 16; i++) w[i] = ((uint32_t)buf[4 * i] << 24) | ((uint32_t)buf[4 * i + 1] << 16) | ((uint32_t)buf[4 * i + 2] << 8) | buf[4 * i + 3];
+  for (int i = 16; i < 64; i++)
+    w[i] = w[i - 16] + (ror32(w[i - 15], 7) ^ ror32(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] + (ror32(w[i - 2], 17) ^ ror32(w[i - 2], 19) ^ (w[i - 2] >> 10));
+  memcpy(v, IV256, sizeof v);
+  for (int t = 0; t < 64; t++) {
+    const uint32_t t1 = v[7] + (ror32(v[4], 6) ^ ror32(v[4], 11) ^ ror32(v[4], 25)) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + K256[t] + w[t];
+    const uint32_t t2 = (ror32(v[0], 2) ^ ror32(v[0], 13) ^ ror32(v[0], 22)) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
+    v[7] = v[6]; v[6] = v[5]; v[5] = v[4]; v[4] = v[3] + t1; v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = t1 + t2;
+    rows[9 * t] = w[t];
+    for (int k = 0; k < 8; k++) rows[9 * t + 1 + k] = v[k];
+  }
+}
+int tmxo_trace_sha256_1_check(const uint64_t* rows, const uint8_t* msg, size_t len, const uint8_t digest[32]) {
+  uint8_t buf[64];
+  memset(buf, 0, 64); memcpy(buf, msg, len); buf[len] = 0x80;
+  const uint64_t bits = (uint64_t)len * 8;
+  for (int i = 0; i < 8; i++) buf[63 - i] = (uint8_t)(bits >> (8 * i));
+  uint32_t w[64], prev[8];
+  memcpy(prev, IV256, sizeof prev);
+  for (int t = 0; t < 64; t++) {
+    const uint64_t* row = rows + 9 * t;
+    const int e = 100 * (t + 1);
+    for (int k = 0; k < 9; k++) if (row[k] >> 32) return e + 1;
+    w[t] = (uint32_t)row[0];
+    uint32_t want;
+    if (t < 16) want = ((uint32_t)buf[4 * t] << 24) | ((uint32_t)buf[4 * t + 1] << 16) | ((uint32_t)buf[4 * t + 2] << 8) | buf[4 * t + 3];
+    else want = w[t - 16] + (ror32(w[t - 15], 7) ^ ror32(w[t - 15], 18) ^ (w[t - 15] >> 3)) + w[t - 7] + (ror32(w[t - 2], 17) ^ ror32(w[t - 2], 19) ^ (w[t - 2] >> 10));
+    if (w[t] != want) return e + 2;
+    const uint32_t t1 = prev[7] + (ror32(prev[4], 6) ^ ror32(prev[4], 11) ^ ror32(prev[4], 25)) + ((prev[4] & prev[5]) ^ (~prev[4] & prev[6])) + K256[t] + w[t];
+    const uint32_t t2 = (ror32(prev[0], 2) ^ ror32(prev[0], 13) ^ ror32(prev[0], 22)) + ((prev[0] & prev[1]) ^ (prev[0] & prev[2]) ^ (prev[1] & prev[2]));
+    const uint32_t v[8] = {t1 + t2, prev[0], prev[1], prev[2], prev[3] + t1, prev[4], prev[5], prev[6]};
+    for (int k = 0; k < 8; k++) if ((uint32_t)row[1 + k] != v[k]) return e + 3;
+    memcpy(prev, v, sizeof prev);
+  }
+  for (int i = 0; i < 8; i++) {
+    const uint32_t s = IV256[i] + prev[i];
+    if (digest[4 * i] != (uint8_t)(s >> 24) || digest[4 * i + 1] != (uint8_t)(s >> 16) || digest[4 * i + 2] != (uint8_t)(s >> 8) || digest[4 * i + 3] != (uint8_t)s) return 4;
+  }
+  return 0;
+}

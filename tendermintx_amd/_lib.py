@@ -15,6 +15,7 @@ N_KERNELS = 4
 KERNEL_NAMES = ("k_eddsa", "k_proof", "k_verdict", "k_serialize")
 ED_STRIDE = 448
 SEC_HINT, SEC_DERIVED, SEC_ALL = 1, 2, 3   # TMX_SEC_*
+TRACE_LADDERS, TRACE_SHA512, TRACE_SHA256, TRACE_MATCH, TRACE_ALL = 1, 2, 4, 8, 15   # TMX_TRACE_*
 
 
 class ValidatorRec(C.Structure):
@@ -129,6 +130,9 @@ def lib():
                                          C.c_void_p, C.c_uint64, C.c_void_p]
     L.tmx_witness_batch_device_sections.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_uint32]
+    L.tmx_trace_elem_count.restype = C.c_uint64
+    L.tmx_trace_elem_count.argtypes = [C.c_int32, C.c_uint32]
+    L.tmx_trace_rows_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.tmx_witness_batch_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]
     L.tmx_ntt_goldilocks_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]

@@ -110,6 +110,13 @@ class Context:
         check(self._L.tmx_witness_batch_device_sections(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports,
                                                         self._stream(stream), sections), self._h)
 
+    def trace_elem_count(self, kind):
+        return int(self._L.tmx_trace_elem_count(kind, self.n_max))
+
+    def trace_rows_device(self, kind, n_proofs, d_targets, d_trusteds, d_trace_out, sections=_lib.TRACE_ALL, stream=None):
+        """Level-2 trace rows of the batch whose Level-1 witness this context computed last (same stream): tmx_trace_rows_device."""
+        check(self._L.tmx_trace_rows_device(self._h, kind, n_proofs, d_targets, d_trusteds, d_trace_out, sections, self._stream(stream)), self._h)
+
     def valid_skip_batch(self, start, n_start, targets, n_targets, sigs, n_sigs):
         """is_valid_skip for len(n_targets) candidates.  start: bytes [n_max x 32]; targets, sigs: bytes [n_cand x n_max x 32].
         Returns (valid [bool], shared power [int], total power [int])."""

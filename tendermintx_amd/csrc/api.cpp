@@ -15,6 +15,7 @@
 
 #include "kernels.h"
 #include "ntt.h"
+#include "trace.h"
 #include "tmx.h"
 
 using namespace tmx;
@@ -855,6 +856,24 @@ int32_t tmx_finish_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, con
                               (size_t)n_proofs * c->cfg.n_max, hipMemcpyDeviceToDevice, ss));
     return TMX_OK;
   });
+}
+
+uint64_t tmx_trace_elem_count(int32_t kind, uint32_t n) {
+  if ((kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP) || n == 0 || n > TMX_N_MAX_LIMIT) return 0;
+  return trace_elems((uint32_t)kind, n);
+}
+
+int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_targets, const void* d_trusteds, void* d_trace_out,
+                              uint32_t sections, void* hip_stream) {
+  if (!c || (kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP) || !d_targets || !d_trace_out || (sections & ~(uint32_t)TMX_TRACE_ALL) || sections == 0)
+    return TMX_ERR_BAD_ARG;
+  if (kind == TMX_KIND_SKIP && !d_trusteds) return fail(c, TMX_ERR_BAD_ARG, "skip needs the trusted hash fields");
+  if (n_proofs > c->cfg.max_batch) return fail(c, TMX_ERR_CAPACITY, "n_proofs exceeds the context's max_batch");
+  if (n_proofs == 0) return TMX_OK;
+  int rc = launch_trace((uint32_t)kind, c->cfg.n_max, n_proofs, d_targets, d_trusteds, reinterpret_cast<const uint8_t*>(c->d_tl) + TL_OFF_ED, TL_STRIDE,
+                        d_trace_out, sections, hip_stream);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_trace launch: ") + hipGetErrorString((hipError_t)rc));
+  return TMX_OK;
 }
 
 int32_t tmx_kernel_ms_mean(tmx_ctx* c, uint32_t last_k, float ms[TMX_N_KERNELS]) {

@@ -89,6 +89,9 @@ struct SerializeSources {
   const uint8_t* nodes_r;
 };
 
+// ---- Level-2 trace rows (trace.hip): row widths in elements
+constexpr uint32_t TR_LADDER_ROW = 65, TR_LADDER_ROWS = 256, TR_SHA512_ROW = 18, TR_SHA256_ROW = 9;
+
 struct ProofParams {
   uint32_t kind, n, tree_nodes, chain_id_len;
   uint64_t skip_max;

@@ -1,0 +1,326 @@
+// Level-2 trace rows (DESIGN.md "Level-2 trace rows", SURVEY 8a "Level-2" / 8f rank 2): the row-level execution trace of the two scalar
+// multiplications, of the EdDSA SHA-512 and of the validator leaf SHA-256 of every lane, plus the N x N match bits -- what the reference
+// generates inside Curta's AIR trace generators (`curta_eddsa_verify_sigs_conditional` at reference circuits/builder/verify.rs:248-259,
+// `curta_sha256_variable` at validator.rs:228; sources absent, so the layout is this build's own specification, validated by the
+// constraint checker oracle/c/tmxo_trace.c).  266 KB of ladder rows per lane: this is the part of the witness that is written, not computed
+// -- 9.8 GB per 256-proof batch at N = 128.
+//
+//   k_trace_ladder   one thread per (lane, ladder): double-and-add in extended coordinates, the 2 x 8 new points of eight rows inverted
+//                    together (Montgomery's trick around one safegcd inversion), rows staged in LDS and written by the whole wave so
+//                    that every store instruction covers 512 contiguous bytes of ONE ladder (a thread-per-ladder store would scatter
+//                    64 x 8 bytes over 64 ladders 133 KB apart)
+//   k_trace_sha512   one thread per lane, four rounds per flush        k_trace_sha256   one thread per (set, lane)
+//   k_trace_match    one thread per (i, j)
+#include "trace.h"
+
+#include <hip/hip_runtime.h>
+
+#include "ge25519.hpp"
+#include "inv25519.hpp"
+#include "sha2.hpp"
+
+namespace tmx {
+namespace {
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+__device__ __forceinline__ uint64_t ld64(const uint8_t* p) { return *reinterpret_cast<const uint64_t*>(p); }
+
+// plonky2x DUMMY_PUBLIC_KEY / DUMMY_SIGNATURE (kernels.hip has the same words; pinned by tests/test_oracle_kat.py::test_dummy_constants)
+__device__ __constant__ const uint32_t T_DUMMY_PK[8] = {0xdde3888au, 0x95f10974u, 0x2ddb52fdu, 0x725dba3cu, 0xbf0967cau, 0x1b12941du, 0x018874f3u, 0x5c6f0fb4u};
+__device__ __constant__ const uint32_t T_DUMMY_SIG[16] = {0x9e681437u, 0x11c27854u, 0xa49ded06u, 0x899e5855u, 0xf0bb77bbu, 0x3f50499fu, 0x5b4aa285u, 0x8a063530u,
+                                                          0x79162901u, 0x91c62ef9u, 0xd203669bu, 0x37ad87a8u, 0x7e2d48fcu, 0x07bfb2a9u, 0x5a704399u, 0x078c2196u};
+// the base point B = (x, 4/5), canonical little-endian words (RFC 8032 section 5.1)
+__device__ __constant__ const uint32_t T_BX[8] = {0x8f25d51au, 0xc9562d60u, 0x9525a7b2u, 0x692cc760u, 0xfdd6dc5cu, 0xc0a4e231u, 0xcd6e53feu, 0x216936d3u};
+__device__ __constant__ const uint32_t T_BY[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u};
+
+constexpr int CH = 8;  // ladder rows per inversion batch (2 CH points)
+
+// flush `nv` staged values of every thread's current row group: value e of thread j goes to out[base[j] + off + e]
+template <int NV>
+__device__ __forceinline__ void coop_flush(const uint32_t (*stage)[NV + 1], const uint64_t* s_base, const uint8_t* s_live, uint64_t off, uint64_t* __restrict__ out) {
+  __syncthreads();
+  const uint32_t tid = threadIdx.x;
+#pragma unroll 1
+  for (int j = 0; j < 64; j++) {
+    if (!s_live[j]) continue;
+    uint64_t* dst = out + s_base[j] + off;
+    for (uint32_t e = tid; e < (uint32_t)NV; e += 64) __builtin_nontemporal_store((uint64_t)stage[j][e], dst + e);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void k_trace_ladder(uint32_t n_lanes, uint32_t n, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
+                                                     uint32_t ed_stride, uint64_t* __restrict__ out, uint64_t proof_stride) {
+  __shared__ uint32_t stage[64][TR_LADDER_ROW + 1];
+  __shared__ uint64_t s_base[64];
+  __shared__ uint8_t s_live[64];
+  const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t;
+  const bool live = id < 2u * n_lanes;
+  const uint32_t lane = live ? id >> 1 : 0u, k = id & 1u;
+  {
+    const uint32_t p = lane / n, i = lane - p * n;
+    s_base[t] = (uint64_t)p * proof_stride + (uint64_t)((2u * i + k) * TR_LADDER_ROWS) * TR_LADDER_ROW;
+    s_live[t] = live ? 1 : 0;
+  }
+  const uint8_t* rec = in_target + (size_t)lane * VR_STRIDE;
+  const uint8_t* er = ed + (size_t)lane * ed_stride;
+  const bool is_signed = rec[VR_OFF_FLAGS] & 1;
+  const bool decoded = ld32(er + ED_OFF_DECODE_OK) != 0;
+  uint32_t sc[8], pw[16];
+#pragma unroll
+  for (int w = 0; w < 8; w++) {
+    sc[w] = k ? ld32(er + ED_OFF_H + 4 * w) : (is_signed ? ld32(rec + VR_OFF_SIG + 32 + 4 * w) : T_DUMMY_SIG[8 + w]);
+    pw[w] = (k && decoded) ? ld32(er + ED_OFF_PTS + 4 * w) : T_BX[w];           // A.x | B.x (an undecodable lane computes on B, stores zeros)
+    pw[8 + w] = (k && decoded) ? ld32(er + ED_OFF_PTS + 32 + 4 * w) : T_BY[w];  // A.y | B.y
+  }
+  ge_affc P;
+  {
+    const fe x = fe_from_words(pw), y = fe_from_words(pw + 8);
+    P.ypx = fe_add(y, x); P.ymx = fe_sub(y, x); P.xy2d = fe_mul(fe_mul(x, y), K_2D);
+  }
+  ge_ext acc = ge_identity();
+  uint32_t accw[16];
+#pragma unroll
+  for (int w = 0; w < 16; w++) accw[w] = w == 8 ? 1u : 0u;  // (0, 1)
+  fe X[2 * CH], Y[2 * CH], Z[2 * CH], pre[2 * CH];
+  uint32_t W[2 * CH][16];
+#pragma unroll 1
+  for (int c = 0; c < (int)TR_LADDER_ROWS / CH; c++) {
+    uint32_t bits = 0;
+#pragma unroll 1
+    for (int j = 0; j < CH; j++) {
+      const int b = 255 - (c * CH + j);
+      uint32_t word = sc[0];
+#pragma unroll
+      for (int w = 1; w < 8; w++) word = (b >> 5) == w ? sc[w] : word;
+      const uint32_t bit = (word >> (b & 31)) & 1u;
+      const ge_ext d = comp_to_ext(ge_double(ext_to_proj(acc)));
+      const ge_ext a = comp_to_ext(ge_add_affc(d, P));
+      X[2 * j] = d.X; Y[2 * j] = d.Y; Z[2 * j] = d.Z;
+      X[2 * j + 1] = a.X; Y[2 * j + 1] = a.Y; Z[2 * j + 1] = a.Z;
+      acc.X = fe_select(d.X, a.X, bit); acc.Y = fe_select(d.Y, a.Y, bit); acc.Z = fe_select(d.Z, a.Z, bit); acc.T = fe_select(d.T, a.T, bit);
+      bits |= bit << j;
+    }
+    // Montgomery's trick over the 2 CH denominators of this batch
+    pre[0] = Z[0];
+#pragma unroll 1
+    for (int i = 1; i < 2 * CH; i++) pre[i] = fe_mul(pre[i - 1], Z[i]);
+    fe inv = fe_invert_safegcd(pre[2 * CH - 1]);
+#pragma unroll 1
+    for (int i = 2 * CH - 1; i >= 0; i--) {
+      const fe zi = i ? fe_mul(inv, pre[i - 1]) : inv;
+      inv = fe_mul(inv, Z[i]);
+      fe_to_words(fe_mul(X[i], zi), W[i]);
+      fe_to_words(fe_mul(Y[i], zi), W[i] + 8);
+    }
+#pragma unroll 1
+    for (int j = 0; j < CH; j++) {
+      const uint32_t bit = (bits >> j) & 1u;
+      const uint32_t z = decoded ? 0xffffffffu : 0u;  // an undecodable lane: all-zero rows (Level-1 reports zero points there too)
+      stage[t][0] = bit & z;
+#pragma unroll
+      for (int w = 0; w < 16; w++) {
+        const uint32_t nx = bit ? W[2 * j + 1][w] : W[2 * j][w];
+        stage[t][1 + w] = accw[w] & z;
+        stage[t][17 + w] = W[2 * j][w] & z;
+        stage[t][33 + w] = W[2 * j + 1][w] & z;
+        stage[t][49 + w] = nx & z;
+        accw[w] = nx;
+      }
+      coop_flush<TR_LADDER_ROW>(stage, s_base, s_live, (uint64_t)(c * CH + j) * TR_LADDER_ROW, out);
+    }
+  }
+}
+
+// SHA-512(R | A | M) of the effective triple of one lane (at most two blocks), 18 values per round
+__global__ __launch_bounds__(64) void k_trace_sha512(uint32_t n_lanes, uint32_t n, const uint8_t* __restrict__ in_target, uint64_t* __restrict__ out,
+                                                     uint64_t proof_stride) {
+  constexpr int RPF = 4, NV = RPF * TR_SHA512_ROW;  // rounds per flush
+  __shared__ uint32_t stage[64][NV + 1];
+  __shared__ uint64_t s_base[64];
+  __shared__ uint8_t s_live[64];
+  const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t;
+  const bool live = id < n_lanes;
+  const uint32_t lane = live ? id : 0u;
+  {
+    const uint32_t p = lane / n, i = lane - p * n;
+    s_base[t] = (uint64_t)p * proof_stride + (uint64_t)n * (2u * TR_LADDER_ROWS * TR_LADDER_ROW) + (uint64_t)i * (2u * 80u * TR_SHA512_ROW);
+    s_live[t] = live ? 1 : 0;
+  }
+  const uint8_t* rec = in_target + (size_t)lane * VR_STRIDE;
+  const bool is_signed = rec[VR_OFF_FLAGS] & 1;
+  uint32_t mlen = is_signed ? (uint32_t)rec[VR_OFF_MLEN] | ((uint32_t)rec[VR_OFF_MLEN + 1] << 8) : 32u;
+  if (mlen > 124u) mlen = 124u;
+  const uint32_t total = 64u + mlen, nblk = total + 17u > 128u ? 2u : 1u;
+  auto byte_at = [&](uint32_t pos) -> uint32_t {  // the padded message
+    if (pos < 32u) return ((is_signed ? ld32(rec + VR_OFF_SIG + (pos & ~3u)) : T_DUMMY_SIG[pos >> 2]) >> (8u * (pos & 3u))) & 0xffu;
+    if (pos < 64u) return ((is_signed ? ld32(rec + VR_OFF_PK + ((pos - 32u) & ~3u)) : T_DUMMY_PK[(pos - 32u) >> 2]) >> (8u * (pos & 3u))) & 0xffu;
+    if (pos < total) return is_signed ? (uint32_t)rec[VR_OFF_MSG + (pos - 64u)] : 0u;
+    return pos == total ? 0x80u : 0u;
+  };
+  uint64_t st[8];
+  sha512_init(st);
+#pragma unroll 1
+  for (uint32_t blk = 0; blk < 2; blk++) {
+    uint64_t w[16], v[8];
+#pragma unroll 1
+    for (int q = 0; q < 16; q++) {
+      uint64_t word = 0;
+      for (int b = 0; b < 8; b++) word = (word << 8) | byte_at(blk * 128u + 8u * q + b);
+      w[q] = word;
+    }
+    if (blk == nblk - 1u) w[15] = (uint64_t)total * 8u;
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = st[q];
+    const bool used = blk < nblk;
+#pragma unroll 1
+    for (int g = 0; g < 80 / RPF; g++) {
+#pragma unroll
+      for (int u = 0; u < RPF; u++) {
+        const int i = g * RPF + u;
+        uint64_t wt;
+        {  // rolling schedule; the index is dynamic (the loop over g is not unrolled), so go through a select chain
+          uint64_t w16 = w[0], w15 = w[0], w7 = w[0], w2 = w[0];
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            w16 = ((i) & 15) == q ? w[q] : w16; w15 = ((i + 1) & 15) == q ? w[q] : w15;
+            w7 = ((i + 9) & 15) == q ? w[q] : w7; w2 = ((i + 14) & 15) == q ? w[q] : w2;
+          }
+          wt = w16;
+          if (i >= 16) {
+            wt = w16 + (rotr64(w15, 1) ^ rotr64(w15, 8) ^ (w15 >> 7)) + w7 + (rotr64(w2, 19) ^ rotr64(w2, 61) ^ (w2 >> 6));
+#pragma unroll
+            for (int q = 0; q < 16; q++) w[q] = (i & 15) == q ? wt : w[q];
+          }
+        }
+        const uint64_t t1 = v[7] + (rotr64(v[4], 14) ^ rotr64(v[4], 18) ^ rotr64(v[4], 41)) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + K_SHA512[i] + wt;
+        const uint64_t t2 = (rotr64(v[0], 28) ^ rotr64(v[0], 34) ^ rotr64(v[0], 39)) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
+        v[7] = v[6]; v[6] = v[5]; v[5] = v[4]; v[4] = v[3] + t1; v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = t1 + t2;
+        uint32_t* o = stage[t] + u * TR_SHA512_ROW;
+        o[0] = used ? (uint32_t)wt : 0u; o[1] = used ? (uint32_t)(wt >> 32) : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { o[2 + 2 * q] = used ? (uint32_t)v[q] : 0u; o[3 + 2 * q] = used ? (uint32_t)(v[q] >> 32) : 0u; }
+      }
+      coop_flush<NV>(stage, s_base, s_live, (uint64_t)(blk * 80u + g * RPF) * TR_SHA512_ROW, out);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) st[q] += v[q];
+  }
+}
+
+// SHA-256(00 | marshalled validator[0 .. vlen]) of one lane of the target or trusted set: one block, 9 values per round
+__global__ __launch_bounds__(64) void k_trace_sha256(uint32_t kind, uint32_t n_lanes, uint32_t n, const uint8_t* __restrict__ in_target,
+                                                     const uint8_t* __restrict__ in_trusted, uint64_t* __restrict__ out, uint64_t proof_stride) {
+  constexpr int RPF = 4, NV = RPF * TR_SHA256_ROW;
+  __shared__ uint32_t stage[64][NV + 1];
+  __shared__ uint64_t s_base[64];
+  __shared__ uint8_t s_live[64];
+  const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t, sets = kind == 0 ? 2u : 1u;
+  const bool live = id < sets * n_lanes;
+  const uint32_t set = live && id >= n_lanes ? 1u : 0u, lane = live ? id - set * n_lanes : 0u;
+  {
+    const uint32_t p = lane / n, i = lane - p * n;
+    s_base[t] = (uint64_t)p * proof_stride + (uint64_t)n * (2u * TR_LADDER_ROWS * TR_LADDER_ROW + 2u * 80u * TR_SHA512_ROW) +
+                (uint64_t)(set * n + i) * (64u * TR_SHA256_ROW);
+    s_live[t] = live ? 1 : 0;
+  }
+  const uint8_t* rec = set ? in_trusted + (size_t)lane * HR_STRIDE : in_target + (size_t)lane * VR_STRIDE;
+  const uint64_t power = ld64(rec + (set ? HR_OFF_POWER : VR_OFF_POWER));
+  uint32_t vlen = rec[set ? HR_OFF_VLEN : VR_OFF_VLEN];
+  if (vlen > 46u) vlen = 46u;
+  int last = 0;
+#pragma unroll
+  for (int s = 0; s < 9; s++) if ((power >> (7 * s)) & 0x7f) last = s;
+  const uint32_t len = 1u + vlen;
+  auto byte_at = [&](uint32_t pos) -> uint32_t {  // 00 | 0a 22 0a 20 | pk | 10 | varint9, cut at len, padded
+    if (pos >= len) return pos == len ? 0x80u : 0u;
+    if (pos == 0u) return 0u;
+    const uint32_t m = pos - 1u;
+    if (m < 4u) return (m & 1u) ? (m == 1u ? 0x22u : 0x20u) : 0x0au;
+    if (m < 36u) return (ld32(rec + ((m - 4u) & ~3u)) >> (8u * ((m - 4u) & 3u))) & 0xffu;
+    if (m == 36u) return 0x10u;
+    const uint32_t s = m - 37u;
+    return (uint32_t)((power >> (7u * s)) & 0x7fu) | ((int)s < last ? 0x80u : 0u);
+  };
+  uint32_t w[16], v[8];
+#pragma unroll 1
+  for (int q = 0; q < 16; q++) {
+    uint32_t word = 0;
+    for (int b = 0; b < 4; b++) word = (word << 8) | byte_at(4u * q + b);
+    w[q] = word;
+  }
+  w[15] = len * 8u;
+  sha256_init(v);
+#pragma unroll 1
+  for (int g = 0; g < 64 / RPF; g++) {
+#pragma unroll
+    for (int u = 0; u < RPF; u++) {
+      const int i = g * RPF + u;
+      uint32_t w16 = w[0], w15 = w[0], w7 = w[0], w2 = w[0];
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        w16 = ((i) & 15) == q ? w[q] : w16; w15 = ((i + 1) & 15) == q ? w[q] : w15;
+        w7 = ((i + 9) & 15) == q ? w[q] : w7; w2 = ((i + 14) & 15) == q ? w[q] : w2;
+      }
+      uint32_t wt = w16;
+      if (i >= 16) {
+        wt = w16 + (rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3)) + w7 + (rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10));
+#pragma unroll
+        for (int q = 0; q < 16; q++) w[q] = (i & 15) == q ? wt : w[q];
+      }
+      const uint32_t t1 = v[7] + (rotr32(v[4], 6) ^ rotr32(v[4], 11) ^ rotr32(v[4], 25)) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + K_SHA256[i] + wt;
+      const uint32_t t2 = (rotr32(v[0], 2) ^ rotr32(v[0], 13) ^ rotr32(v[0], 22)) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
+      v[7] = v[6]; v[6] = v[5]; v[5] = v[4]; v[4] = v[3] + t1; v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = t1 + t2;
+      uint32_t* o = stage[t] + u * TR_SHA256_ROW;
+      o[0] = wt;
+#pragma unroll
+      for (int q = 0; q < 8; q++) o[1 + q] = v[q];
+    }
+    coop_flush<NV>(stage, s_base, s_live, (uint64_t)(g * RPF) * TR_SHA256_ROW, out);
+  }
+}
+
+// skip: m[i][j] = signed[i] and target pubkey i == trusted pubkey j (verify.rs:398-418, every pair)
+__global__ __launch_bounds__(256) void k_trace_match(uint32_t n_proofs, uint32_t n, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ in_trusted,
+                                                     uint64_t* __restrict__ out, uint64_t proof_stride, uint64_t sec_off) {
+  const uint32_t p = blockIdx.y, e = blockIdx.x * 256u + threadIdx.x;
+  if (p >= n_proofs || e >= n * n) return;
+  const uint32_t i = e / n, j = e - i * n;
+  const uint8_t* a = in_target + ((size_t)p * n + i) * VR_STRIDE;
+  const uint8_t* b = in_trusted + ((size_t)p * n + j) * HR_STRIDE;
+  uint32_t d = 0;
+#pragma unroll
+  for (int w = 0; w < 8; w++) d |= ld32(a + 4 * w) ^ ld32(b + 4 * w);
+  out[(size_t)p * proof_stride + sec_off + e] = (d == 0 && (a[VR_OFF_FLAGS] & 1)) ? 1ull : 0ull;
+}
+
+}  // namespace
+
+static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+uint64_t trace_elems(uint32_t kind, uint32_t n) {
+  const uint64_t sets = kind == 0 ? 2 : 1;
+  return (uint64_t)n * (2ull * TR_LADDER_ROWS * TR_LADDER_ROW + 2ull * 80 * TR_SHA512_ROW + sets * 64 * TR_SHA256_ROW) + (kind == 0 ? (uint64_t)n * n : 0);
+}
+
+int launch_trace(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_trusted, const void* d_ed, uint32_t ed_stride, void* d_out,
+                 uint32_t sections, void* stream) {
+  if (n_proofs == 0) return 0;
+  const uint32_t lanes = n_proofs * n;
+  const uint64_t stride = trace_elems(kind, n);
+  uint64_t* out = reinterpret_cast<uint64_t*>(d_out);
+  const uint8_t* tg = reinterpret_cast<const uint8_t*>(d_target);
+  const uint8_t* tr = reinterpret_cast<const uint8_t*>(d_trusted);
+  if (sections & 1u)
+    hipLaunchKernelGGL(k_trace_ladder, dim3((2 * lanes + 63) / 64), dim3(64), 0, S_(stream), lanes, n, tg, reinterpret_cast<const uint8_t*>(d_ed), ed_stride, out, stride);
+  if (sections & 2u) hipLaunchKernelGGL(k_trace_sha512, dim3((lanes + 63) / 64), dim3(64), 0, S_(stream), lanes, n, tg, out, stride);
+  if (sections & 4u)
+    hipLaunchKernelGGL(k_trace_sha256, dim3(((kind == 0 ? 2 : 1) * lanes + 63) / 64), dim3(64), 0, S_(stream), kind, lanes, n, tg, tr, out, stride);
+  if ((sections & 8u) && kind == 0) {
+    const uint64_t off = (uint64_t)n * (2ull * TR_LADDER_ROWS * TR_LADDER_ROW + 2ull * 80 * TR_SHA512_ROW + 2ull * 64 * TR_SHA256_ROW);
+    hipLaunchKernelGGL(k_trace_match, dim3((n * n + 255) / 256, n_proofs), dim3(256), 0, S_(stream), n_proofs, n, tg, tr, out, stride, off);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace tmx
