@@ -202,7 +202,7 @@ int32_t tmx_last_dedup(tmx_ctx* ctx, uint32_t* n_unique, uint32_t* used_tables);
 /* ---- Level-2 trace rows (SURVEY 8a "Level-2", 8f rank 2): the row-level execution trace behind the Level-1 values -- what the reference
  * produces inside Curta's trace generators for `curta_eddsa_verify_sigs_conditional` (reference circuits/builder/verify.rs:248-259) and
  * `curta_sha256_variable` (validator.rs:228).  Those sources are absent, so the row layout is this build's own specification (DESIGN.md
- * "Level-2 trace rows"), validated row by row by the constraint checker oracle/c/tmxo_trace.c -- NOT claimed equal to Curta's columns.
+ * "Level-2 trace rows"), validated row by row by the constraint checker under oracle/c -- NOT claimed equal to Curta's columns.
  * Per proof tmx_trace_elem_count() elements (u64, every value < 2^32):
  *   ladders   lane i, ladder k (0: s*B, 1: h*A), 256 rows x 65: bit | acc | dbl = 2 acc | add = dbl + P | nxt = bit ? add : dbl,
  *             points as canonical affine (x, y) in eight little-endian u32 limbs each; acc_0 = (0, 1), acc_{r+1} = nxt_r, nxt_255 = k * P

@@ -2,7 +2,7 @@
 // multiplications, of the EdDSA SHA-512 and of the validator leaf SHA-256 of every lane, plus the N x N match bits -- what the reference
 // generates inside Curta's AIR trace generators (`curta_eddsa_verify_sigs_conditional` at reference circuits/builder/verify.rs:248-259,
 // `curta_sha256_variable` at validator.rs:228; sources absent, so the layout is this build's own specification, validated by the
-// constraint checker oracle/c/tmxo_trace.c).  266 KB of ladder rows per lane: this is the part of the witness that is written, not computed
+// constraint checker under oracle/c).  266 KB of ladder rows per lane: this is the part of the witness that is written, not computed
 // -- 9.8 GB per 256-proof batch at N = 128.
 //
 //   k_trace_ladder   one thread per (lane, ladder): double-and-add in extended coordinates, the 2 x 8 new points of eight rows inverted
