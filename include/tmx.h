@@ -17,8 +17,10 @@
  * Conventions: every function returns 0 on success or a negative tmx_status; nothing throws across the ABI;
  * the caller owns all buffers passed in; the library never keeps caller pointers after returning; a tmx_ctx is
  * not thread-safe (use one per thread).  Contexts of one device share three internal side streams (the GPU runs four hardware queues:
- * DESIGN.md section 3) and each context owns ONE set of scratch buffers and join events, reused by every call: consecutive *_device calls
- * on one context must be stream-ordered -- the same stream, or an explicit dependency from the end of one call to the start of the next.
+ * DESIGN.md section 3) and each context owns ONE set of scratch buffers and join events, reused by every call: consecutive
+ * tmx_witness_batch_device / tmx_finish_batch_device calls on one context are ordered by the library itself (a call on another stream
+ * waits for the end of the previous one); the other *_device entry points (EdDSA lanes, trace rows, NTT) must be stream-ordered by the
+ * caller -- the same stream, or an explicit dependency.
  * The host-buffer entry points block until their results are in host memory, so they are ordered by construction.
  */
 #ifndef TMX_H
@@ -264,12 +266,18 @@ void tmx_pack_step_input(uint64_t prev_block, const uint8_t prev_header_hash[32]
 void tmx_unpack_step_input(const uint8_t in[40], uint64_t* prev_block, uint8_t prev_header_hash[32]);
 
 /* ---- Goldilocks NTT / coset low-degree extension (the step after the witness fill of a plonky2-style prover).
- * Own statement of the published definitions (plonky2_field is not in the reference tree; parity pinned against oracle/c/tmxo_ntt.c):
- * p = 2^64 - 2^32 + 1, g = 7, omega_N = g^((p-1)/N); forward X[j] = sum_i x[i] omega_N^(ij), inverse with N^-1, natural order in and
- * out, any u64 input taken mod p, canonical outputs.  n_cols columns of 2^log_n elements, column c at element c << log_n; device
- * pointers, asynchronous on hip_stream (used exactly as passed).  In place (d_out == d_in) is allowed.
- * tmx_lde_goldilocks_device: evaluations on <omega_N> -> evaluations on the coset g <omega_M>, M = N << log_blowup (interpolate,
- * scale coefficient i by g^i, zero-pad, evaluate); d_out holds n_cols << (log_n + log_blowup) elements. */
+ * Own statement of the published definitions (plonky2_field is not in the reference tree; parity pinned against the CPU restatement
+ * under oracle/c):  p = 2^64 - 2^32 + 1, omega_N = root^(2^32 / N) for a primitive 2^32-th root of unity `root`; forward
+ * X[j] = sum_i x[i] omega_N^(ij), inverse with N^-1, natural order in and out, any u64 input taken mod p, canonical outputs.
+ * Domain constants: by default the ones recalled from plonky2's GoldilocksField -- POWER_OF_TWO_GENERATOR = 7277203076849721926 and coset
+ * shift MULTIPLICATIVE_GROUP_GENERATOR = 14293326489335486720 (the first is the second to the power (p-1)/2^32: checked in
+ * tests/test_ntt_oracle.py; plonky2's source is absent, so "recalled" stays the word).  tmx_ntt_set_domain selects another convention,
+ * e.g. g = 7 with root 0x185629dcda58878c (Plonky3 / winterfell).
+ * n_cols columns of 2^log_n elements, column c at element c << log_n; device pointers, asynchronous on hip_stream (used exactly as
+ * passed).  In place (d_out == d_in) is allowed.
+ * tmx_lde_goldilocks_device: evaluations on <omega_N> -> evaluations on the coset shift <omega_M>, M = N << log_blowup (interpolate,
+ * scale coefficient i by shift^i, zero-pad, evaluate); d_out holds n_cols << (log_n + log_blowup) elements. */
+int32_t tmx_ntt_set_domain(tmx_ctx* ctx, uint64_t root_2_32, uint64_t coset_shift);
 #define TMX_NTT_MAX_LOG 22
 int32_t tmx_ntt_goldilocks_device(tmx_ctx* ctx, uint32_t log_n, uint32_t n_cols, const uint64_t* d_in, uint64_t* d_out,
                                   int32_t inverse, void* hip_stream);

@@ -101,6 +101,7 @@ int tmxo_trace_sha256_1_check(const uint64_t* rows, const uint8_t* msg, size_t l
 /* ---- Goldilocks NTT / coset LDE (tmxo_ntt.c; parity unpinned against plonky2, see the file header) */
 uint64_t tmxo_gl_pow(uint64_t b, uint64_t e);
 uint64_t tmxo_gl_root(uint32_t log_n);
+void tmxo_ntt_set_domain(uint64_t root_2_32, uint64_t coset_shift);
 void tmxo_ntt(uint64_t* x, uint32_t log_n, int inverse);
 void tmxo_lde(const uint64_t* in, uint64_t* out, uint32_t log_n, uint32_t log_blowup);
 

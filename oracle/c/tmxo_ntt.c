@@ -2,7 +2,9 @@
  * Goldilocks NTT / coset low-degree extension, the primitive SURVEY 8(f) rank 2 names as the step after the witness fill of a
  * plonky2-style prover.  plonky2 itself is an un-vendored dependency (Cargo.lock: plonky2_field 0.2.0 @ mir-protocol/plonky2#4f8e6315),
  * so this restates the published definitions -- PARITY UNPINNED against plonky2's own code:
- *   p = 2^64 - 2^32 + 1, multiplicative generator g = 7, omega_(2^32) = g^((p-1)/2^32) = 0x185629dcda58878c,
+ *   p = 2^64 - 2^32 + 1; domain = (primitive 2^32-th root of unity, coset shift), by default the constants recalled from plonky2's
+ *   GoldilocksField (POWER_OF_TWO_GENERATOR 7277203076849721926 = MULTIPLICATIVE_GROUP_GENERATOR 14293326489335486720 ^ ((p-1)/2^32));
+ *   tmxo_ntt_set_domain selects another one, e.g. g = 7 with 0x185629dcda58878c (Plonky3 / winterfell),
  *   forward  X[j] = sum_i x[i] omega_N^(ij)   (natural order in and out),   inverse  x[i] = N^-1 sum_j X[j] omega_N^(-ij),
  *   coset LDE: coefficients c = INTT_N(x); y = NTT_M(c_i g^i, zero padded), M = N 2^b  (evaluations on the coset g <omega_M>).
  * Arithmetic with unsigned __int128 and %, textbook iterative radix-2 with a bit-reversal permutation: nothing shared with the HIP path. */
@@ -26,7 +28,9 @@ uint64_t tmxo_gl_pow(uint64_t b, uint64_t e) {
   }
   return r;
 }
-uint64_t tmxo_gl_root(uint32_t log_n) { return tmxo_gl_pow(tmxo_gl_pow(7, (GL_P - 1) >> 32), 1ull << (32 - log_n)); }
+static uint64_t g_root = 7277203076849721926ull, g_shift = 14293326489335486720ull;
+void tmxo_ntt_set_domain(uint64_t root_2_32, uint64_t coset_shift) { g_root = root_2_32; g_shift = coset_shift; }
+uint64_t tmxo_gl_root(uint32_t log_n) { return tmxo_gl_pow(g_root, 1ull << (32 - log_n)); }
 
 /* in place, natural order in and out; values are taken mod p */
 void tmxo_ntt(uint64_t* x, uint32_t log_n, int inverse) {
@@ -58,7 +62,7 @@ void tmxo_ntt(uint64_t* x, uint32_t log_n, int inverse) {
   }
 }
 
-/* out[0 .. n 2^b) = evaluations on the coset 7 <omega_(n 2^b)> of the polynomial with evaluations in[0 .. n) on <omega_n> */
+/* out[0 .. n 2^b) = evaluations on the coset shift <omega_(n 2^b)> of the polynomial with evaluations in[0 .. n) on <omega_n> */
 void tmxo_lde(const uint64_t* in, uint64_t* out, uint32_t log_n, uint32_t log_blowup) {
   const uint64_t n = 1ull << log_n, m = n << log_blowup;
   memset(out, 0, m * sizeof(uint64_t));
@@ -67,7 +71,7 @@ void tmxo_lde(const uint64_t* in, uint64_t* out, uint32_t log_n, uint32_t log_bl
   uint64_t s = 1;
   for (uint64_t i = 0; i < n; i++) {
     out[i] = gl_mul(out[i], s);
-    s = gl_mul(s, 7);
+    s = gl_mul(s, g_shift);
   }
   tmxo_ntt(out, log_n + log_blowup, 0);
 }

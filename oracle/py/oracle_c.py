@@ -207,6 +207,14 @@ def trace_check(kind, target_recs, trusted_recs, n, trace_rows):
 GL_P = 2**64 - 2**32 + 1
 
 
+PLONKY2_DOMAIN = (7277203076849721926, 14293326489335486720)   # recalled POWER_OF_TWO_GENERATOR, MULTIPLICATIVE_GROUP_GENERATOR
+G7_DOMAIN = (0x185629DCDA58878C, 7)                             # g = 7 (Plonky3 / winterfell)
+
+
+def ntt_set_domain(root_2_32, coset_shift):
+    lib().tmxo_ntt_set_domain(C.c_uint64(root_2_32), C.c_uint64(coset_shift))
+
+
 def gl_root(log_n):
     L = lib()
     L.tmxo_gl_root.restype = C.c_uint64

@@ -135,6 +135,7 @@ def lib():
     L.tmx_trace_rows_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.tmx_witness_batch_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tmx_ntt_set_domain.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
     L.tmx_ntt_goldilocks_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.tmx_lde_goldilocks_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tmx_selftest_fe_invert.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]

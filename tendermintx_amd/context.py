@@ -164,6 +164,10 @@ class Context:
         return out
 
     # ---- Goldilocks NTT / coset LDE (device pointers; columns of 2**log_n u64, column c at element c << log_n)
+    def ntt_set_domain(self, root_2_32, coset_shift):
+        """Domain constants of the NTT / LDE: a primitive 2^32-th root of unity and the coset shift (default: plonky2's, as recalled)."""
+        check(self._L.tmx_ntt_set_domain(self._h, C.c_uint64(root_2_32), C.c_uint64(coset_shift)), self._h)
+
     def ntt_device(self, log_n, n_cols, d_in, d_out, inverse=False, stream=None):
         check(self._L.tmx_ntt_goldilocks_device(self._h, log_n, n_cols, d_in, d_out, 1 if inverse else 0, self._stream(stream)), self._h)
 

@@ -239,6 +239,9 @@ struct tmx_ctx {
   static constexpr int EV_RING = EV_RING_DECL;
   hipEvent_t ev[EV_RING][4] = {};
   uint64_t n_calls = 0;
+  hipStream_t last_stream = nullptr;  // stream and end event of the previous batch (cross-stream callers are ordered behind it)
+  bool last_stream_valid = false;
+  hipEvent_t ev_done = nullptr;
   Program prog[2];
   void* d_lut[2] = {nullptr, nullptr};
   void* d_wave_sec[2] = {nullptr, nullptr};
@@ -267,10 +270,19 @@ struct tmx_ctx {
   void* d_pack = nullptr;  // dense / narrowed rows for tmx_witness_batch_opts (allocated on first use)
   uint64_t d_pack_bytes = 0;
   uint32_t sections = 3;  // TMX_SEC_* of the batch being enqueued
+  // schedule knobs of the enqueue path, read ONCE at context creation (getenv is not safe against a concurrent setenv, and the enqueue
+  // path is latency-critical): TMX_INPUTS_ON, TMX_PROOFSER_HOLD, TMX_EXT_EVENTS, TMX_TINY, TMX_FUSE_FIN (-1 = by size), TMX_WALK_PARTS (-1 = by size)
+  bool k_inputs_side2 = false, k_proofser_hold = false, k_ext_events = true, k_tiny = true;
+  int k_fuse_fin = -1, k_walk_parts = -1;
+  uint32_t k_mul_split = 0;
+  bool k_no_wide = false;
   // Goldilocks NTT: twiddle tables per transform size (built on first use), scratch for the four-step split / LDE
   void* d_ntt_w[TMX_NTT_MAX_LOG + 1] = {};
   void* d_ntt_tmp = nullptr;
   size_t ntt_tmp_bytes = 0;
+  // NTT domain: primitive 2^32-th root of unity and coset shift.  Default: the constants recalled from plonky2's GoldilocksField
+  // (POWER_OF_TWO_GENERATOR, MULTIPLICATIVE_GROUP_GENERATOR; self-consistent: the first is the second to the (p-1)/2^32).
+  uint64_t ntt_root = 7277203076849721926ull, ntt_shift = 14293326489335486720ull;
 };
 
 static int32_t fail(tmx_ctx* c, int32_t st, const std::string& msg) {
@@ -288,6 +300,7 @@ static ProofParams proof_params(const tmx_ctx* c, int32_t kind) {
   std::memset(&P, 0, sizeof P);
   P.kind = (uint32_t)kind; P.n = c->cfg.n_max; P.tree_nodes = tree_nodes(c->cfg.n_max); P.chain_id_len = c->cfg.chain_id_len;
   P.skip_max = c->cfg.skip_max;
+  P.no_wide = c->k_no_wide ? 1u : 0u;
   std::memcpy(P.chain_id, c->cfg.chain_id, sizeof P.chain_id);
   return P;
 }
@@ -323,6 +336,9 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   };
   // (every record / wait is a packet the command processor handles in order: the caller's stream carries the critical path, so
   // events are shared where they mark the same point and joins are chained through the side streams)
+  // One set of scratch buffers and join events per context: a call on another stream starts behind the previous call's end
+  // (a no-op in the usual case of one stream per context)
+  if (c->last_stream_valid && c->last_stream != s) HIPCK(c, hipStreamWaitEvent(s, c->ev_done, 0));
   HIPCK(c, hipEventRecord(ev[0], s));
   HIPCK(c, hipStreamWaitEvent(c->side, ev[0], 0));
   HIPCK(c, hipStreamWaitEvent(c->side3, ev[0], 0));
@@ -332,8 +348,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // (TMX_INPUTS_ON=side2 puts them behind the key chain on the high-priority stream instead.  At 1024 proofs the low-priority launch
   // is starved -- it runs from 0 to 1.8 ms and ends the step -- but the step is VALU-bound there (the serializer is 21 % of all VALU
   // instructions) and the high-priority placement only moves the time around: 1.894 vs 1.895 ms; at 256 proofs it costs 8 %.)
-  const char* ion = std::getenv("TMX_INPUTS_ON");
-  const bool inputs_hi = c->quad && c->ser_split && ion && ion[0] == 's' && ion[4] == '2';
+  const bool inputs_hi = c->quad && c->ser_split && c->k_inputs_side2;
   hipStream_t in_stream = inputs_hi ? c->side2 : c->side3;
   auto inputs_on_side3 = [&]() -> int32_t {
     const int32_t r = c->ser_split ? serialize(prog.mask_inputs, in_stream) : TMX_OK;
@@ -351,11 +366,9 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   HIPCK(c, hipEventRecord(evs[1], c->side));
 
   c->ev_mul_recorded = false;
-  const char* hold = std::getenv("TMX_PROOFSER_HOLD");
-  c->want_ev_mul = hold && hold[0] == '1';
+  c->want_ev_mul = c->k_proofser_hold;
   {  // ev[1] rides on the k_ed_fin dispatch itself when the quad path runs (TMX_EXT_EVENTS=0: a record packet behind it)
-    const char* xe = std::getenv("TMX_EXT_EVENTS");
-    c->ext_events = !(xe && xe[0] == '0');
+    c->ext_events = c->k_ext_events;
     c->fin_done = c->ext_events ? ev[1] : nullptr;
     c->fin_done_attached = false;
   }
@@ -408,6 +421,8 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     if ((st0 = serialize(prog.mask_inputs | prog.mask_proof | prog.mask_final | prog.mask_tail, s))) return st0;
   }
   HIPCK(c, hipEventRecord(ev[3], s));
+  c->last_stream = s; c->last_stream_valid = true;
+  c->ev_done = ev[3];
   c->n_calls++;
   return TMX_OK;
 }
@@ -428,7 +443,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   Q.d_uid_of_owner = c->d_uid_of_owner; Q.d_owners = c->d_owners; Q.d_keyrec = c->d_keyrec; Q.d_anchors = c->d_anchors; Q.d_keytab = c->d_keytab;
   Q.key_cap = c->key_cap; Q.key_w = c->key_w; Q.mode = c->dedup_mode;
   Q.fin_done = c->fin_done; c->fin_done = nullptr;
-  Q.anchor16 = c->anchor16; Q.keys16 = c->keys16; Q.mul16 = c->mul16;
+  Q.anchor16 = c->anchor16; Q.keys16 = c->keys16; Q.mul16 = c->mul16; Q.mul_split = c->k_mul_split;
   c->last_lanes = n_lanes;
   Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * c->parity;
   Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1);
@@ -437,8 +452,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   // dedup kernel, its hop to side2 and the empty table launches are 30 us of a 0.31 ms step.  Every lane is its own key: k_ed_keys starts
   // at once on side2 (it writes the identity maps itself), phase 1 on s, then h*A one wave per lane and the finish.  TMX_TINY=0: off.
   {
-    const char* tn = std::getenv("TMX_TINY");
-    c->last_tiny = n_lanes != 0 && n_lanes <= 512 && c->keys16 && c->mul16 && !(tn && tn[0] == '0');
+    c->last_tiny = n_lanes != 0 && n_lanes <= 512 && c->keys16 && c->mul16 && c->k_tiny;
   }
   if (c->last_tiny) {
     Q.mode = 0;
@@ -450,9 +464,8 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     rc = launch_ed_phase1(Q, s);
     if (rc) return rc;
     if ((e = hipStreamWaitEvent(s, c->ev_keys, 0)) != hipSuccess) return (int)e;
-    const char* ff = std::getenv("TMX_FUSE_FIN");
     // (up to 256 lanes: at 512 the 512 waves of the fused kernel slow k_proof, the longer of the two there, by more than they save)
-    const bool fuse = ff ? ff[0] != '0' : n_lanes <= 256;
+    const bool fuse = c->k_fuse_fin >= 0 ? c->k_fuse_fin != 0 : n_lanes <= 256;
     rc = launch_ed_mul_direct(Q, s, fuse);
     if (rc) return rc;
     if (!fuse) rc = launch_ed_fin(Q, s);
@@ -523,8 +536,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   if (rc) return rc;
   // The table walk can follow the table build part by part (partial sums in mulout).  Measured: +4 % step time at 256-512 proofs (the
   // parts sit on the caller's normal-priority queue beside the chain), -2.7 % at 1024, where the walk dominates -> by batch size.
-  const char* wp = std::getenv("TMX_WALK_PARTS");
-  const bool walk_parts = wp ? wp[0] == '1' : n_lanes >= 65536;
+  const bool walk_parts = c->k_walk_parts >= 0 ? c->k_walk_parts == 1 : n_lanes >= 65536;
   for (uint32_t p = 0; p < parts; p++) {
     if ((e = hipStreamWaitEvent(s, c->ev_part[p], 0)) != hipSuccess) return (int)e;
     if (p + 1 < parts) {
@@ -735,6 +747,17 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   HIPCK(c, hipMalloc(&c->d_nodes_t, B * (tn + 1) * 32));
   HIPCK(c, hipMalloc(&c->d_nodes_r, B * (tn + 1) * 32));
   HIPCK(c, hipMalloc(&c->d_reports, B * sizeof(tmx_report)));
+  {
+    const char* v;
+    c->k_inputs_side2 = (v = std::getenv("TMX_INPUTS_ON")) && std::string(v) == "side2";
+    c->k_proofser_hold = (v = std::getenv("TMX_PROOFSER_HOLD")) && v[0] == '1';
+    c->k_ext_events = !((v = std::getenv("TMX_EXT_EVENTS")) && v[0] == '0');
+    c->k_tiny = !((v = std::getenv("TMX_TINY")) && v[0] == '0');
+    c->k_fuse_fin = (v = std::getenv("TMX_FUSE_FIN")) ? (v[0] != '0' ? 1 : 0) : -1;
+    c->k_walk_parts = (v = std::getenv("TMX_WALK_PARTS")) ? (v[0] == '1' ? 1 : 0) : -1;
+    c->k_mul_split = (v = std::getenv("TMX_MUL_SPLIT")) ? (v[0] == '1' ? 1u : (v[0] == '4' ? 4u : 2u)) : 0u;
+    c->k_no_wide = (v = std::getenv("TMX_PROOF_WIDE")) && v[0] == '0';
+  }
   const char* ss = std::getenv("TMX_SER_SPLIT");
   c->ser_split = !(ss && ss[0] == '0');
   const char* mode = std::getenv("TMX_EDDSA");
@@ -752,9 +775,10 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   {
     const char* dm = std::getenv("TMX_DEDUP");
     if (dm && dm[0] >= '0' && dm[0] <= '2') c->dedup_mode = (uint32_t)(dm[0] - '0');
-    uint32_t cap = 1;
-    while (cap < 2 * lanes) cap <<= 1;
-    c->hash_mask = cap - 1;
+    if (lanes > ((size_t)1 << 30)) return fail(c, TMX_ERR_CAPACITY, "max_batch * n_max exceeds 2^30 lanes");
+    uint64_t cap = 1;
+    while (cap < 2 * (uint64_t)lanes) cap <<= 1;  // <= 2^31: the open-addressing table of the key deduplication
+    c->hash_mask = (uint32_t)(cap - 1);
     // tables pay off from ~4 lanes per key; automatic mode asks for 8, so lanes/8 keys suffice (mode 2: as many as fit)
     size_t kc = c->dedup_mode == 2 ? lanes : (lanes + 7) / 8;
     if (kc < 16) kc = lanes < 16 ? lanes : 16;
@@ -1075,7 +1099,7 @@ static int32_t ntt_table(tmx_ctx* c, uint32_t log_n, hipStream_t s, void** w) {
     const size_t half = log_n ? ((size_t)1 << (log_n - 1)) : 1;
     HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, hipMalloc(&c->d_ntt_w[log_n], half * 8));
-    int rc = launch_ntt_table(c->d_ntt_w[log_n], log_n, s);
+    int rc = launch_ntt_table(c->d_ntt_w[log_n], log_n, c->ntt_root, s);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_ntt_table launch: ") + hipGetErrorString((hipError_t)rc));
     HIPCK(c, hipStreamSynchronize(s));  // once per size: later calls may come on another stream
   }
@@ -1145,6 +1169,21 @@ static int32_t ntt_run(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const void* 
   return TMX_OK;
 }
 
+int32_t tmx_ntt_set_domain(tmx_ctx* c, uint64_t root_2_32, uint64_t coset_shift) {
+  if (!c) return TMX_ERR_BAD_ARG;
+  const uint64_t P = 0xffffffff00000001ull;
+  if (root_2_32 >= P || coset_shift == 0 || coset_shift >= P || gl_pow_host(root_2_32, 1ull << 31) != P - 1)
+    return fail(c, TMX_ERR_BAD_ARG, "root_2_32 must be a primitive 2^32-th root of unity of the Goldilocks field, coset_shift a non-zero element");
+  if (root_2_32 != c->ntt_root) {  // the twiddle tables belong to the old root
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipDeviceSynchronize());
+    for (auto& w : c->d_ntt_w)
+      if (w) { (void)hipFree(w); w = nullptr; }
+  }
+  c->ntt_root = root_2_32; c->ntt_shift = coset_shift;
+  return TMX_OK;
+}
+
 int32_t tmx_ntt_goldilocks_device(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const uint64_t* d_in, uint64_t* d_out, int32_t inverse,
                                   void* hip_stream) {
   if (!c || !d_in || !d_out) return TMX_ERR_BAD_ARG;
@@ -1174,7 +1213,7 @@ int32_t tmx_lde_goldilocks_device(tmx_ctx* c, uint32_t log_n, uint32_t log_blowu
   uint64_t* tmp = coef + (size_t)n_cols * M;
   st = ntt_run(c, log_n, n_cols, d_in, N, coef, M, tmp, true, s);  // coefficients into the first N slots of every M-slot column
   if (st) return st;
-  int rc = launch_lde_expand(coef, log_n, log_m, n_cols, s);           // c_i g^i, zero padding
+  int rc = launch_lde_expand(coef, log_n, log_m, n_cols, c->ntt_shift, s);  // c_i shift^i, zero padding
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_lde_expand launch: ") + hipGetErrorString((hipError_t)rc));
   return ntt_run(c, log_m, n_cols, coef, M, d_out, M, tmp, false, s);
 }

@@ -33,6 +33,7 @@ struct EdQuad {
   uint32_t mul16;    // 1: h*A of small launches without tables in the limb-parallel form (one wave per lane)
   uint32_t keys16;   // 1: keys are decoded in the limb-parallel form when there are few enough of them
   uint32_t anchor16; // 1: the anchor chain runs in the limb-parallel form (one wave per key), 0: one quad per key
+  uint32_t mul_split; // quads per lane in the table walk: 1, 2, 4, or 0 = by launch size (TMX_MUL_SPLIT)
   void* fin_done;    // event attached to the k_ed_fin dispatch as its completion signal (no separate record packet), or null
 };
 size_t quad_table_bytes(uint32_t w_bits);

@@ -94,6 +94,7 @@ constexpr uint32_t TR_LADDER_ROW = 65, TR_LADDER_ROWS = 256, TR_SHA512_ROW = 18,
 
 struct ProofParams {
   uint32_t kind, n, tree_nodes, chain_id_len;
+  uint32_t no_wide, pad_;  // 1: keep 256 threads per proof above N = 256 (TMX_PROOF_WIDE=0)
   uint64_t skip_max;
   uint8_t chain_id[52];
 };

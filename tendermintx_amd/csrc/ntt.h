@@ -17,8 +17,8 @@ struct NttPass {
   uint64_t scale;         // multiply every output by this (N^-1 on the last pass of an inverse transform), 1 = none
 };
 
-int launch_ntt_table(void* d_w, uint32_t log_n, void* stream);
+int launch_ntt_table(void* d_w, uint32_t log_n, uint64_t root_2_32, void* stream);
 int launch_ntt_pass(const NttPass& P, uint32_t n_cols, const void* d_in, void* d_out, const void* d_w, void* stream);
-int launch_lde_expand(void* d_buf, uint32_t log_n, uint32_t log_m, uint32_t n_cols, void* stream);
+int launch_lde_expand(void* d_buf, uint32_t log_n, uint32_t log_m, uint32_t n_cols, uint64_t shift, void* stream);
 
 }  // namespace tmx

@@ -1,6 +1,6 @@
 // Goldilocks NTT / coset low-degree extension on gfx950 (the step after the witness fill of a plonky2-style prover).
 // Definitions (the CPU checker under oracle/ restates them independently; plonky2 itself is not in the reference tree -- parity unpinned):
-//   p = 2^64 - 2^32 + 1, g = 7, omega_N = g^((p-1)/N);  X[j] = sum_i x[i] omega_N^(ij), natural order in and out.
+//   p = 2^64 - 2^32 + 1, omega_N = root^(2^32/N) for the context's 2^32-th root of unity (plonky2's by default, tmx_ntt_set_domain);  X[j] = sum_i x[i] omega_N^(ij), natural order in and out.
 //
 // One kernel does every pass: a workgroup loads a tile of T sub-transforms of length L = 2^log_l into LDS (T L <= 4096 elements =
 // 32 KB), runs the log_l radix-2 decimation-in-frequency stages there and stores the tile -- so a column of up to 2^11 elements
@@ -60,13 +60,12 @@ __device__ __forceinline__ uint64_t gl_pow(uint64_t b, uint64_t e) {
   }
   return r;
 }
-constexpr uint64_t GL_ROOT_2_32 = 0x185629dcda58878cull;  // 7^((p-1)/2^32)
 
 // W[i] = omega_N^i, i < N/2 (at least one entry)
-__global__ __launch_bounds__(256) void k_ntt_table(uint64_t* __restrict__ W, uint32_t log_n) {
+__global__ __launch_bounds__(256) void k_ntt_table(uint64_t* __restrict__ W, uint32_t log_n, uint64_t root_2_32) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, half = log_n ? (1ull << (log_n - 1)) : 1ull;
   if (i >= half) return;
-  uint64_t w = GL_ROOT_2_32;
+  uint64_t w = root_2_32;  // primitive 2^32-th root of unity of the configured domain (api.cpp: plonky2's by default)
   for (uint32_t k = log_n; k < 32; k++) w = gl_mul(w, w);
   W[i] = gl_pow(w, i);
 }
@@ -158,18 +157,18 @@ __global__ __launch_bounds__(256) void k_ntt_tile(NttPass P, const uint64_t* __r
 }
 
 // coefficient scaling of the coset LDE: c_i <- c_i g^i for i < n, zero for n <= i < m (per column of stride m)
-__global__ __launch_bounds__(256) void k_lde_expand(uint64_t* __restrict__ buf, uint32_t log_n, uint32_t log_m, uint64_t total) {
+__global__ __launch_bounds__(256) void k_lde_expand(uint64_t* __restrict__ buf, uint32_t log_n, uint32_t log_m, uint64_t total, uint64_t shift) {
   const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
   const uint64_t i = e & ((1ull << log_m) - 1);
   if (i >> log_n) { buf[e] = 0; return; }
-  buf[e] = gl_mul(buf[e], gl_pow(7, i));
+  buf[e] = gl_mul(buf[e], gl_pow(shift, i));
 }
 
-int launch_ntt_table(void* d_w, uint32_t log_n, void* stream) {
+int launch_ntt_table(void* d_w, uint32_t log_n, uint64_t root_2_32, void* stream) {
   const uint64_t half = log_n ? (1ull << (log_n - 1)) : 1ull;
   hipLaunchKernelGGL(k_ntt_table, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<uint64_t*>(d_w), log_n);
+                     reinterpret_cast<uint64_t*>(d_w), log_n, root_2_32);
   return (int)hipGetLastError();
 }
 int launch_ntt_pass(const NttPass& P, uint32_t n_cols, const void* d_in, void* d_out, const void* d_w, void* stream) {
@@ -179,10 +178,10 @@ int launch_ntt_pass(const NttPass& P, uint32_t n_cols, const void* d_in, void* d
                      reinterpret_cast<const uint64_t*>(d_in), reinterpret_cast<uint64_t*>(d_out), reinterpret_cast<const uint64_t*>(d_w));
   return (int)hipGetLastError();
 }
-int launch_lde_expand(void* d_buf, uint32_t log_n, uint32_t log_m, uint32_t n_cols, void* stream) {
+int launch_lde_expand(void* d_buf, uint32_t log_n, uint32_t log_m, uint32_t n_cols, uint64_t shift, void* stream) {
   const uint64_t total = (uint64_t)n_cols << log_m;
   hipLaunchKernelGGL(k_lde_expand, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<uint64_t*>(d_buf), log_n, log_m, total);
+                     reinterpret_cast<uint64_t*>(d_buf), log_n, log_m, total, shift);
   return (int)hipGetLastError();
 }
 

@@ -20,6 +20,36 @@ def env():
     ctx.close()
 
 
+def test_domain_conventions(env):
+    """Default domain = the constants recalled from plonky2's GoldilocksField; tmx_ntt_set_domain switches library and oracle to g = 7
+    (Plonky3 / winterfell) and back: the transform of a delta shows the root in use, an LDE the coset shift."""
+    torch, ctx, oc = env
+    s = torch.cuda.current_stream().cuda_stream
+    delta = np.zeros((1, 16), dtype=np.uint64)
+    delta[0, 1] = 1
+    try:
+        for root, shift in (oc.PLONKY2_DOMAIN, oc.G7_DOMAIN, oc.PLONKY2_DOMAIN):
+            ctx.ntt_set_domain(root, shift)
+            oc.ntt_set_domain(root, shift)
+            d = _to_dev(torch, delta)
+            out = torch.empty_like(d)
+            ctx.ntt_device(4, 1, d.data_ptr(), out.data_ptr(), False, s)
+            torch.cuda.synchronize()
+            w = pow(root, 1 << 28, P)
+            assert _to_host(out)[0].tolist() == [pow(w, j, P) for j in range(16)] == oc.ntt(delta[0]).tolist()
+            x = np.arange(1, 9, dtype=np.uint64).reshape(1, 8)
+            dx = _to_dev(torch, x)
+            lo = torch.empty(32, dtype=torch.int64, device="cuda:0")
+            ctx.lde_device(3, 2, 1, dx.data_ptr(), lo.data_ptr(), s)
+            torch.cuda.synchronize()
+            assert np.array_equal(_to_host(lo), oc.lde(x[0], 2))
+        with pytest.raises(Exception):
+            ctx.ntt_set_domain(5, 7)          # 5 is not a primitive 2^32-th root of unity
+    finally:
+        ctx.ntt_set_domain(*oc.PLONKY2_DOMAIN)
+        oc.ntt_set_domain(*oc.PLONKY2_DOMAIN)
+
+
 def _to_dev(torch, a):
     return torch.from_numpy(a.view(np.int64)).to("cuda:0")
 

@@ -13,8 +13,22 @@ import oracle_c as oc  # noqa: E402
 P = 2**64 - 2**32 + 1
 
 
+DOMAIN = {"root": oc.PLONKY2_DOMAIN[0], "shift": oc.PLONKY2_DOMAIN[1]}   # the default of both the oracle and the library
+
+
+@pytest.fixture(params=["plonky2", "g7"], autouse=True)
+def domain(request):
+    """Every test runs on both conventions: the constants recalled from plonky2's GoldilocksField (default) and g = 7."""
+    root, shift = oc.PLONKY2_DOMAIN if request.param == "plonky2" else oc.G7_DOMAIN
+    DOMAIN["root"], DOMAIN["shift"] = root, shift
+    oc.ntt_set_domain(root, shift)
+    yield request.param
+    oc.ntt_set_domain(*oc.PLONKY2_DOMAIN)
+    DOMAIN["root"], DOMAIN["shift"] = oc.PLONKY2_DOMAIN
+
+
 def _root(log_n):
-    return pow(pow(7, (P - 1) >> 32, P), 1 << (32 - log_n), P)
+    return pow(DOMAIN["root"], 1 << (32 - log_n), P)
 
 
 def _dft(x, inverse=False):
@@ -29,10 +43,14 @@ def _dft(x, inverse=False):
     return out
 
 
-def test_constants():
-    # the 2^32-th root of unity recalled from plonky2's GoldilocksField (POWER_OF_TWO_GENERATOR) is what g = 7 generates
-    assert pow(7, (P - 1) >> 32, P) == 1753635133440165772 == 0x185629DCDA58878C
-    assert oc.gl_root(32) == 1753635133440165772 and oc.gl_root(1) == P - 1 and oc.gl_root(0) == 1
+def test_constants(domain):
+    # g = 7 (Plonky3 / winterfell): the 2^32-th root of unity it generates
+    assert pow(7, (P - 1) >> 32, P) == 1753635133440165772 == 0x185629DCDA58878C == oc.G7_DOMAIN[0]
+    # the pair recalled from plonky2's GoldilocksField is self-consistent: POWER_OF_TWO_GENERATOR = MULTIPLICATIVE_GROUP_GENERATOR^((p-1)/2^32),
+    # and the latter generates the whole multiplicative group (p - 1 = 2^32 * 3 * 5 * 17 * 257 * 65537)
+    root, gen = oc.PLONKY2_DOMAIN
+    assert pow(gen, (P - 1) >> 32, P) == root and all(pow(gen, (P - 1) // q, P) != 1 for q in (2, 3, 5, 17, 257, 65537))
+    assert oc.gl_root(32) == DOMAIN["root"] and oc.gl_root(1) == P - 1 and oc.gl_root(0) == 1
     for k in range(1, 33):
         w = oc.gl_root(k)
         assert w == _root(k) and pow(w, 1 << k, P) == 1 and pow(w, 1 << (k - 1), P) == P - 1
@@ -81,5 +99,5 @@ def test_lde_evaluates_the_interpolant_on_the_coset(log_n, log_blowup):
     x = rng.integers(0, P, size=n, dtype=np.uint64)
     coeffs = _dft(x, inverse=True)
     wm = _root(log_n + log_blowup)
-    want = [sum(c * pow(7 * pow(wm, j, P) % P, i, P) for i, c in enumerate(coeffs)) % P for j in range(m)]
+    want = [sum(c * pow(DOMAIN["shift"] * pow(wm, j, P) % P, i, P) for i, c in enumerate(coeffs)) % P for j in range(m)]
     assert oc.lde(x, log_blowup).tolist() == want
