@@ -5,7 +5,7 @@ import sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name,start,end,stream_id from kernels order by start").fetchall()
 # a step starts with k_ed_dedup; print the step before the last one
-ded = [i for i, r in enumerate(rows) if "k_ed_dedup" in r[0]]
+ded = [i for i, r in enumerate(rows) if "k_ed_dedup" in r[0]] or [i for i, r in enumerate(rows) if "k_ed_keys" in r[0]]
 i1, i2 = ded[-2] - 1, ded[-1] - 1
 t0 = None
 for r in rows[i1 + 1:i2 + 1]:
