@@ -7,7 +7,7 @@
 //   get_vote_from_commit_sig                                                            reference circuits/input/tendermint_utils.rs:404-441
 //   header -> 14 protobuf field encodings                                               reference circuits/input/tendermint_utils.rs:374-393
 // The protobuf / amino-JSON shapes come from tendermint-rs 0.33.2 + tendermint-proto (un-vendored); they are
-// restated here from the wire format and pinned by the reference fixtures (tests/test_codec.py).
+// restated here from the wire format and pinned by the reference fixtures (tests/test_abi_codec.py).
 // The host Ed25519 check of conversion.rs:48-49 is NOT done here: it runs on the GPU (k_eddsa) and is reported as
 // tmx_report.first_bad_sig.
 #include <algorithm>

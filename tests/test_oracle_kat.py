@@ -244,3 +244,35 @@ def test_sc_fold_model():
             if y >= ell:
                 y -= ell
         assert y == x % ell
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """`make asan` (oracle/c/Makefile): the witness, the trace generator and its checker on a golden case under -fsanitize=address,undefined,
+    in a subprocess (the sanitizer runtime has to be loaded first)."""
+    import os
+    import subprocess
+    import sys
+    cdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "c")
+    subprocess.check_call(["make", "-s", "-C", cdir, "asan"])
+    asan_rt = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    code = r'''
+import ctypes as C, json, os, sys
+import numpy as np
+L = C.CDLL(os.path.join(sys.argv[1], "libtmx_oracle_asan.so"))
+c = json.load(open(sys.argv[2]))["skip_10000_10500_n4"]
+p, t, r = bytes.fromhex(c["proof"]), bytes.fromhex(c["target"]), bytes.fromhex(c["trusted"])
+L.tmxo_elem_count.restype = C.c_size_t; L.tmxo_elem_count.argtypes = [C.c_int, C.c_size_t]
+out = np.zeros(L.tmxo_elem_count(0, 4), dtype=np.uint64)
+rep = (C.c_uint8 * 64)()
+assert L.tmxo_witness(0, p, t, r, C.c_uint32(4), b"mocha-4", C.c_uint32(7), C.c_uint64(100800), out.ctypes.data_as(C.c_void_p), rep) == 0
+L.tmxo_trace_elem_count.restype = C.c_size_t; L.tmxo_trace_elem_count.argtypes = [C.c_int, C.c_size_t]
+tr = np.zeros(L.tmxo_trace_elem_count(0, 4), dtype=np.uint64)
+assert L.tmxo_trace(0, t, r, C.c_uint32(4), tr.ctypes.data_as(C.c_void_p)) == 0
+L.tmxo_trace_check.restype = C.c_longlong
+assert L.tmxo_trace_check(0, t, r, C.c_uint32(4), tr.ctypes.data_as(C.c_void_p)) == 0
+print("asan ok")
+'''
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cases.json")
+    env = dict(os.environ, LD_PRELOAD=asan_rt, ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run([sys.executable, "-c", code, cdir, golden], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "asan ok" in out.stdout, out.stderr[-2000:]
