@@ -415,10 +415,10 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
             "what": "row-level trace of both scalar multiplications (256 rows x 65 elements each), SHA-512 / leaf SHA-256 round states, N x N match "
                     "bits of every lane of the batch: this build's own row specification, DESIGN.md 'Level-2 trace rows'",
             "sections": l2, "ms_per_batch": l2["all"]["ms"], "ms_per_proof": round(l2["all"]["ms"] / P, 5),
-            "roofline": {"kernel": "k_trace_ladder", "bound": "hbm", "achieved": l2["ladders"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "k_trace_ladder_pass1 + _pass2", "bound": "hbm", "achieved": l2["ladders"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(l2["ladders"]["gbs"] / HBM_PEAK_GBS, 4), "algorithmic_bytes": l2["ladders"]["bytes"], "traffic": None,
-                         "note": "one thread per ladder (65536 threads = one wave per SIMD at 256 proofs): bounded by the dependent chain of "
-                                 "~6 k VALU instructions per row, not yet by HBM"}}
+                         "note": "pass 1 (the double-and-add chain, one thread per ladder) is latency-bound, pass 2 (inversions, canonical limbs, "
+                                 "stores; one thread per eight rows) issue-bound at ~44 % of the slots: not yet HBM-bound (DESIGN.md section 3)"}}
         tr0 = d_tr[:te].cpu().numpy().view(np.uint64)
         del d_tr
     except Exception as e:  # the trace rows are a widening row: never let them take the headline line down

@@ -267,6 +267,7 @@ struct tmx_ctx {
   // staging for the host-buffer entry points
   void *d_in_proofs = nullptr, *d_in_targets = nullptr, *d_in_trusteds = nullptr, *d_out = nullptr;
   uint64_t d_out_elems = 0;
+  void* d_trace_tmp = nullptr;  // projective ladder points between the two passes of the Level-2 ladder kernels (allocated on first use)
   void* d_pack = nullptr;  // dense / narrowed rows for tmx_witness_batch_opts (allocated on first use)
   uint64_t d_pack_bytes = 0;
   uint32_t sections = 3;  // TMX_SEC_* of the batch being enqueued
@@ -666,7 +667,7 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   }
   void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_owner_of, c->d_uid_of_owner, c->d_owners, c->d_keyrec,
                   c->d_anchors, c->d_keytab, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
-                  c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out, c->d_pack};
+                  c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out, c->d_pack, c->d_trace_tmp};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (void* w : c->d_ntt_w)
@@ -894,8 +895,12 @@ int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const
   if (kind == TMX_KIND_SKIP && !d_trusteds) return fail(c, TMX_ERR_BAD_ARG, "skip needs the trusted hash fields");
   if (n_proofs > c->cfg.max_batch) return fail(c, TMX_ERR_CAPACITY, "n_proofs exceeds the context's max_batch");
   if (n_proofs == 0) return TMX_OK;
+  if ((sections & TMX_TRACE_LADDERS) && !c->d_trace_tmp) {  // 61 KB per ladder between the two ladder passes: allocated on first use
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipMalloc(&c->d_trace_tmp, trace_tmp_bytes(c->cfg.n_max, c->cfg.max_batch)));
+  }
   int rc = launch_trace((uint32_t)kind, c->cfg.n_max, n_proofs, d_targets, d_trusteds, reinterpret_cast<const uint8_t*>(c->d_tl) + TL_OFF_ED, TL_STRIDE,
-                        d_trace_out, sections, hip_stream);
+                        d_trace_out, c->d_trace_tmp, sections, hip_stream);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_trace launch: ") + hipGetErrorString((hipError_t)rc));
   return TMX_OK;
 }

@@ -5,10 +5,8 @@
 // constraint checker under oracle/c).  266 KB of ladder rows per lane: this is the part of the witness that is written, not computed
 // -- 9.8 GB per 256-proof batch at N = 128.
 //
-//   k_trace_ladder   one thread per (lane, ladder): double-and-add in extended coordinates, the 2 x 8 new points of eight rows inverted
-//                    together (Montgomery's trick around one safegcd inversion), rows staged in LDS and written by the whole wave so
-//                    that every store instruction covers 512 contiguous bytes of ONE ladder (a thread-per-ladder store would scatter
-//                    64 x 8 bytes over 64 ladders 133 KB apart)
+//   k_trace_ladder_pass1 / _pass2   the double-and-add chain in extended coordinates (one thread per ladder), then the inversions, canonical
+//                    limbs and stores with one thread per (ladder, eight rows): see the comment at the kernels
 //   k_trace_sha512   one thread per lane, four rounds per flush        k_trace_sha256   one thread per (set, lane)
 //   k_trace_match    one thread per (i, j)
 #include "trace.h"
@@ -49,12 +47,82 @@ __device__ __forceinline__ void coop_flush(const uint32_t (*stage)[NV + 1], cons
   __syncthreads();
 }
 
-__global__ __launch_bounds__(64) void k_trace_ladder(uint32_t n_lanes, uint32_t n, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
-                                                     uint32_t ed_stride, uint64_t* __restrict__ out, uint64_t proof_stride) {
+// ---- ladders, in two passes so that the expensive half (inversions, canonical limbs, the stores) is not a 256-step chain:
+//   pass 1  one thread per (lane, ladder): the double-and-add chain in extended coordinates; (X:Y:Z) of dbl_r and add_r of every row go
+//           to a scratch buffer (240 B per row, laid out [block][row][word][thread] so that every store / load instruction is coalesced)
+//   pass 2  one thread per (ladder, batch of eight rows), a wave = the same 64 ladders as in pass 1: the 16 points of the batch plus the
+//           accumulator it starts from made affine together (Montgomery's trick around one safegcd inversion), rows staged in LDS and
+//           written by the whole wave (every store instruction covers 512 contiguous bytes of ONE ladder).
+// 32 x the threads of the one-pass form for the part that is 60 % of the instructions.  Measured per 256-proof batch at N = 128: one pass
+// 8.3 ms (7.2 ms at 32 proofs: a pure latency chain); two passes 2.75 + 4.25 ms (1.9 ms at 32 proofs).
+struct LadderIn {
+  uint32_t sc[8];  // the scalar
+  ge_affc P;       // the point that is added
+  bool decoded;
+};
+__device__ __forceinline__ LadderIn ladder_inputs(uint32_t lane, uint32_t k, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
+                                                  uint32_t ed_stride, bool want_point) {
+  LadderIn L;
+  const uint8_t* rec = in_target + (size_t)lane * VR_STRIDE;
+  const uint8_t* er = ed + (size_t)lane * ed_stride;
+  const bool is_signed = rec[VR_OFF_FLAGS] & 1;
+  L.decoded = ld32(er + ED_OFF_DECODE_OK) != 0;
+  uint32_t pw[16];
+#pragma unroll
+  for (int w = 0; w < 8; w++) {
+    L.sc[w] = k ? ld32(er + ED_OFF_H + 4 * w) : (is_signed ? ld32(rec + VR_OFF_SIG + 32 + 4 * w) : T_DUMMY_SIG[8 + w]);
+    pw[w] = (k && L.decoded) ? ld32(er + ED_OFF_PTS + 4 * w) : T_BX[w];           // A.x | B.x (an undecodable lane computes on B, stores zeros)
+    pw[8 + w] = (k && L.decoded) ? ld32(er + ED_OFF_PTS + 32 + 4 * w) : T_BY[w];  // A.y | B.y
+  }
+  if (want_point) {
+    const fe x = fe_from_words(pw), y = fe_from_words(pw + 8);
+    L.P.ypx = fe_add(y, x); L.P.ymx = fe_sub(y, x); L.P.xy2d = fe_mul(fe_mul(x, y), K_2D);
+  }
+  return L;
+}
+__device__ __forceinline__ uint32_t scalar_bit(const uint32_t sc[8], int r) {  // bit 255 - r
+  const int b = 255 - r;
+  uint32_t word = sc[0];
+#pragma unroll
+  for (int w = 1; w < 8; w++) word = (b >> 5) == w ? sc[w] : word;
+  return (word >> (b & 31)) & 1u;
+}
+constexpr uint32_t TR_PT_WORDS = 60;  // per row in the scratch buffer: dbl (X, Y, Z), add (X, Y, Z), ten limbs each
+
+__global__ __launch_bounds__(64) void k_trace_ladder_pass1(uint32_t n_lanes, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
+                                                           uint32_t ed_stride, int32_t* __restrict__ pts) {
+  const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t;
+  const bool live = id < 2u * n_lanes;
+  const LadderIn L = ladder_inputs(live ? id >> 1 : 0u, id & 1u, in_target, ed, ed_stride, true);
+  int32_t* o = pts + (size_t)blockIdx.x * TR_LADDER_ROWS * TR_PT_WORDS * 64u + t;
+  ge_ext acc = ge_identity();
+#pragma unroll 1
+  for (int r = 0; r < (int)TR_LADDER_ROWS; r++) {
+    const uint32_t bit = scalar_bit(L.sc, r);
+    const ge_ext d = comp_to_ext(ge_double(ext_to_proj(acc)));
+    const ge_ext a = comp_to_ext(ge_add_affc(d, L.P));
+    int32_t* row = o + (size_t)r * TR_PT_WORDS * 64u;
+#pragma unroll
+    for (int l = 0; l < 10; l++) {
+      row[(0 + l) * 64] = d.X.v[l]; row[(10 + l) * 64] = d.Y.v[l]; row[(20 + l) * 64] = d.Z.v[l];
+      row[(30 + l) * 64] = a.X.v[l]; row[(40 + l) * 64] = a.Y.v[l]; row[(50 + l) * 64] = a.Z.v[l];
+    }
+    acc.X = fe_select(d.X, a.X, bit); acc.Y = fe_select(d.Y, a.Y, bit); acc.Z = fe_select(d.Z, a.Z, bit); acc.T = fe_select(d.T, a.T, bit);
+  }
+}
+
+// Everything below is unrolled with compile-time indices: no indexed private array (the first version kept X, Y, Z, prefix products and the
+// affine words of a batch in 4 KB of scratch per thread -- 8 GB of spill traffic per 256-proof batch, twice the rows themselves).
+// Montgomery's trick with SUFFIX products so that the points come out in row order: total = Z_0 ... Z_16, then for i = 0, 1, ...:
+// 1 / Z_i = inv_i * suf_{i+1} with inv_i = 1 / suf_i, inv_{i+1} = inv_i * Z_i.  Only suf_4, suf_8, suf_12, suf_16 are kept (40 VGPRs);
+// the three in between are recomputed per group of four from the Z's (re-read from the scratch buffer: coalesced, mostly L2).
+__global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t n_lanes, uint32_t n, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
+                                                           uint32_t ed_stride, const int32_t* __restrict__ pts, uint64_t* __restrict__ out,
+                                                           uint64_t proof_stride) {
   __shared__ uint32_t stage[64][TR_LADDER_ROW + 1];
   __shared__ uint64_t s_base[64];
   __shared__ uint8_t s_live[64];
-  const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t;
+  const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t, c = blockIdx.y;  // batch c = rows CH c .. CH c + CH - 1
   const bool live = id < 2u * n_lanes;
   const uint32_t lane = live ? id >> 1 : 0u, k = id & 1u;
   {
@@ -62,74 +130,73 @@ __global__ __launch_bounds__(64) void k_trace_ladder(uint32_t n_lanes, uint32_t 
     s_base[t] = (uint64_t)p * proof_stride + (uint64_t)((2u * i + k) * TR_LADDER_ROWS) * TR_LADDER_ROW;
     s_live[t] = live ? 1 : 0;
   }
-  const uint8_t* rec = in_target + (size_t)lane * VR_STRIDE;
-  const uint8_t* er = ed + (size_t)lane * ed_stride;
-  const bool is_signed = rec[VR_OFF_FLAGS] & 1;
-  const bool decoded = ld32(er + ED_OFF_DECODE_OK) != 0;
-  uint32_t sc[8], pw[16];
+  const LadderIn L = ladder_inputs(lane, k, in_target, ed, ed_stride, false);
+  const int32_t* src = pts + (size_t)blockIdx.x * TR_LADDER_ROWS * TR_PT_WORDS * 64u + t;
+  static_assert(CH == 8, "the unrolled schedule below is written for batches of eight rows (17 points)");
+  const uint32_t start_bit = c ? scalar_bit(L.sc, (int)(CH * c) - 1) : 0u;
+  // point i of the batch: 0 = the accumulator the batch starts from (row CH c - 1's nxt; the identity for c = 0); 1 + 2j / 2 + 2j = dbl / add of row j
+  auto coord = [&](int i, int which_coord) -> fe {  // which_coord: 0 X, 1 Y, 2 Z
+    fe v;
+    if (i == 0 && c == 0) { v = which_coord == 0 ? fe_zero() : fe_one(); return v; }
+    const int r = i == 0 ? (int)(CH * c) - 1 : (int)(CH * c) + (i - 1) / 2;
+    const uint32_t which = i == 0 ? start_bit : (uint32_t)((i - 1) & 1);
+    const int32_t* row = src + (size_t)r * TR_PT_WORDS * 64u + (size_t)(which * 30u + (uint32_t)which_coord * 10u) * 64u;
 #pragma unroll
-  for (int w = 0; w < 8; w++) {
-    sc[w] = k ? ld32(er + ED_OFF_H + 4 * w) : (is_signed ? ld32(rec + VR_OFF_SIG + 32 + 4 * w) : T_DUMMY_SIG[8 + w]);
-    pw[w] = (k && decoded) ? ld32(er + ED_OFF_PTS + 4 * w) : T_BX[w];           // A.x | B.x (an undecodable lane computes on B, stores zeros)
-    pw[8 + w] = (k && decoded) ? ld32(er + ED_OFF_PTS + 32 + 4 * w) : T_BY[w];  // A.y | B.y
+    for (int l = 0; l < 10; l++) v.v[l] = row[l * 64];
+    return v;
+  };
+  fe ck[4];  // suf_4, suf_8, suf_12, suf_16
+  fe tot = coord(16, 2);
+  ck[3] = tot;
+#pragma unroll
+  for (int i = 15; i >= 0; i--) {
+    tot = fe_mul(coord(i, 2), tot);
+    if (i == 12) ck[2] = tot;
+    if (i == 8) ck[1] = tot;
+    if (i == 4) ck[0] = tot;
   }
-  ge_affc P;
-  {
-    const fe x = fe_from_words(pw), y = fe_from_words(pw + 8);
-    P.ypx = fe_add(y, x); P.ymx = fe_sub(y, x); P.xy2d = fe_mul(fe_mul(x, y), K_2D);
-  }
-  ge_ext acc = ge_identity();
-  uint32_t accw[16];
+  fe inv = fe_invert_safegcd(tot);
+  const uint32_t z = L.decoded ? 0xffffffffu : 0u;  // an undecodable lane: all-zero rows (Level-1 reports zero points there too)
+  uint32_t accw[16], dblw[16];
+  auto affine = [&](int i, const fe& zinv, uint32_t w[16]) {
+    fe_to_words(fe_mul(coord(i, 0), zinv), w);
+    fe_to_words(fe_mul(coord(i, 1), zinv), w + 8);
+  };
+  auto emit_point = [&](int i, const fe& zinv) {  // points arrive in order: start, dbl_0, add_0, dbl_1, ...
+    uint32_t w[16];
+    affine(i, zinv, w);
+    if (i == 0) {
 #pragma unroll
-  for (int w = 0; w < 16; w++) accw[w] = w == 8 ? 1u : 0u;  // (0, 1)
-  fe X[2 * CH], Y[2 * CH], Z[2 * CH], pre[2 * CH];
-  uint32_t W[2 * CH][16];
-#pragma unroll 1
-  for (int c = 0; c < (int)TR_LADDER_ROWS / CH; c++) {
-    uint32_t bits = 0;
-#pragma unroll 1
-    for (int j = 0; j < CH; j++) {
-      const int b = 255 - (c * CH + j);
-      uint32_t word = sc[0];
+      for (int q = 0; q < 16; q++) accw[q] = w[q];
+    } else if (i & 1) {
 #pragma unroll
-      for (int w = 1; w < 8; w++) word = (b >> 5) == w ? sc[w] : word;
-      const uint32_t bit = (word >> (b & 31)) & 1u;
-      const ge_ext d = comp_to_ext(ge_double(ext_to_proj(acc)));
-      const ge_ext a = comp_to_ext(ge_add_affc(d, P));
-      X[2 * j] = d.X; Y[2 * j] = d.Y; Z[2 * j] = d.Z;
-      X[2 * j + 1] = a.X; Y[2 * j + 1] = a.Y; Z[2 * j + 1] = a.Z;
-      acc.X = fe_select(d.X, a.X, bit); acc.Y = fe_select(d.Y, a.Y, bit); acc.Z = fe_select(d.Z, a.Z, bit); acc.T = fe_select(d.T, a.T, bit);
-      bits |= bit << j;
-    }
-    // Montgomery's trick over the 2 CH denominators of this batch
-    pre[0] = Z[0];
-#pragma unroll 1
-    for (int i = 1; i < 2 * CH; i++) pre[i] = fe_mul(pre[i - 1], Z[i]);
-    fe inv = fe_invert_safegcd(pre[2 * CH - 1]);
-#pragma unroll 1
-    for (int i = 2 * CH - 1; i >= 0; i--) {
-      const fe zi = i ? fe_mul(inv, pre[i - 1]) : inv;
-      inv = fe_mul(inv, Z[i]);
-      fe_to_words(fe_mul(X[i], zi), W[i]);
-      fe_to_words(fe_mul(Y[i], zi), W[i] + 8);
-    }
-#pragma unroll 1
-    for (int j = 0; j < CH; j++) {
-      const uint32_t bit = (bits >> j) & 1u;
-      const uint32_t z = decoded ? 0xffffffffu : 0u;  // an undecodable lane: all-zero rows (Level-1 reports zero points there too)
+      for (int q = 0; q < 16; q++) dblw[q] = w[q];
+    } else {
+      const int j = (i - 2) / 2;
+      const uint32_t bit = scalar_bit(L.sc, (int)(CH * c) + j);
       stage[t][0] = bit & z;
 #pragma unroll
-      for (int w = 0; w < 16; w++) {
-        const uint32_t nx = bit ? W[2 * j + 1][w] : W[2 * j][w];
-        stage[t][1 + w] = accw[w] & z;
-        stage[t][17 + w] = W[2 * j][w] & z;
-        stage[t][33 + w] = W[2 * j + 1][w] & z;
-        stage[t][49 + w] = nx & z;
-        accw[w] = nx;
+      for (int q = 0; q < 16; q++) {
+        const uint32_t nx = bit ? w[q] : dblw[q];
+        stage[t][1 + q] = accw[q] & z;
+        stage[t][17 + q] = dblw[q] & z;
+        stage[t][33 + q] = w[q] & z;
+        stage[t][49 + q] = nx & z;
+        accw[q] = nx;
       }
-      coop_flush<TR_LADDER_ROW>(stage, s_base, s_live, (uint64_t)(c * CH + j) * TR_LADDER_ROW, out);
+      coop_flush<TR_LADDER_ROW>(stage, s_base, s_live, (uint64_t)(CH * c + j) * TR_LADDER_ROW, out);
     }
+  };
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const fe z3 = coord(4 * g + 3, 2), z2 = coord(4 * g + 2, 2), z1 = coord(4 * g + 1, 2), z0 = coord(4 * g, 2);
+    const fe s3 = fe_mul(z3, ck[g]), s2 = fe_mul(z2, s3), s1 = fe_mul(z1, s2);
+    emit_point(4 * g, fe_mul(inv, s1)); inv = fe_mul(inv, z0);
+    emit_point(4 * g + 1, fe_mul(inv, s2)); inv = fe_mul(inv, z1);
+    emit_point(4 * g + 2, fe_mul(inv, s3)); inv = fe_mul(inv, z2);
+    emit_point(4 * g + 3, fe_mul(inv, ck[g])); inv = fe_mul(inv, z3);
   }
+  emit_point(16, inv);
 }
 
 // SHA-512(R | A | M) of the effective triple of one lane (at most two blocks), 18 values per round
@@ -303,16 +370,23 @@ uint64_t trace_elems(uint32_t kind, uint32_t n) {
   return (uint64_t)n * (2ull * TR_LADDER_ROWS * TR_LADDER_ROW + 2ull * 80 * TR_SHA512_ROW + sets * 64 * TR_SHA256_ROW) + (kind == 0 ? (uint64_t)n * n : 0);
 }
 
+size_t trace_tmp_bytes(uint32_t n, uint32_t n_proofs) { return (size_t)((2ull * n_proofs * n + 63) / 64) * 64 * TR_LADDER_ROWS * TR_PT_WORDS * 4; }
+
 int launch_trace(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_trusted, const void* d_ed, uint32_t ed_stride, void* d_out,
-                 uint32_t sections, void* stream) {
+                 void* d_tmp, uint32_t sections, void* stream) {
   if (n_proofs == 0) return 0;
   const uint32_t lanes = n_proofs * n;
   const uint64_t stride = trace_elems(kind, n);
   uint64_t* out = reinterpret_cast<uint64_t*>(d_out);
   const uint8_t* tg = reinterpret_cast<const uint8_t*>(d_target);
   const uint8_t* tr = reinterpret_cast<const uint8_t*>(d_trusted);
-  if (sections & 1u)
-    hipLaunchKernelGGL(k_trace_ladder, dim3((2 * lanes + 63) / 64), dim3(64), 0, S_(stream), lanes, n, tg, reinterpret_cast<const uint8_t*>(d_ed), ed_stride, out, stride);
+  if (sections & 1u) {
+    const uint32_t blocks = (2 * lanes + 63) / 64;
+    hipLaunchKernelGGL(k_trace_ladder_pass1, dim3(blocks), dim3(64), 0, S_(stream), lanes, tg, reinterpret_cast<const uint8_t*>(d_ed), ed_stride,
+                       reinterpret_cast<int32_t*>(d_tmp));
+    hipLaunchKernelGGL(k_trace_ladder_pass2, dim3(blocks, TR_LADDER_ROWS / CH), dim3(64), 0, S_(stream), lanes, n, tg, reinterpret_cast<const uint8_t*>(d_ed),
+                       ed_stride, reinterpret_cast<const int32_t*>(d_tmp), out, stride);
+  }
   if (sections & 2u) hipLaunchKernelGGL(k_trace_sha512, dim3((lanes + 63) / 64), dim3(64), 0, S_(stream), lanes, n, tg, out, stride);
   if (sections & 4u)
     hipLaunchKernelGGL(k_trace_sha256, dim3(((kind == 0 ? 2 : 1) * lanes + 63) / 64), dim3(64), 0, S_(stream), kind, lanes, n, tg, tr, out, stride);
