@@ -267,6 +267,7 @@ struct tmx_ctx {
   // staging for the host-buffer entry points
   void *d_in_proofs = nullptr, *d_in_targets = nullptr, *d_in_trusteds = nullptr, *d_out = nullptr;
   uint64_t d_out_elems = 0;
+  hipEvent_t ev_trace[5] = {};  // ladder segments done (4) + the side stream's pass 2 done
   void* d_trace_tmp = nullptr;  // projective ladder points between the two passes of the Level-2 ladder kernels (allocated on first use)
   void* d_pack = nullptr;  // dense / narrowed rows for tmx_witness_batch_opts (allocated on first use)
   uint64_t d_pack_bytes = 0;
@@ -688,6 +689,8 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   if (c->ev_hash_clean) (void)hipEventDestroy(c->ev_hash_clean);
   if (c->ev_mul) (void)hipEventDestroy(c->ev_mul);
   if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
+  for (hipEvent_t e : c->ev_trace)
+    if (e) (void)hipEventDestroy(e);
   if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
   if (c->have_streams) release_streams(c->cfg.device);
   delete c;
@@ -899,9 +902,38 @@ int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const
     HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, hipMalloc(&c->d_trace_tmp, trace_tmp_bytes(c->cfg.n_max, c->cfg.max_batch)));
   }
-  int rc = launch_trace((uint32_t)kind, c->cfg.n_max, n_proofs, d_targets, d_trusteds, reinterpret_cast<const uint8_t*>(c->d_tl) + TL_OFF_ED, TL_STRIDE,
-                        d_trace_out, c->d_trace_tmp, sections, hip_stream);
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  const uint8_t* edr = reinterpret_cast<const uint8_t*>(c->d_tl) + TL_OFF_ED;
+  const uint32_t n = c->cfg.n_max;
+  int rc = 0;
+  if (sections & TMX_TRACE_LADDERS) {
+    // The chain (pass 1: 1024 latency-bound waves per 256 proofs) in four segments of 64 rows on the caller's stream; the affine rows of a
+    // segment (pass 2: issue-bound) follow on the side stream while the next segment is being doubled.  TMX_TRACE_SEGMENTS=1: one after the other.
+    const char* sg = std::getenv("TMX_TRACE_SEGMENTS");
+    const uint32_t segs = sg && sg[0] == '1' ? 1u : 4u;
+    for (auto& e : c->ev_trace)
+      if (!e) HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (uint32_t g = 0; g < segs && !rc; g++) {
+      const uint32_t r0 = TR_LADDER_ROWS * g / segs, r1 = TR_LADDER_ROWS * (g + 1) / segs;
+      rc = launch_trace_ladder_pass1(n, n_proofs, d_targets, edr, TL_STRIDE, c->d_trace_tmp, r0, r1, s);
+      if (rc) break;
+      hipStream_t p2 = segs > 1 ? c->side : s;
+      if (segs > 1) {
+        HIPCK(c, hipEventRecord(c->ev_trace[g], s));
+        HIPCK(c, hipStreamWaitEvent(p2, c->ev_trace[g], 0));
+      }
+      rc = launch_trace_ladder_pass2((uint32_t)kind, n, n_proofs, d_targets, edr, TL_STRIDE, c->d_trace_tmp, d_trace_out, r0, r1, p2);
+    }
+    if (!rc && segs > 1) {
+      HIPCK(c, hipEventRecord(c->ev_trace[4], c->side));
+    }
+  }
+  if (!rc && (sections & ~(uint32_t)TMX_TRACE_LADDERS)) rc = launch_trace_rest((uint32_t)kind, n, n_proofs, d_targets, d_trusteds, d_trace_out, sections, s);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_trace launch: ") + hipGetErrorString((hipError_t)rc));
+  if ((sections & TMX_TRACE_LADDERS) && c->ev_trace[4]) {
+    const char* sg = std::getenv("TMX_TRACE_SEGMENTS");
+    if (!(sg && sg[0] == '1')) HIPCK(c, hipStreamWaitEvent(s, c->ev_trace[4], 0));  // the call ends on the caller's stream
+  }
   return TMX_OK;
 }
 

@@ -8,11 +8,15 @@ namespace tmx {
 
 // elements of one proof's trace block (DESIGN.md "Level-2 trace rows")
 uint64_t trace_elems(uint32_t kind, uint32_t n);
-// sections: bit 0 ladders, 1 SHA-512 rounds, 2 leaf SHA-256 rounds, 3 N x N match bits.  d_ed: the Level-1 EdDSA lane records of the
-// SAME batch (h, A, decode flag).  Returns a hipError_t value.
-// d_tmp: trace_tmp_bytes(n, n_proofs) bytes of scratch (the projective points between the two ladder passes), needed with section bit 0
+// Ladder rows [row0, row1) (multiples of eight) of every lane: pass 1 = the double-and-add chain into the scratch buffer d_tmp
+// (trace_tmp_bytes; a segment with row0 > 0 continues from the buffer), pass 2 = affine rows out of it.  d_ed: the Level-1 EdDSA lane
+// records of the SAME batch (h, A, decode flag).  Each returns a hipError_t value.
 size_t trace_tmp_bytes(uint32_t n, uint32_t n_proofs);
-int launch_trace(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_trusted, const void* d_ed, uint32_t ed_stride, void* d_out,
-                 void* d_tmp, uint32_t sections, void* stream);
+int launch_trace_ladder_pass1(uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_ed, uint32_t ed_stride, void* d_tmp, uint32_t row0,
+                              uint32_t row1, void* stream);
+int launch_trace_ladder_pass2(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_ed, uint32_t ed_stride, const void* d_tmp,
+                              void* d_out, uint32_t row0, uint32_t row1, void* stream);
+// sections: bit 1 SHA-512 rounds, 2 leaf SHA-256 rounds, 3 N x N match bits
+int launch_trace_rest(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_trusted, void* d_out, uint32_t sections, void* stream);
 
 }  // namespace tmx

@@ -90,24 +90,29 @@ __device__ __forceinline__ uint32_t scalar_bit(const uint32_t sc[8], int r) {  /
 constexpr uint32_t TR_PT_WORDS = 60;  // per row in the scratch buffer: dbl (X, Y, Z), add (X, Y, Z), ten limbs each
 
 __global__ __launch_bounds__(64) void k_trace_ladder_pass1(uint32_t n_lanes, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
-                                                           uint32_t ed_stride, int32_t* __restrict__ pts) {
+                                                           uint32_t ed_stride, int32_t* __restrict__ pts, uint32_t row0, uint32_t row1) {
   const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t;
   const bool live = id < 2u * n_lanes;
   const LadderIn L = ladder_inputs(live ? id >> 1 : 0u, id & 1u, in_target, ed, ed_stride, true);
   int32_t* o = pts + (size_t)blockIdx.x * TR_LADDER_ROWS * TR_PT_WORDS * 64u + t;
-  ge_ext acc = ge_identity();
+  ge_proj acc = ext_to_proj(ge_identity());
+  if (row0) {  // a later segment of the chain: the accumulator is row0 - 1's nxt, already in the scratch buffer
+    const int32_t* prev = o + (size_t)(row0 - 1) * TR_PT_WORDS * 64u + (size_t)scalar_bit(L.sc, (int)row0 - 1) * 30u * 64u;
+#pragma unroll
+    for (int l = 0; l < 10; l++) { acc.X.v[l] = prev[l * 64]; acc.Y.v[l] = prev[(10 + l) * 64]; acc.Z.v[l] = prev[(20 + l) * 64]; }
+  }
 #pragma unroll 1
-  for (int r = 0; r < (int)TR_LADDER_ROWS; r++) {
+  for (int r = (int)row0; r < (int)row1; r++) {
     const uint32_t bit = scalar_bit(L.sc, r);
-    const ge_ext d = comp_to_ext(ge_double(ext_to_proj(acc)));
-    const ge_ext a = comp_to_ext(ge_add_affc(d, L.P));
+    const ge_ext d = comp_to_ext(ge_double(acc));
+    const ge_proj a = comp_to_proj(ge_add_affc(d, L.P));  // (the sum's T is never needed: the next step doubles from (X : Y : Z))
     int32_t* row = o + (size_t)r * TR_PT_WORDS * 64u;
 #pragma unroll
     for (int l = 0; l < 10; l++) {
       row[(0 + l) * 64] = d.X.v[l]; row[(10 + l) * 64] = d.Y.v[l]; row[(20 + l) * 64] = d.Z.v[l];
       row[(30 + l) * 64] = a.X.v[l]; row[(40 + l) * 64] = a.Y.v[l]; row[(50 + l) * 64] = a.Z.v[l];
     }
-    acc.X = fe_select(d.X, a.X, bit); acc.Y = fe_select(d.Y, a.Y, bit); acc.Z = fe_select(d.Z, a.Z, bit); acc.T = fe_select(d.T, a.T, bit);
+    acc.X = fe_select(d.X, a.X, bit); acc.Y = fe_select(d.Y, a.Y, bit); acc.Z = fe_select(d.Z, a.Z, bit);
   }
 }
 
@@ -118,11 +123,11 @@ __global__ __launch_bounds__(64) void k_trace_ladder_pass1(uint32_t n_lanes, con
 // the three in between are recomputed per group of four from the Z's (re-read from the scratch buffer: coalesced, mostly L2).
 __global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t n_lanes, uint32_t n, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
                                                            uint32_t ed_stride, const int32_t* __restrict__ pts, uint64_t* __restrict__ out,
-                                                           uint64_t proof_stride) {
+                                                           uint64_t proof_stride, uint32_t chunk0) {
   __shared__ uint32_t stage[64][TR_LADDER_ROW + 1];
   __shared__ uint64_t s_base[64];
   __shared__ uint8_t s_live[64];
-  const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t, c = blockIdx.y;  // batch c = rows CH c .. CH c + CH - 1
+  const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t, c = chunk0 + blockIdx.y;  // batch c = rows CH c .. CH c + CH - 1
   const bool live = id < 2u * n_lanes;
   const uint32_t lane = live ? id >> 1 : 0u, k = id & 1u;
   {
@@ -372,21 +377,33 @@ uint64_t trace_elems(uint32_t kind, uint32_t n) {
 
 size_t trace_tmp_bytes(uint32_t n, uint32_t n_proofs) { return (size_t)((2ull * n_proofs * n + 63) / 64) * 64 * TR_LADDER_ROWS * TR_PT_WORDS * 4; }
 
-int launch_trace(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_trusted, const void* d_ed, uint32_t ed_stride, void* d_out,
-                 void* d_tmp, uint32_t sections, void* stream) {
+// rows [row0, row1) of every ladder: the chain (pass 1) and, once it is done, the affine rows (pass 2); row0 / row1 multiples of eight
+int launch_trace_ladder_pass1(uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_ed, uint32_t ed_stride, void* d_tmp, uint32_t row0,
+                              uint32_t row1, void* stream) {
+  if (n_proofs == 0) return 0;
+  const uint32_t lanes = n_proofs * n;
+  hipLaunchKernelGGL(k_trace_ladder_pass1, dim3((2 * lanes + 63) / 64), dim3(64), 0, S_(stream), lanes, reinterpret_cast<const uint8_t*>(d_target),
+                     reinterpret_cast<const uint8_t*>(d_ed), ed_stride, reinterpret_cast<int32_t*>(d_tmp), row0, row1);
+  return (int)hipGetLastError();
+}
+int launch_trace_ladder_pass2(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_ed, uint32_t ed_stride, const void* d_tmp,
+                              void* d_out, uint32_t row0, uint32_t row1, void* stream) {
+  if (n_proofs == 0) return 0;
+  const uint32_t lanes = n_proofs * n;
+  hipLaunchKernelGGL(k_trace_ladder_pass2, dim3((2 * lanes + 63) / 64, (row1 - row0) / CH), dim3(64), 0, S_(stream), lanes, n, reinterpret_cast<const uint8_t*>(d_target),
+                     reinterpret_cast<const uint8_t*>(d_ed), ed_stride, reinterpret_cast<const int32_t*>(d_tmp), reinterpret_cast<uint64_t*>(d_out),
+                     trace_elems(kind, n), row0 / CH);
+  return (int)hipGetLastError();
+}
+
+// the other sections (bits 1, 2, 3 of `sections`)
+int launch_trace_rest(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_trusted, void* d_out, uint32_t sections, void* stream) {
   if (n_proofs == 0) return 0;
   const uint32_t lanes = n_proofs * n;
   const uint64_t stride = trace_elems(kind, n);
   uint64_t* out = reinterpret_cast<uint64_t*>(d_out);
   const uint8_t* tg = reinterpret_cast<const uint8_t*>(d_target);
   const uint8_t* tr = reinterpret_cast<const uint8_t*>(d_trusted);
-  if (sections & 1u) {
-    const uint32_t blocks = (2 * lanes + 63) / 64;
-    hipLaunchKernelGGL(k_trace_ladder_pass1, dim3(blocks), dim3(64), 0, S_(stream), lanes, tg, reinterpret_cast<const uint8_t*>(d_ed), ed_stride,
-                       reinterpret_cast<int32_t*>(d_tmp));
-    hipLaunchKernelGGL(k_trace_ladder_pass2, dim3(blocks, TR_LADDER_ROWS / CH), dim3(64), 0, S_(stream), lanes, n, tg, reinterpret_cast<const uint8_t*>(d_ed),
-                       ed_stride, reinterpret_cast<const int32_t*>(d_tmp), out, stride);
-  }
   if (sections & 2u) hipLaunchKernelGGL(k_trace_sha512, dim3((lanes + 63) / 64), dim3(64), 0, S_(stream), lanes, n, tg, out, stride);
   if (sections & 4u)
     hipLaunchKernelGGL(k_trace_sha256, dim3(((kind == 0 ? 2 : 1) * lanes + 63) / 64), dim3(64), 0, S_(stream), kind, lanes, n, tg, tr, out, stride);
