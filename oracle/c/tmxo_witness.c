@@ -229,17 +229,20 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
   uint64_t scal_t[4], scal_r[4] = {0, 0, 0, 0};
   int gt_t = tmxo_tally(powers, n, nb, signedv, 2, 3, totp, accp, scal_t, &no_overflow), gt_r = 0;
   int all_eddsa = 1, all_sigdata = 1; int32_t first_bad = -1;
+  tmxo_eddsa_trace* trs = (tmxo_eddsa_trace*)malloc(sizeof(tmxo_eddsa_trace) * n);
+  uint8_t* lflags = (uint8_t*)malloc(6 * n);
+  /* D.1a: the byte fields of every target lane (marshalled validator, leaf hash, SHA-512 digest) */
   for (uint32_t i = 0; i < n; i++) {
     const uint8_t* v = trec + (size_t)TMXO_REC_VALIDATOR * i;
     uint8_t m[46], lh[32];
     tmxo_marshal_validator(v, powers[i], m);
     tmxo_leaf_hash(m, v[222] > 46 ? 46 : v[222], lh);    /* validator.rs:209-229: 1 + vlen bytes (vlen <= 46 by type) */
     memcpy(leaves + 32 * i, lh, 32);
-    tmxo_eddsa_trace tr;
+    tmxo_eddsa_trace* tr = &trs[i];
     size_t mlen = (size_t)v[220] | ((size_t)v[221] << 8);
     if (mlen > 124) mlen = 124;                              /* message buffer is 124 bytes (consts.rs:29) */
-    if (signedv[i]) tmxo_eddsa_trace_lane(v, v + 32, v + 96, mlen, &tr);
-    else tmxo_eddsa_trace_lane(dummy_pk, dummy_sig, zero_msg, 32, &tr);   /* conditional substitution (verify.rs:248-259) */
+    if (signedv[i]) tmxo_eddsa_trace_lane(v, v + 32, v + 96, mlen, tr);
+    else tmxo_eddsa_trace_lane(dummy_pk, dummy_sig, zero_msg, 32, tr);   /* conditional substitution (verify.rs:248-259) */
     const uint8_t* msg = v + 96;
     int enabled = i < nb;
     int off = round == 0 ? 16 : 25;
@@ -249,14 +252,22 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
     int round_ok = round == 0 ? 1 : (rd64(msg + 13) == round);              /* validator.rs:125-141 */
     int valid = signedv[i] && enabled && hash_in_msg && is_precommit && height_ok && round_ok;
     int sigdata_ok = (signedv[i] != 0) == valid;                            /* validator.rs:143-152 */
-    e_bytes(&E, m, 46); e_bytes(&E, lh, 32); e_bytes(&E, tr.digest, 64); e_u256le(&E, tr.h);
-    for (int k = 0; k < 10; k++) e_u256le(&E, tr.pt[k]);
-    e_bool(&E, tr.ok); e_bool(&E, enabled); e_bool(&E, hash_in_msg); e_bool(&E, is_precommit); e_bool(&E, height_ok);
-    e_bool(&E, round_ok); e_bool(&E, sigdata_ok);
-    e_u64(&E, totp[i]); e_u64(&E, accp[i]);
-    if (!tr.ok) { all_eddsa = 0; if (first_bad < 0) first_bad = (int32_t)i; }
+    uint8_t* f = lflags + 6 * i;
+    f[0] = (uint8_t)enabled; f[1] = (uint8_t)hash_in_msg; f[2] = (uint8_t)is_precommit; f[3] = (uint8_t)height_ok; f[4] = (uint8_t)round_ok; f[5] = (uint8_t)sigdata_ok;
+    e_bytes(&E, m, 46); e_bytes(&E, lh, 32); e_bytes(&E, tr->digest, 64);
+    if (!tr->ok) { all_eddsa = 0; if (first_bad < 0) first_bad = (int32_t)i; }
     if (!sigdata_ok) all_sigdata = 0;
   }
+  /* D.1b: the word elements of every target lane (h, the ten coordinates, the EdDSA verdict, the six flags, the two prefix sums) */
+  for (uint32_t i = 0; i < n; i++) {
+    const tmxo_eddsa_trace* tr = &trs[i];
+    e_u256le(&E, tr->h);
+    for (int k = 0; k < 10; k++) e_u256le(&E, tr->pt[k]);
+    e_bool(&E, tr->ok);
+    for (int k = 0; k < 6; k++) e_bool(&E, lflags[6 * i + k]);
+    e_u64(&E, totp[i]); e_u64(&E, accp[i]);
+  }
+  free(trs); free(lflags);
   uint8_t root_t[32], root_r[32];
   tmxo_fixed_shape_tree(leaves, n, nb, nodes, root_t);
   size_t tn = tmxo_tree_nodes(n);

@@ -396,13 +396,21 @@ def witness(kind, proof_rec, target_recs, trusted_recs, chain_id, skip_max):
     varint_ok = all(v["power"] < (1 << 63) for v in tgt) and height_a < (1 << 63)
     # verify_non_negative_round (validator.rs:73-78; asserted per lane at :141 on the proof-wide round, signed or not)
     round_nonneg = (round_ >> 63) == 0
-    for i, v in enumerate(tgt):
+    lane_vals = []
+    for i, v in enumerate(tgt):      # D.1a: the byte fields of every target lane
         tr = eddsa_lane(v)
         enabled = i < nb
         chk = sigdata_checks(v["msg"], header, expected_height, round_, enabled, signed[i])
         E.bytes(tder[i][0])
         E.bytes(tder[i][1])
         E.bytes(tr["digest"])
+        lane_vals.append((tr, enabled, chk))
+        if not tr["ok"]:
+            all_eddsa = False
+            if first_bad_sig < 0:
+                first_bad_sig = i
+        all_sigdata = all_sigdata and chk[4]
+    for i, (tr, enabled, chk) in enumerate(lane_vals):      # D.1b: the word elements of every target lane
         E.u256(tr["h"])
         for name in ("A", "R", "sB", "hA", "sum"):
             pt = tr[name] if tr[name] is not None else (0, 0)
@@ -414,11 +422,6 @@ def witness(kind, proof_rec, target_recs, trusted_recs, chain_id, skip_max):
             E.bool(c)
         E.u64(tal_t["tot_prefix"][i])
         E.u64(tal_t["acc_prefix"][i])
-        if not tr["ok"]:
-            all_eddsa = False
-            if first_bad_sig < 0:
-                first_bad_sig = i
-        all_sigdata = all_sigdata and chk[4]
     layers_t, root_t = tm.fixed_shape_layers([d[1] for d in tder], nb)
 
     if kind == KIND_SKIP:

@@ -69,7 +69,7 @@ void emit_proof_d(LutBuilder& L, int q) { L.bytes(PF_OFF_PROOFD + 160 * q, 160);
 struct Program {
   SerializeProgram sp;
   std::vector<uint32_t> lut;
-  uint32_t mask_inputs = 0, mask_proof = 0, mask_final = 0, mask_tail = 0;  // sections by readiness: inputs only / after k_proof / after EdDSA / after k_verdict
+  uint32_t mask_inputs = 0, mask_proof = 0, mask_final = 0, mask_tail = 0, mask_p1 = 0;  // sections by readiness: inputs only / after k_proof / after EdDSA / after k_verdict
   std::vector<uint32_t> seam_waves;  // indices of the spans that straddle a boundary (0xff entries of wave_sec)
   std::vector<uint8_t> wave_sec;  // per sp.span-element span of a row: its section, or 0xff if it straddles a boundary / the row end
   uint32_t hint_elems;
@@ -83,9 +83,10 @@ Program build_program(int kind, uint32_t n) {
   const bool skip = kind == TMX_KIND_SKIP;
   const uint32_t tn = tree_nodes(n);
   uint32_t elem = 0;
-  // ready: 0 = needs only the input records, 1 = needs k_proof, 2 = needs the EdDSA kernels (and k_proof), 3 = needs k_verdict
+  // ready: 0 = needs only the input records, 1 = needs k_proof, 2 = needs the EdDSA kernels (and k_proof), 3 = needs k_verdict,
+  // 4 = needs k_proof and the hash role of phase 1 (not k_ed_fin)
   auto add_section = [&](uint32_t lane_elems, uint32_t n_lanes, uint32_t lut_off, uint32_t kind_, uint32_t src, int ready) {
-    (ready == 0 ? P.mask_inputs : ready == 1 ? P.mask_proof : ready == 2 ? P.mask_final : P.mask_tail) |= 1u << P.sp.n_sections;
+    (ready == 0 ? P.mask_inputs : ready == 1 ? P.mask_proof : ready == 2 ? P.mask_final : ready == 4 ? P.mask_p1 : P.mask_tail) |= 1u << P.sp.n_sections;
     Section& s = P.sp.sec[P.sp.n_sections++];
     s.elem_start = elem; s.lane_elems = lane_elems; s.n_lanes = n_lanes; s.lut_off = lut_off; s.kind = kind_; s.src = src;
     s.magic = (uint32_t)((0x100000000ull + lane_elems - 1) / lane_elems);  // lane = mulhi(rel, magic); rel * lane_elems < 2^32 here
@@ -143,11 +144,15 @@ Program build_program(int kind, uint32_t n) {
   }
   P.hint_elems = elem;
 
-  // D.1 per target lane
+  // D.1a per target lane: the byte fields (marshalled validator, leaf hash: k_proof; SHA-512 digest: phase 1).  Their own section so that
+  // they are written while the table walk runs; only D.1b waits for k_ed_fin.
   mark = (uint32_t)L.v.size();
   L.bytes(TL_OFF_LT + LN_OFF_MARSHAL, 46);
   L.bytes(TL_OFF_LT + LN_OFF_LEAF, 32);
   L.bytes(TL_OFF_ED + ED_OFF_DIGEST, 64);
+  add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_TL, 4);
+  // D.1b per target lane: h, the ten coordinates, the EdDSA verdict, the six flags, the two prefix sums
+  mark = (uint32_t)L.v.size();
   L.u256(TL_OFF_ED + ED_OFF_H);
   for (int p = 0; p < 10; p++) L.u256(TL_OFF_ED + ED_OFF_PTS + 32 * p);
   L.u32(TL_OFF_ED + ED_OFF_OK);
@@ -228,6 +233,9 @@ struct tmx_ctx {
   hipStream_t side = nullptr;  // k_proof runs here, concurrently with the EdDSA kernels of the caller's stream
   hipEvent_t ev_join = nullptr;
   hipEvent_t ev_side[EV_RING_DECL][4] = {};
+  hipEvent_t ev_hash = nullptr;  // phase 1 is done: the SHA-512 digest and h of every lane are in the lane records
+  bool ev_hash_recorded = false;
+  int k_p1_early = -1;  // TMX_P1_EARLY: 1 / 0, default by batch size
   hipEvent_t ev_p1 = nullptr, ev_tail = nullptr, ev_fork2 = nullptr, ev_hash_clean = nullptr, ev_keys = nullptr, ev_mul = nullptr;
   bool ev_mul_recorded = false, want_ev_mul = false, fin_done_attached = false, ext_events = true;
   void* fin_done = nullptr;  // set by run_batch around the EdDSA producer: the event k_ed_fin signals
@@ -374,6 +382,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     c->fin_done = c->ext_events ? ev[1] : nullptr;
     c->fin_done_attached = false;
   }
+  c->ev_hash_recorded = false;
   int32_t st = ed_producer(s);
   c->fin_done = nullptr;
   if (st) return st;
@@ -383,6 +392,15 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   if (c->ev_mul_recorded) HIPCK(c, hipStreamWaitEvent(c->side, c->ev_mul, 0));
   st0 = c->ser_split ? serialize(prog.mask_proof, c->side) : TMX_OK;
   if (st0) return st0;
+  // D.1a (the byte fields of the per-target-lane derived values: a quarter of the row) needs k_proof and phase 1, not k_ed_fin: behind
+  // k_proof's sections on the side stream, i.e. while the table walk and the finish run.  Measured (TMX_P1_EARLY=1|0): -6.3 % step at 1024
+  // proofs x 128; +-0.5 % at 256 and 64, +4 % on the one-validator-set batch at 256 (the side stream, not k_ed_fin, ends the step there) ->
+  // (and +1 ... +2 % at 512 proofs): on from 131072 lanes
+  const bool p1_early = c->ser_split && c->ev_hash_recorded && (c->k_p1_early >= 0 ? c->k_p1_early != 0 : (uint64_t)n_proofs * n >= 131072);
+  if (p1_early) {
+    HIPCK(c, hipStreamWaitEvent(c->side, c->ev_hash, 0));
+    if ((st0 = serialize(prog.mask_p1, c->side))) return st0;
+  }
   HIPCK(c, hipStreamWaitEvent(c->side, c->ev_join3, 0));  // ev_join = both low-priority streams done
   HIPCK(c, hipEventRecord(c->ev_join, c->side));
   if (!c->fin_done_attached) HIPCK(c, hipEventRecord(ev[1], s));
@@ -395,7 +413,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, s, xv ? evs[2] : nullptr, xv ? evs[3] : nullptr);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
     if (!xv) HIPCK(c, hipEventRecord(evs[3], s));
-    if ((st0 = serialize(prog.mask_final | prog.mask_tail, s))) return st0;
+    if ((st0 = serialize(prog.mask_final | prog.mask_p1 | prog.mask_tail, s))) return st0;
     HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
   } else if (c->ser_split) {
     // tail: the per-lane derived section (a quarter of the row) only needs k_ed_fin + k_proof, so it is written on s while the
@@ -411,7 +429,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     HIPCK(c, hipStreamWaitEvent(c->side2, c->ev_join, 0));  // ev_tail = every side stream done
     HIPCK(c, hipEventRecord(c->ev_tail, c->side2));
     HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
-    if ((st0 = serialize(prog.mask_final, s))) return st0;
+    if ((st0 = serialize(prog.mask_final | (p1_early ? 0u : prog.mask_p1), s))) return st0;
     HIPCK(c, hipStreamWaitEvent(s, c->ev_tail, 0));
   } else {
     HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
@@ -420,7 +438,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
     HIPCK(c, hipEventRecord(evs[3], s));
     HIPCK(c, hipEventRecord(ev[2], s));
-    if ((st0 = serialize(prog.mask_inputs | prog.mask_proof | prog.mask_final | prog.mask_tail, s))) return st0;
+    if ((st0 = serialize(prog.mask_inputs | prog.mask_proof | prog.mask_final | prog.mask_p1 | prog.mask_tail, s))) return st0;
   }
   HIPCK(c, hipEventRecord(ev[3], s));
   c->last_stream = s; c->last_stream_valid = true;
@@ -530,8 +548,10 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     if (!x && (e = hipEventRecord(c->ev_p1, c->side3)) != hipSuccess) return (int)e;
     wait_p1_late = true;
   } else {
-    rc = launch_ed_phase1(Q, s);
+    rc = launch_ed_phase1(Q, s, x ? c->ev_hash : nullptr);
     if (rc) return rc;
+    if (!x && (e = hipEventRecord(c->ev_hash, s)) != hipSuccess) return (int)e;
+    c->ev_hash_recorded = true;
   }
   if ((e = hipStreamWaitEvent(s, c->ev_keys, 0)) != hipSuccess) return (int)e;
   rc = launch_ed_mul_direct(Q, s);  // empty when the tables are used: enqueued before the wait for them
@@ -686,6 +706,7 @@ void tmx_ctx_destroy(tmx_ctx* c) {
     if (ev) (void)hipEventDestroy(ev);
   if (c->ev_keys) (void)hipEventDestroy(c->ev_keys);
   if (c->ev_p1) (void)hipEventDestroy(c->ev_p1);
+  if (c->ev_hash) (void)hipEventDestroy(c->ev_hash);
   if (c->ev_hash_clean) (void)hipEventDestroy(c->ev_hash_clean);
   if (c->ev_mul) (void)hipEventDestroy(c->ev_mul);
   if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
@@ -724,6 +745,7 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   }
   HIPCK(c, hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_p1, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_hash, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_hash_clean, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_mul, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -761,6 +783,7 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     c->k_walk_parts = (v = std::getenv("TMX_WALK_PARTS")) ? (v[0] == '1' ? 1 : 0) : -1;
     c->k_mul_split = (v = std::getenv("TMX_MUL_SPLIT")) ? (v[0] == '1' ? 1u : (v[0] == '4' ? 4u : 2u)) : 0u;
     c->k_no_wide = (v = std::getenv("TMX_PROOF_WIDE")) && v[0] == '0';
+    c->k_p1_early = (v = std::getenv("TMX_P1_EARLY")) ? (v[0] != '0' ? 1 : 0) : -1;
   }
   const char* ss = std::getenv("TMX_SER_SPLIT");
   c->ser_split = !(ss && ss[0] == '0');
