@@ -286,10 +286,8 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
       tmxo_leaf_hash(rm + 46 * j, t[40] > 46 ? 46 : t[40], rleaves + 32 * j);
     }
     gt_r = tmxo_tally(rp, n, nbt, matched, 1, 3, totp, accp, scal_r, &no_overflow);
-    for (uint32_t j = 0; j < n; j++) {
-      e_bytes(&E, rm + 46 * j, 46); e_bytes(&E, rleaves + 32 * j, 32); e_bool(&E, j < nbt); e_bool(&E, matched[j]);
-      e_u64(&E, totp[j]); e_u64(&E, accp[j]);
-    }
+    for (uint32_t j = 0; j < n; j++) { e_bytes(&E, rm + 46 * j, 46); e_bytes(&E, rleaves + 32 * j, 32); }                    /* D.2a: byte fields */
+    for (uint32_t j = 0; j < n; j++) { e_bool(&E, j < nbt); e_bool(&E, matched[j]); e_u64(&E, totp[j]); e_u64(&E, accp[j]); }  /* D.2b: word fields */
     tmxo_fixed_shape_tree(rleaves, n, nbt, nodes_r, root_r);
     free(matched); free(rp); free(rleaves); free(rm);
   }

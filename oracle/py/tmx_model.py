@@ -431,9 +431,10 @@ def witness(kind, proof_rec, target_recs, trusted_recs, chain_id, skip_max):
         # N x N match (verify.rs:398-418)
         matched = [any(signed[i] and tgt[i]["pubkey"] == trs[j]["pubkey"] for i in range(n)) for j in range(n)]
         tal_r = tally([t["power"] for t in trs], nbt, matched, 1, 3)
-        for j, t in enumerate(trs):
+        for j, t in enumerate(trs):      # D.2a: byte fields
             E.bytes(rder[j][0])
             E.bytes(rder[j][1])
+        for j, t in enumerate(trs):      # D.2b: word fields
             E.bool(j < nbt)
             E.bool(matched[j])
             E.u64(tal_r["tot_prefix"][j])

@@ -69,7 +69,7 @@ void emit_proof_d(LutBuilder& L, int q) { L.bytes(PF_OFF_PROOFD + 160 * q, 160);
 struct Program {
   SerializeProgram sp;
   std::vector<uint32_t> lut;
-  uint32_t mask_inputs = 0, mask_proof = 0, mask_final = 0, mask_tail = 0, mask_p1 = 0;  // sections by readiness: inputs only / after k_proof / after EdDSA / after k_verdict
+  uint32_t mask_inputs = 0, mask_proof = 0, mask_final = 0, mask_tail = 0, mask_p1 = 0, mask_leaves = 0;  // sections by readiness: inputs only / after k_proof / after EdDSA / after k_verdict
   std::vector<uint32_t> seam_waves;  // indices of the spans that straddle a boundary (0xff entries of wave_sec)
   std::vector<uint8_t> wave_sec;  // per sp.span-element span of a row: its section, or 0xff if it straddles a boundary / the row end
   uint32_t hint_elems;
@@ -84,9 +84,10 @@ Program build_program(int kind, uint32_t n) {
   const uint32_t tn = tree_nodes(n);
   uint32_t elem = 0;
   // ready: 0 = needs only the input records, 1 = needs k_proof, 2 = needs the EdDSA kernels (and k_proof), 3 = needs k_verdict,
-  // 4 = needs k_proof and the hash role of phase 1 (not k_ed_fin)
+  // 4 = needs the leaves (k_leaves, or k_proof) and phase 1 (not k_ed_fin), 5 = needs only the leaves
   auto add_section = [&](uint32_t lane_elems, uint32_t n_lanes, uint32_t lut_off, uint32_t kind_, uint32_t src, int ready) {
-    (ready == 0 ? P.mask_inputs : ready == 1 ? P.mask_proof : ready == 2 ? P.mask_final : ready == 4 ? P.mask_p1 : P.mask_tail) |= 1u << P.sp.n_sections;
+    (ready == 0 ? P.mask_inputs : ready == 1 ? P.mask_proof : ready == 2 ? P.mask_final : ready == 4 ? P.mask_p1 : ready == 5 ? P.mask_leaves : P.mask_tail) |=
+        1u << P.sp.n_sections;
     Section& s = P.sp.sec[P.sp.n_sections++];
     s.elem_start = elem; s.lane_elems = lane_elems; s.n_lanes = n_lanes; s.lut_off = lut_off; s.kind = kind_; s.src = src;
     s.magic = (uint32_t)((0x100000000ull + lane_elems - 1) / lane_elems);  // lane = mulhi(rel, magic); rel * lane_elems < 2^32 here
@@ -161,11 +162,13 @@ Program build_program(int kind, uint32_t n) {
   L.u64(TL_OFF_LT + LN_OFF_ACC);
   add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_TL, 2);
 
-  // D.2 per trusted lane
+  // D.2a / D.2b per trusted lane: byte fields (marshalled validator, leaf hash: ready with the leaves), word fields (flags, prefix sums: k_proof)
   if (skip) {
     mark = (uint32_t)L.v.size();
     L.bytes(LN_OFF_MARSHAL, 46);
     L.bytes(LN_OFF_LEAF, 32);
+    add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_LR, 5);
+    mark = (uint32_t)L.v.size();
     L.u8(LN_OFF_FLAGS);
     L.u8(LN_OFF_FLAGS + 1);
     L.u64(LN_OFF_TOT);
@@ -236,6 +239,8 @@ struct tmx_ctx {
   hipEvent_t ev_hash = nullptr;  // phase 1 is done: the SHA-512 digest and h of every lane are in the lane records
   bool ev_hash_recorded = false;
   int k_p1_early = -1;  // TMX_P1_EARLY: 1 / 0, default by batch size
+  int k_leaves = -1;    // TMX_LEAVES: 1 / 0, default by batch size
+  hipEvent_t ev_leaves = nullptr;
   hipEvent_t ev_p1 = nullptr, ev_tail = nullptr, ev_fork2 = nullptr, ev_hash_clean = nullptr, ev_keys = nullptr, ev_mul = nullptr;
   bool ev_mul_recorded = false, want_ev_mul = false, fin_done_attached = false, ext_events = true;
   void* fin_done = nullptr;  // set by run_batch around the EdDSA producer: the event k_ed_fin signals
@@ -305,9 +310,10 @@ static int32_t fail(tmx_ctx* c, int32_t st, const std::string& msg) {
     if (e_ != hipSuccess) return fail(c, TMX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-static ProofParams proof_params(const tmx_ctx* c, int32_t kind) {
+static ProofParams proof_params(const tmx_ctx* c, int32_t kind, bool leaves_done) {
   ProofParams P;
   std::memset(&P, 0, sizeof P);
+  P.leaves_done = leaves_done ? 1u : 0u;
   P.kind = (uint32_t)kind; P.n = c->cfg.n_max; P.tree_nodes = tree_nodes(c->cfg.n_max); P.chain_id_len = c->cfg.chain_id_len;
   P.skip_max = c->cfg.skip_max;
   P.no_wide = c->k_no_wide ? 1u : 0u;
@@ -368,9 +374,25 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   };
   const bool inputs_late = (c->p1_side == 1 || inputs_hi) && c->quad;
   if (!inputs_late && (st0 = inputs_on_side3())) return st0;
+  // Leaves first (TMX_LEAVES=1|0, default by size): marshalled validators + leaf hashes as a 10-us launch of their own in front of k_proof,
+  // so that the byte fields of the two per-lane derived sections (D.2a: the leaves; D.1a: the leaves + phase 1 -- 42 % of a skip row) are
+  // written by the low-priority stream behind the input sections instead of behind k_proof (which ends at ~300 us inside a step) / k_ed_fin.
+  // Measured (TMX_LEAVES=1|0, N = 128): -5 % step at 1024 proofs (on top of the -6 % of D.1a behind k_proof's sections), but +1.5 % at 256,
+  // +4.5 % at 512, +8 % at 64, +6.5 % on the one-set batch at 256: below ~1000 proofs every extra concurrent launch stretches the EdDSA
+  // chain by more than the tail it removes.  On from 131072 lanes.
+  const bool leaves_first = c->ser_split && d_out_elems && c->quad && !inputs_late &&
+                            (c->k_leaves >= 0 ? c->k_leaves != 0 : (uint64_t)n_proofs * n >= 131072);
   // side: k_proof, then the sections that only need its results
   HIPCK(c, hipEventRecord(evs[0], c->side));
-  int rc = launch_proof(proof_params(c, kind), n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf, c->d_nodes_t,
+  int rc = 0;
+  if (leaves_first) {
+    rc = launch_leaves((uint32_t)kind, n, n_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->side, c->k_ext_events ? c->ev_leaves : nullptr);
+    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_leaves launch: ") + hipGetErrorString((hipError_t)rc));
+    if (!c->k_ext_events) HIPCK(c, hipEventRecord(c->ev_leaves, c->side));
+    HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_leaves, 0));
+    if ((st0 = serialize(prog.mask_leaves, c->side3))) return st0;
+  }
+  rc = launch_proof(proof_params(c, kind, leaves_first), n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf, c->d_nodes_t,
                         c->d_nodes_r, reports, c->side);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_proof launch: ") + hipGetErrorString((hipError_t)rc));
   HIPCK(c, hipEventRecord(evs[1], c->side));
@@ -390,14 +412,20 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // TMX_PROOFSER_HOLD=1 keeps these launches back until the table walk is done (with the 80 KB 4-bit key tables they doubled its run
   // time; with the 6-bit tables and the short finish they are better off right behind k_proof: -2 % step at 256 proofs)
   if (c->ev_mul_recorded) HIPCK(c, hipStreamWaitEvent(c->side, c->ev_mul, 0));
-  st0 = c->ser_split ? serialize(prog.mask_proof, c->side) : TMX_OK;
+  if (leaves_first) {  // side3, behind the input sections and D.2a: D.1a as soon as phase 1 is done; ev_join3 moves behind it
+    if (!c->ev_hash_recorded) HIPCK(c, hipEventRecord(c->ev_hash, s));  // (a producer without a phase-1 event: everything it enqueued)
+    HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_hash, 0));
+    if ((st0 = serialize(prog.mask_p1, c->side3))) return st0;
+    HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
+  }
+  st0 = c->ser_split ? serialize(prog.mask_proof | (leaves_first ? 0u : prog.mask_leaves), c->side) : TMX_OK;
   if (st0) return st0;
   // D.1a (the byte fields of the per-target-lane derived values: a quarter of the row) needs k_proof and phase 1, not k_ed_fin: behind
   // k_proof's sections on the side stream, i.e. while the table walk and the finish run.  Measured (TMX_P1_EARLY=1|0): -6.3 % step at 1024
   // proofs x 128; +-0.5 % at 256 and 64, +4 % on the one-validator-set batch at 256 (the side stream, not k_ed_fin, ends the step there) ->
   // (and +1 ... +2 % at 512 proofs): on from 131072 lanes
-  const bool p1_early = c->ser_split && c->ev_hash_recorded && (c->k_p1_early >= 0 ? c->k_p1_early != 0 : (uint64_t)n_proofs * n >= 131072);
-  if (p1_early) {
+  const bool p1_early = leaves_first || (c->ser_split && c->ev_hash_recorded && (c->k_p1_early >= 0 ? c->k_p1_early != 0 : (uint64_t)n_proofs * n >= 131072));
+  if (p1_early && !leaves_first) {
     HIPCK(c, hipStreamWaitEvent(c->side, c->ev_hash, 0));
     if ((st0 = serialize(prog.mask_p1, c->side))) return st0;
   }
@@ -438,7 +466,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
     HIPCK(c, hipEventRecord(evs[3], s));
     HIPCK(c, hipEventRecord(ev[2], s));
-    if ((st0 = serialize(prog.mask_inputs | prog.mask_proof | prog.mask_final | prog.mask_p1 | prog.mask_tail, s))) return st0;
+    if ((st0 = serialize(prog.mask_inputs | prog.mask_proof | prog.mask_leaves | prog.mask_final | prog.mask_p1 | prog.mask_tail, s))) return st0;
   }
   HIPCK(c, hipEventRecord(ev[3], s));
   c->last_stream = s; c->last_stream_valid = true;
@@ -707,6 +735,7 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   if (c->ev_keys) (void)hipEventDestroy(c->ev_keys);
   if (c->ev_p1) (void)hipEventDestroy(c->ev_p1);
   if (c->ev_hash) (void)hipEventDestroy(c->ev_hash);
+  if (c->ev_leaves) (void)hipEventDestroy(c->ev_leaves);
   if (c->ev_hash_clean) (void)hipEventDestroy(c->ev_hash_clean);
   if (c->ev_mul) (void)hipEventDestroy(c->ev_mul);
   if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
@@ -746,6 +775,7 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   HIPCK(c, hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_p1, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_hash, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_leaves, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_hash_clean, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_mul, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -784,6 +814,7 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     c->k_mul_split = (v = std::getenv("TMX_MUL_SPLIT")) ? (v[0] == '1' ? 1u : (v[0] == '4' ? 4u : 2u)) : 0u;
     c->k_no_wide = (v = std::getenv("TMX_PROOF_WIDE")) && v[0] == '0';
     c->k_p1_early = (v = std::getenv("TMX_P1_EARLY")) ? (v[0] != '0' ? 1 : 0) : -1;
+    c->k_leaves = (v = std::getenv("TMX_LEAVES")) ? (v[0] != '0' ? 1 : 0) : -1;
   }
   const char* ss = std::getenv("TMX_SER_SPLIT");
   c->ser_split = !(ss && ss[0] == '0');

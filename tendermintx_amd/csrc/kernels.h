@@ -57,6 +57,9 @@ int launch_ed_mul_tab(const EdQuad& Q, uint32_t part, uint32_t parts, void* stre
 int launch_ed_fin(const EdQuad& Q, void* stream);
 int launch_proof(const ProofParams& P, uint32_t n_proofs, const void* d_proofs, const void* d_target, const void* d_trusted, void* d_lt,
                  uint32_t lt_stride, void* d_lr, void* d_pf, void* d_nodes_t, void* d_nodes_r, void* d_reports, void* stream);
+// marshalled validators + leaf hashes of both sets as a launch of its own; k_proof then reads them (ProofParams::leaves_done)
+int launch_leaves(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_trusted, void* d_lt, uint32_t lt_stride, void* d_lr,
+                  void* stream, void* done = nullptr);
 int launch_valid_skip(uint32_t n_cand, uint32_t n_max, const void* d_start, uint32_t n_start, const void* d_targets, const void* d_nt, const void* d_sigs,
                       const void* d_ns, void* d_valid, void* d_shared, void* d_total, void* stream);
 int launch_verdict(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_ed, uint32_t ed_stride, void* d_pf, void* d_reports, void* stream,
