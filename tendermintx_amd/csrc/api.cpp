@@ -291,6 +291,7 @@ struct tmx_ctx {
   int k_fuse_fin = -1, k_walk_parts = -1;
   uint32_t k_mul_split = 0;
   bool k_no_wide = false;
+  uint32_t k_proof_threads = 0;
   // Goldilocks NTT: twiddle tables per transform size (built on first use), scratch for the four-step split / LDE
   void* d_ntt_w[TMX_NTT_MAX_LOG + 1] = {};
   void* d_ntt_tmp = nullptr;
@@ -317,6 +318,7 @@ static ProofParams proof_params(const tmx_ctx* c, int32_t kind, bool leaves_done
   P.kind = (uint32_t)kind; P.n = c->cfg.n_max; P.tree_nodes = tree_nodes(c->cfg.n_max); P.chain_id_len = c->cfg.chain_id_len;
   P.skip_max = c->cfg.skip_max;
   P.no_wide = c->k_no_wide ? 1u : 0u;
+  P.threads = c->k_proof_threads;
   std::memcpy(P.chain_id, c->cfg.chain_id, sizeof P.chain_id);
   return P;
 }
@@ -813,6 +815,7 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     c->k_walk_parts = (v = std::getenv("TMX_WALK_PARTS")) ? (v[0] == '1' ? 1 : 0) : -1;
     c->k_mul_split = (v = std::getenv("TMX_MUL_SPLIT")) ? (v[0] == '1' ? 1u : (v[0] == '4' ? 4u : 2u)) : 0u;
     c->k_no_wide = (v = std::getenv("TMX_PROOF_WIDE")) && v[0] == '0';
+    c->k_proof_threads = (v = std::getenv("TMX_PROOF_THREADS")) && (std::atoi(v) == 64 || std::atoi(v) == 128 || std::atoi(v) == 256) ? (uint32_t)std::atoi(v) : 0u;
     c->k_p1_early = (v = std::getenv("TMX_P1_EARLY")) ? (v[0] != '0' ? 1 : 0) : -1;
     c->k_leaves = (v = std::getenv("TMX_LEAVES")) ? (v[0] != '0' ? 1 : 0) : -1;
   }
