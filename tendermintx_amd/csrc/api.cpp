@@ -1232,6 +1232,15 @@ static int32_t ntt_run(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const void* 
   NttPass P;
   std::memset(&P, 0, sizeof P);
   P.log_n = log_n; P.inverse = inverse ? 1 : 0;
+  {  // omega_16 of the domain (its inverse for an inverse transform) is an odd power k of 2^12: the kernel loads in the order kinv i
+    const uint64_t w16 = gl_pow_host(c->ntt_root, (1ull << 28) * (inverse ? 15u : 1u));
+    uint32_t k = 0;
+    for (uint32_t t = 1; t < 16; t += 2)
+      if (gl_pow_host(1ull << 12, t) == w16) k = t;
+    if (!k) return fail(c, TMX_ERR_BAD_ARG, "omega_16 of the NTT domain is not a power of 2^12");
+    for (uint32_t t = 1; t < 16; t += 2)
+      if (((t * k) & 15u) == 1u) P.kinv = t;
+  }
   int rc;
   if (log_n <= 11) {  // one pass: whole columns in LDS, T columns per tile
     P.log_l = log_n; P.log_t = 12 - log_n;
@@ -1248,13 +1257,18 @@ static int32_t ntt_run(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const void* 
   }
   const uint32_t a = (log_n + 1) / 2, b = log_n - a;  // N = N1 N2, N1 = 2^a (pass A, strided), N2 = 2^b (pass B, contiguous)
   const uint64_t N = (uint64_t)1 << log_n, N1 = (uint64_t)1 << a, N2 = (uint64_t)1 << b;
-  P.log_l = a; P.log_t = 12 - a; P.n_sub = N2; P.tiles_per_col = (uint32_t)(N2 >> P.log_t);
+  // tiles of the two strided passes: T >= 8 sub-transforms side by side (runs of >= 64 B along the unit-stride dimension; with T = 4 at
+  // N1 = 2^10, FETCH_SIZE was 4x the data), in the smallest tile that allows it (2^12 .. 2^14 elements: three, two or one workgroup per
+  // CU's LDS).  Measured at 2^16 / 2^20 / 2^22: tiles of 2^12 / 2^13 / 2^14 elements are each the fastest there.
+  const char* tl_env = std::getenv("TMX_NTT_TILE_LOG");
+  auto tile_log_of = [&](uint32_t log_l) { return tl_env ? (uint32_t)std::atoi(tl_env) : std::min(14u, std::max(12u, log_l + 3u)); };
+  P.log_l = a; P.log_t = std::min(tile_log_of(a) - a, b); P.n_sub = N2; P.tiles_per_col = (uint32_t)(N2 >> P.log_t);
   P.col_stride_in = in_stride; P.t_stride_in = 1; P.j_stride_in = N2;
   P.col_stride_out = N; P.t_stride_out = 1; P.j_stride_out = N2;
   P.post_twiddle = 1; P.scale = 1;
   rc = launch_ntt_pass(P, n_cols, d_in, tmp, w, s);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_ntt_tile launch: ") + hipGetErrorString((hipError_t)rc));
-  P.log_l = b; P.log_t = 12 - b; P.n_sub = N1; P.tiles_per_col = (uint32_t)(N1 >> P.log_t);
+  P.log_l = b; P.log_t = std::min(tile_log_of(b) - b, a); P.n_sub = N1; P.tiles_per_col = (uint32_t)(N1 >> P.log_t);
   P.col_stride_in = N; P.t_stride_in = N2; P.j_stride_in = 1;
   P.col_stride_out = out_stride; P.t_stride_out = 1; P.j_stride_out = N1;
   P.post_twiddle = 0; P.scale = n_inv;

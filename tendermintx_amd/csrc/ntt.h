@@ -15,6 +15,8 @@ struct NttPass {
   uint32_t inverse;
   uint32_t post_twiddle;  // multiply output k of sub-transform t by omega_N^(t k) (four-step pass A)
   uint64_t scale;         // multiply every output by this (N^-1 on the last pass of an inverse transform), 1 = none
+  uint32_t kinv;          // omega_16 of this pass's direction = (2^12)^k; kinv k = 1 (mod 16): load order of the radix-16 groups
+  uint32_t pad_;
 };
 
 int launch_ntt_table(void* d_w, uint32_t log_n, uint64_t root_2_32, void* stream);

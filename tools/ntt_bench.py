@@ -20,7 +20,10 @@ ctx = tmx.Context(4, b"celestia", max_batch=1)
 s = torch.cuda.current_stream().cuda_stream
 rng = np.random.default_rng(1)
 rows = []
-for log_n, cols in ((10, 4096), (11, 2048), (16, 256), (20, 64), (20, 256), (22, 16)):
+CASES = ((10, 4096), (11, 2048), (16, 256), (20, 64), (20, 256), (22, 16))
+if os.environ.get("NTT_ONLY"):  # e.g. NTT_ONLY=20x256 (profiling runs)
+    CASES = tuple(tuple(int(v) for v in c.split("x")) for c in os.environ["NTT_ONLY"].split(","))
+for log_n, cols in CASES:
     n = 1 << log_n
     x = rng.integers(0, P, size=(cols, n), dtype=np.uint64)
     d = torch.from_numpy(x.view(np.int64)).to("cuda:0")
@@ -46,6 +49,9 @@ for log_n, cols in ((10, 4096), (11, 2048), (16, 256), (20, 64), (20, 256), (22,
                  "butterfly_mul_per_s": round(n * cols * log_n / 2 / (ms * 1e-3), 0),
                  "cpu_oracle_ms_one_column": round(cpu_ms, 2), "speedup_vs_one_core": round(cpu_ms * cols / ms, 0), "bit_exact_col0": ok})
     print(json.dumps(rows[-1]), flush=True)
+if os.environ.get("NTT_ONLY"):
+    ctx.close()
+    sys.exit(0)
 log_n, lb, cols = 18, 3, 32
 x = rng.integers(0, P, size=(cols, 1 << log_n), dtype=np.uint64)
 d = torch.from_numpy(x.view(np.int64)).to("cuda:0")
