@@ -294,6 +294,7 @@ struct tmx_ctx {
   uint32_t k_proof_threads = 0;
   // Goldilocks NTT: twiddle tables per transform size (built on first use), scratch for the four-step split / LDE
   void* d_ntt_w[TMX_NTT_MAX_LOG + 1] = {};
+  void* d_ntt_m[2][TMX_NTT_MAX_LOG + 1] = {};  // four-step twiddle matrices omega_N^(+- n2 k1) (forward, inverse), built on first use
   void* d_ntt_tmp = nullptr;
   size_t ntt_tmp_bytes = 0;
   // NTT domain: primitive 2^32-th root of unity and coset shift.  Default: the constants recalled from plonky2's GoldilocksField
@@ -723,6 +724,9 @@ void tmx_ctx_destroy(tmx_ctx* c) {
     if (b) (void)hipFree(b);
   for (void* w : c->d_ntt_w)
     if (w) (void)hipFree(w);
+  for (auto& dir : c->d_ntt_m)
+    for (void* m : dir)
+      if (m) (void)hipFree(m);
   if (c->d_ntt_tmp) (void)hipFree(c->d_ntt_tmp);
   for (auto& set : c->ev)
     for (auto& e : set)
@@ -1200,6 +1204,20 @@ static int32_t ntt_table(tmx_ctx* c, uint32_t log_n, hipStream_t s, void** w) {
   *w = c->d_ntt_w[log_n];
   return TMX_OK;
 }
+// the twiddles between the two passes of a four-step transform (log_n > 11), as a matrix in the layout pass A writes: N x 8 bytes per
+// size and direction, built once (the passes then read them with the coalescing of their own stores instead of gathering 8-byte words)
+static int32_t ntt_matrix(tmx_ctx* c, uint32_t log_n, uint32_t log_n2, bool inverse, const void* w, hipStream_t s, void** m) {
+  void*& slot = c->d_ntt_m[inverse ? 1 : 0][log_n];
+  if (!slot) {
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipMalloc(&slot, (size_t)8 << log_n));
+    int rc = launch_ntt_matrix(slot, w, log_n, log_n2, inverse, s);
+    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_ntt_matrix launch: ") + hipGetErrorString((hipError_t)rc));
+    HIPCK(c, hipStreamSynchronize(s));
+  }
+  *m = slot;
+  return TMX_OK;
+}
 static int32_t ntt_scratch(tmx_ctx* c, size_t bytes, hipStream_t s) {
   if (c->ntt_tmp_bytes >= bytes) return TMX_OK;
   HIPCK(c, hipSetDevice(c->cfg.device));
@@ -1251,7 +1269,7 @@ static int32_t ntt_run(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const void* 
     P.col_stride_in = 0; P.t_stride_in = in_stride; P.j_stride_in = 1;
     P.col_stride_out = 0; P.t_stride_out = out_stride; P.j_stride_out = 1;
     P.scale = n_inv;
-    rc = launch_ntt_pass(P, 1, d_in, d_out, w, s);
+    rc = launch_ntt_pass(P, 1, d_in, d_out, w, nullptr, s);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_ntt_tile launch: ") + hipGetErrorString((hipError_t)rc));
     return TMX_OK;
   }
@@ -1266,13 +1284,16 @@ static int32_t ntt_run(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const void* 
   P.col_stride_in = in_stride; P.t_stride_in = 1; P.j_stride_in = N2;
   P.col_stride_out = N; P.t_stride_out = 1; P.j_stride_out = N2;
   P.post_twiddle = 1; P.scale = 1;
-  rc = launch_ntt_pass(P, n_cols, d_in, tmp, w, s);
+  void* m = nullptr;
+  st = ntt_matrix(c, log_n, b, inverse, w, s, &m);
+  if (st) return st;
+  rc = launch_ntt_pass(P, n_cols, d_in, tmp, w, m, s);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_ntt_tile launch: ") + hipGetErrorString((hipError_t)rc));
   P.log_l = b; P.log_t = std::min(tile_log_of(b) - b, a); P.n_sub = N1; P.tiles_per_col = (uint32_t)(N1 >> P.log_t);
   P.col_stride_in = N; P.t_stride_in = N2; P.j_stride_in = 1;
   P.col_stride_out = out_stride; P.t_stride_out = 1; P.j_stride_out = N1;
   P.post_twiddle = 0; P.scale = n_inv;
-  rc = launch_ntt_pass(P, n_cols, tmp, d_out, w, s);
+  rc = launch_ntt_pass(P, n_cols, tmp, d_out, w, nullptr, s);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_ntt_tile launch: ") + hipGetErrorString((hipError_t)rc));
   return TMX_OK;
 }
@@ -1287,6 +1308,9 @@ int32_t tmx_ntt_set_domain(tmx_ctx* c, uint64_t root_2_32, uint64_t coset_shift)
     HIPCK(c, hipDeviceSynchronize());
     for (auto& w : c->d_ntt_w)
       if (w) { (void)hipFree(w); w = nullptr; }
+    for (auto& dir : c->d_ntt_m)
+      for (auto& m : dir)
+        if (m) { (void)hipFree(m); m = nullptr; }
   }
   c->ntt_root = root_2_32; c->ntt_shift = coset_shift;
   return TMX_OK;

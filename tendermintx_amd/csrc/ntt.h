@@ -20,7 +20,8 @@ struct NttPass {
 };
 
 int launch_ntt_table(void* d_w, uint32_t log_n, uint64_t root_2_32, void* stream);
-int launch_ntt_pass(const NttPass& P, uint32_t n_cols, const void* d_in, void* d_out, const void* d_w, void* stream);
+int launch_ntt_matrix(void* d_m, const void* d_w, uint32_t log_n, uint32_t log_n2, bool inverse, void* stream);  // the pass-A twiddles
+int launch_ntt_pass(const NttPass& P, uint32_t n_cols, const void* d_in, void* d_out, const void* d_w, const void* d_m, void* stream);
 int launch_lde_expand(void* d_buf, uint32_t log_n, uint32_t log_m, uint32_t n_cols, uint64_t shift, void* stream);
 
 }  // namespace tmx

@@ -252,25 +252,29 @@ __device__ __forceinline__ void tile_load(uint64_t* __restrict__ s, const uint64
 // takes the 16 CONSECUTIVE words 16 r .. 16 r + 15 of its sub-transform, i.e. the outputs k = bitrev(16 r + i) = (bitrev4(i) << (LOG_L - 4)) |
 // bitrev(r) -- lanes with consecutive k would read words L/2, L/4, ... apart, all in a few banks.  Contiguous passes: k follows the lanes.
 template <int LOG_L, int LOG_T, bool CONTIG, bool FULL>
-__device__ __forceinline__ void tile_store(const uint64_t* __restrict__ s, uint64_t* __restrict__ dst, const uint64_t* __restrict__ W,
+__device__ __forceinline__ void tile_store(const uint64_t* __restrict__ s, uint64_t* __restrict__ dst, const uint64_t* __restrict__ TM,
                                            const NttPass& P, uint32_t t0, uint32_t n_sub, uint32_t ts, uint32_t js) {
   using M = TileMap<LOG_L, LOG_T, CONTIG>;
   constexpr uint32_t SS = sub_stride<LOG_L, LOG_T>();
   const uint32_t tl = M::t_of(threadIdx.x), r0 = M::j_of(threadIdx.x);
-  const bool inv = P.inverse != 0, post = P.post_twiddle != 0, scaled = P.scale != 1;
+  const bool post = P.post_twiddle != 0, scaled = P.scale != 1;
   constexpr int HB = LOG_L > 4 ? LOG_L - 4 : 1;  // bits of r0 in the strided mapping
   const uint32_t k0 = CONTIG ? r0 : (LOG_L > 4 ? (__brev(r0) >> (32 - HB)) : 0u);
   const uint32_t kr0 = __brev(r0) >> (32 - LOG_L);  // (contiguous mapping) bitrev(k0 + dj) = bitrev(k0) + bitrev(dj): no common bits
   const uint64_t* q = s + tl * SS + (CONTIG ? lds_pad(kr0) : 17u * r0);
+  // the four-step twiddles omega_N^(n2 k1) come from a matrix in the layout of this pass's output column: same offsets, same coalescing
+  const uint64_t in_col = (uint64_t)(t0 + tl) * ts + (uint64_t)k0 * js;
+  const uint64_t* tm = TM + in_col;
   uint64_t v[16], w[16];
   uint32_t dk[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     dk[i] = CONTIG ? M::dj(i) : (brev_bits(i, 4) << (LOG_L - 4));
+    const uint64_t step = (uint64_t)M::dt(i) * ts + (uint64_t)dk[i] * js;
     v[i] = q[CONTIG ? M::dt(i) * SS + pad_off(brev_bits(M::dj(i), LOG_L)) : (uint32_t)i];
-    w[i] = post ? twiddle(W, P.log_n, (uint64_t)__umul24(t0 + tl + M::dt(i), k0 + dk[i]), inv) : 1;  // omega_N^(n2 k1), both < 2^11
+    w[i] = (post && (FULL || t0 + tl + M::dt(i) < n_sub)) ? tm[step] : 1;
   }
-  uint64_t* o = dst + ((uint64_t)(t0 + tl) * ts + (uint64_t)k0 * js);
+  uint64_t* o = dst + in_col;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     uint64_t r = v[i];
@@ -285,7 +289,7 @@ __device__ __forceinline__ void tile_store(const uint64_t* __restrict__ s, uint6
 // of up to 2^14 elements, launch with max(64, tile / 16) threads)
 template <int LOG_L, int LOG_T>
 __global__ __launch_bounds__(1024) void k_ntt_tile(NttPass P, const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
-                                                  const uint64_t* __restrict__ W) {
+                                                  const uint64_t* __restrict__ W, const uint64_t* __restrict__ M) {
   extern __shared__ uint64_t lds[];
   constexpr uint32_t L = 1u << LOG_L;
   constexpr bool FIXED = LOG_T >= 0;
@@ -345,8 +349,8 @@ __global__ __launch_bounds__(1024) void k_ntt_tile(NttPass P, const uint64_t* __
     const bool contiguous = js == 1;
     if constexpr (FIXED) {
       constexpr int LT = FIXED ? LOG_T : 0;
-      if (contiguous) { if (full) tile_store<LOG_L, LT, true, true>(s, dst, W, P, t0, n_sub, ts, js); else tile_store<LOG_L, LT, true, false>(s, dst, W, P, t0, n_sub, ts, js); }
-      else { if (full) tile_store<LOG_L, LT, false, true>(s, dst, W, P, t0, n_sub, ts, js); else tile_store<LOG_L, LT, false, false>(s, dst, W, P, t0, n_sub, ts, js); }
+      if (contiguous) { if (full) tile_store<LOG_L, LT, true, true>(s, dst, M, P, t0, n_sub, ts, js); else tile_store<LOG_L, LT, true, false>(s, dst, M, P, t0, n_sub, ts, js); }
+      else { if (full) tile_store<LOG_L, LT, false, true>(s, dst, M, P, t0, n_sub, ts, js); else tile_store<LOG_L, LT, false, false>(s, dst, M, P, t0, n_sub, ts, js); }
     } else {
       const bool post = P.post_twiddle != 0, scaled = P.scale != 1;
       uint64_t v[16], w[16];
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(1024) void k_ntt_tile(NttPass P, const uint64_t* __
         const bool live = e < tile && t0 + t < n_sub;
         const uint32_t kr = LOG_L ? (__brev(k) >> (32 - (LOG_L ? LOG_L : 1))) : 0u;
         v[i] = live ? s[lds_pad(t * L + kr)] : 0;
-        w[i] = (post && live) ? twiddle(W, P.log_n, (uint64_t)((t0 + t) * k), inv) : 1;  // omega_N^(n2 k1), n2 k1 < N <= 2^22
+        w[i] = (post && live) ? M[(uint64_t)(t0 + t) * ts + (uint64_t)k * js] : 1;  // omega_N^(n2 k1), in the layout of the output column
       }
 #pragma unroll
       for (int i = 0; i < 16; i++) {
@@ -390,7 +394,21 @@ int launch_ntt_table(void* d_w, uint32_t log_n, uint64_t root_2_32, void* stream
                      reinterpret_cast<uint64_t*>(d_w), log_n, root_2_32);
   return (int)hipGetLastError();
 }
-int launch_ntt_pass(const NttPass& P, uint32_t n_cols, const void* d_in, void* d_out, const void* d_w, void* stream) {
+// M[k1 N2 + n2] = omega_N^(+- n2 k1): the twiddles between the two passes of the four-step split, in the layout pass A writes
+__global__ __launch_bounds__(256) void k_ntt_matrix(uint64_t* __restrict__ M, const uint64_t* __restrict__ W, uint32_t log_n, uint32_t log_n2,
+                                                    uint32_t inverse) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >> log_n) return;
+  const uint64_t k1 = e >> log_n2, n2 = e & ((1ull << log_n2) - 1);
+  M[e] = twiddle(W, log_n, n2 * k1, inverse != 0);
+}
+int launch_ntt_matrix(void* d_m, const void* d_w, uint32_t log_n, uint32_t log_n2, bool inverse, void* stream) {
+  const uint64_t n = 1ull << log_n;
+  hipLaunchKernelGGL(k_ntt_matrix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<uint64_t*>(d_m), reinterpret_cast<const uint64_t*>(d_w), log_n, log_n2, inverse ? 1u : 0u);
+  return (int)hipGetLastError();
+}
+int launch_ntt_pass(const NttPass& P, uint32_t n_cols, const void* d_in, void* d_out, const void* d_w, const void* d_m, void* stream) {
   const size_t tile = ((size_t)1 << P.log_l) << P.log_t;
   // the outer twiddles (fewer than L words) + the padded tile (+ 64 words for the per-sub-transform skew of the fixed-shape kernels)
   const size_t lds = 8 * (tile + (tile >> 4) + 1 + 64) + ((size_t)8 << P.log_l);
@@ -404,7 +422,8 @@ int launch_ntt_pass(const NttPass& P, uint32_t n_cols, const void* d_in, void* d
       lds_set = lds;                                                                                                                 \
     }                                                                                                                                \
     hipLaunchKernelGGL((k_ntt_tile<LL, LT>), dim3(n_cols * P.tiles_per_col), dim3(threads), lds, reinterpret_cast<hipStream_t>(stream), P, \
-                       reinterpret_cast<const uint64_t*>(d_in), reinterpret_cast<uint64_t*>(d_out), reinterpret_cast<const uint64_t*>(d_w)); \
+                       reinterpret_cast<const uint64_t*>(d_in), reinterpret_cast<uint64_t*>(d_out), reinterpret_cast<const uint64_t*>(d_w), \
+                       reinterpret_cast<const uint64_t*>(d_m));                                                                        \
   }
   // tiles of 2^12 .. 2^14 elements take the kernels with a compile-time shape, anything else (few columns) the generic one
 #define TMX_NTT_CASE(LL)                                                                                                              \
