@@ -83,6 +83,31 @@ def test_ntt_matches_oracle(env, log_n, cols):
     assert np.array_equal(oc.ntt(want, inverse=True), x % np.uint64(P))
 
 
+@pytest.mark.parametrize("log_n,cols", [(4, 3), (10, 4), (11, 8), (13, 2), (16, 1)])
+@pytest.mark.parametrize("fill", ["all_ones", "p_minus_1", "above_p", "extremes"])
+def test_ntt_noncanonical_and_extreme_inputs(env, log_n, cols, fill):
+    """The kernel keeps values as arbitrary 64-bit representatives between its stages (only the second operand of a butterfly and the
+    final store are canonical): inputs at and above p, all 2^64 - 1, and alternating extremes must still come out bit-exact."""
+    torch, ctx, oc = env
+    n = 1 << log_n
+    rng = np.random.default_rng(7000 + log_n)
+    if fill == "all_ones":
+        x = np.full((cols, n), 2**64 - 1, dtype=np.uint64)
+    elif fill == "p_minus_1":
+        x = np.full((cols, n), P - 1, dtype=np.uint64)
+    elif fill == "above_p":
+        x = rng.integers(P, 2**64, size=(cols, n), dtype=np.uint64, endpoint=False)
+    else:
+        x = rng.choice(np.array([0, 1, P - 1, P, P + 1, 2**64 - 1, 2**32 - 1, 2**32, 2**63], dtype=np.uint64), size=(cols, n))
+    d = _to_dev(torch, x)
+    out = torch.empty_like(d)
+    s = torch.cuda.current_stream().cuda_stream
+    for inverse in (False, True):
+        ctx.ntt_device(log_n, cols, d.data_ptr(), out.data_ptr(), inverse, s)
+        torch.cuda.synchronize()
+        assert np.array_equal(_to_host(out), oc.ntt(x, inverse=inverse)), (fill, inverse)
+
+
 @pytest.mark.parametrize("log_n,log_blowup,cols", [(0, 1, 2), (3, 3, 3), (8, 2, 5), (10, 3, 2), (12, 1, 3), (13, 3, 1)])
 def test_lde_matches_oracle(env, log_n, log_blowup, cols):
     torch, ctx, oc = env
