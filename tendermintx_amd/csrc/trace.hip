@@ -13,6 +13,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "ge25519.hpp"
 #include "inv25519.hpp"
 #include "sha2.hpp"
@@ -121,13 +123,19 @@ __global__ __launch_bounds__(64) void k_trace_ladder_pass1(uint32_t n_lanes, con
 // Montgomery's trick with SUFFIX products so that the points come out in row order: total = Z_0 ... Z_16, then for i = 0, 1, ...:
 // 1 / Z_i = inv_i * suf_{i+1} with inv_i = 1 / suf_i, inv_{i+1} = inv_i * Z_i.  Only suf_4, suf_8, suf_12, suf_16 are kept (40 VGPRs);
 // the three in between are recomputed per group of four from the Z's (re-read from the scratch buffer: coalesced, mostly L2).
+// One safegcd inversion serves GCH batches (the inversion was 35 % of this pass's instructions with one per batch): a first backward
+// sweep over the Z's of all GCH batches leaves the suffix products at the batch boundaries in LDS, the inversion of the total gives
+// 1 / (everything from batch 0 on), and every batch then runs the schedule above with "everything behind this batch" folded into its
+// suffix products; the running inverse ends a batch as the inverse of what is left, i.e. where the next batch starts.
+template <int GCH>
 __global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t n_lanes, uint32_t n, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
                                                            uint32_t ed_stride, const int32_t* __restrict__ pts, uint64_t* __restrict__ out,
                                                            uint64_t proof_stride, uint32_t chunk0) {
   __shared__ uint32_t stage[64][TR_LADDER_ROW + 1];
   __shared__ uint64_t s_base[64];
   __shared__ uint8_t s_live[64];
-  const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t, c = chunk0 + blockIdx.y;  // batch c = rows CH c .. CH c + CH - 1
+  __shared__ int32_t s_behind[GCH > 1 ? GCH - 1 : 1][10][64];  // [q - 1]: product of the Z's of batches q .. GCH - 1 of this thread
+  const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t, c_first = chunk0 + blockIdx.y * GCH;  // batch c = rows CH c .. CH c + CH - 1
   const bool live = id < 2u * n_lanes;
   const uint32_t lane = live ? id >> 1 : 0u, k = id & 1u;
   {
@@ -138,9 +146,8 @@ __global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t n_lanes, uin
   const LadderIn L = ladder_inputs(lane, k, in_target, ed, ed_stride, false);
   const int32_t* src = pts + (size_t)blockIdx.x * TR_LADDER_ROWS * TR_PT_WORDS * 64u + t;
   static_assert(CH == 8, "the unrolled schedule below is written for batches of eight rows (17 points)");
-  const uint32_t start_bit = c ? scalar_bit(L.sc, (int)(CH * c) - 1) : 0u;
-  // point i of the batch: 0 = the accumulator the batch starts from (row CH c - 1's nxt; the identity for c = 0); 1 + 2j / 2 + 2j = dbl / add of row j
-  auto coord = [&](int i, int which_coord) -> fe {  // which_coord: 0 X, 1 Y, 2 Z
+  // point i of batch c: 0 = the accumulator the batch starts from (row CH c - 1's nxt; the identity for c = 0); 1 + 2j / 2 + 2j = dbl / add of row j
+  auto coord = [&](uint32_t c, uint32_t start_bit, int i, int which_coord) -> fe {  // which_coord: 0 X, 1 Y, 2 Z
     fe v;
     if (i == 0 && c == 0) { v = which_coord == 0 ? fe_zero() : fe_one(); return v; }
     const int r = i == 0 ? (int)(CH * c) - 1 : (int)(CH * c) + (i - 1) / 2;
@@ -150,58 +157,88 @@ __global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t n_lanes, uin
     for (int l = 0; l < 10; l++) v.v[l] = row[l * 64];
     return v;
   };
-  fe ck[4];  // suf_4, suf_8, suf_12, suf_16
-  fe tot = coord(16, 2);
-  ck[3] = tot;
+  auto start_bit_of = [&](uint32_t c) -> uint32_t { return c ? scalar_bit(L.sc, (int)(CH * c) - 1) : 0u; };
+  // sweep 1: the product of every Z of the GCH batches, suffixes at the batch boundaries to LDS
+  fe inv;
+  {
+    fe tot = fe_one();
+#pragma unroll 1
+    for (int q = GCH - 1; q >= 0; q--) {
+      const uint32_t c = c_first + (uint32_t)q, sb = start_bit_of(c);
 #pragma unroll
-  for (int i = 15; i >= 0; i--) {
-    tot = fe_mul(coord(i, 2), tot);
-    if (i == 12) ck[2] = tot;
-    if (i == 8) ck[1] = tot;
-    if (i == 4) ck[0] = tot;
+      for (int i = 16; i >= 0; i--) tot = (q == GCH - 1 && i == 16) ? coord(c, sb, 16, 2) : fe_mul(coord(c, sb, i, 2), tot);
+      if (q > 0) {
+#pragma unroll
+        for (int l = 0; l < 10; l++) s_behind[q - 1][l][t] = tot.v[l];
+      }
+    }
+    inv = fe_invert_safegcd(tot);
   }
-  fe inv = fe_invert_safegcd(tot);
   const uint32_t z = L.decoded ? 0xffffffffu : 0u;  // an undecodable lane: all-zero rows (Level-1 reports zero points there too)
   uint32_t accw[16], dblw[16];
-  auto affine = [&](int i, const fe& zinv, uint32_t w[16]) {
-    fe_to_words(fe_mul(coord(i, 0), zinv), w);
-    fe_to_words(fe_mul(coord(i, 1), zinv), w + 8);
-  };
-  auto emit_point = [&](int i, const fe& zinv) {  // points arrive in order: start, dbl_0, add_0, dbl_1, ...
-    uint32_t w[16];
-    affine(i, zinv, w);
-    if (i == 0) {
+#pragma unroll 1
+  for (int q = 0; q < GCH; q++) {
+    const uint32_t c = c_first + (uint32_t)q, start_bit = start_bit_of(c);
+    const bool last = q == GCH - 1;
+    fe behind = fe_one();  // product of everything behind this batch
+    if (!last) {
 #pragma unroll
-      for (int q = 0; q < 16; q++) accw[q] = w[q];
-    } else if (i & 1) {
-#pragma unroll
-      for (int q = 0; q < 16; q++) dblw[q] = w[q];
-    } else {
-      const int j = (i - 2) / 2;
-      const uint32_t bit = scalar_bit(L.sc, (int)(CH * c) + j);
-      stage[t][0] = bit & z;
-#pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const uint32_t nx = bit ? w[q] : dblw[q];
-        stage[t][1 + q] = accw[q] & z;
-        stage[t][17 + q] = dblw[q] & z;
-        stage[t][33 + q] = w[q] & z;
-        stage[t][49 + q] = nx & z;
-        accw[q] = nx;
-      }
-      coop_flush<TR_LADDER_ROW>(stage, s_base, s_live, (uint64_t)(CH * c + j) * TR_LADDER_ROW, out);
+      for (int l = 0; l < 10; l++) behind.v[l] = s_behind[last ? 0 : q][l][t];
     }
-  };
+    fe ck[4];  // suf_4, suf_8, suf_12, suf_16 (each times `behind`)
+    {
+      fe tot = last ? coord(c, start_bit, 16, 2) : fe_mul(coord(c, start_bit, 16, 2), behind);
+      ck[3] = tot;
 #pragma unroll
-  for (int g = 0; g < 4; g++) {
-    const fe z3 = coord(4 * g + 3, 2), z2 = coord(4 * g + 2, 2), z1 = coord(4 * g + 1, 2), z0 = coord(4 * g, 2);
-    const fe s3 = fe_mul(z3, ck[g]), s2 = fe_mul(z2, s3), s1 = fe_mul(z1, s2);
-    emit_point(4 * g, fe_mul(inv, s1)); inv = fe_mul(inv, z0);
-    emit_point(4 * g + 1, fe_mul(inv, s2)); inv = fe_mul(inv, z1);
-    emit_point(4 * g + 2, fe_mul(inv, s3)); inv = fe_mul(inv, z2);
-    emit_point(4 * g + 3, fe_mul(inv, ck[g])); inv = fe_mul(inv, z3);
+      for (int i = 15; i >= 1; i--) {
+        tot = fe_mul(coord(c, start_bit, i, 2), tot);
+        if (i == 12) ck[2] = tot;
+        if (i == 8) ck[1] = tot;
+        if (i == 4) ck[0] = tot;
+      }
+    }
+    auto affine = [&](int i, const fe& zinv, uint32_t w[16]) {
+      fe_to_words(fe_mul(coord(c, start_bit, i, 0), zinv), w);
+      fe_to_words(fe_mul(coord(c, start_bit, i, 1), zinv), w + 8);
+    };
+    auto emit_point = [&](int i, const fe& zinv) {  // points arrive in order: start, dbl_0, add_0, dbl_1, ...
+      uint32_t w[16];
+      affine(i, zinv, w);
+      if (i == 0) {
+#pragma unroll
+        for (int qq = 0; qq < 16; qq++) accw[qq] = w[qq];
+      } else if (i & 1) {
+#pragma unroll
+        for (int qq = 0; qq < 16; qq++) dblw[qq] = w[qq];
+      } else {
+        const int j = (i - 2) / 2;
+        const uint32_t bit = scalar_bit(L.sc, (int)(CH * c) + j);
+        stage[t][0] = bit & z;
+#pragma unroll
+        for (int qq = 0; qq < 16; qq++) {
+          const uint32_t nx = bit ? w[qq] : dblw[qq];
+          stage[t][1 + qq] = accw[qq] & z;
+          stage[t][17 + qq] = dblw[qq] & z;
+          stage[t][33 + qq] = w[qq] & z;
+          stage[t][49 + qq] = nx & z;
+          accw[qq] = nx;
+        }
+        coop_flush<TR_LADDER_ROW>(stage, s_base, s_live, (uint64_t)(CH * c + j) * TR_LADDER_ROW, out);
+      }
+    };
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const fe z3 = coord(c, start_bit, 4 * g + 3, 2), z2 = coord(c, start_bit, 4 * g + 2, 2), z1 = coord(c, start_bit, 4 * g + 1, 2),
+               z0 = coord(c, start_bit, 4 * g, 2);
+      const fe s3 = fe_mul(z3, ck[g]), s2 = fe_mul(z2, s3), s1 = fe_mul(z1, s2);
+      emit_point(4 * g, fe_mul(inv, s1)); inv = fe_mul(inv, z0);
+      emit_point(4 * g + 1, fe_mul(inv, s2)); inv = fe_mul(inv, z1);
+      emit_point(4 * g + 2, fe_mul(inv, s3)); inv = fe_mul(inv, z2);
+      emit_point(4 * g + 3, fe_mul(inv, ck[g])); inv = fe_mul(inv, z3);
+    }
+    emit_point(16, last ? inv : fe_mul(inv, behind));
+    if (!last) inv = fe_mul(inv, coord(c, start_bit, 16, 2));
   }
-  emit_point(16, inv);
 }
 
 // SHA-512(R | A | M) of the effective triple of one lane (at most two blocks), 18 values per round
@@ -389,10 +426,20 @@ int launch_trace_ladder_pass1(uint32_t n, uint32_t n_proofs, const void* d_targe
 int launch_trace_ladder_pass2(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_ed, uint32_t ed_stride, const void* d_tmp,
                               void* d_out, uint32_t row0, uint32_t row1, void* stream) {
   if (n_proofs == 0) return 0;
-  const uint32_t lanes = n_proofs * n;
-  hipLaunchKernelGGL(k_trace_ladder_pass2, dim3((2 * lanes + 63) / 64, (row1 - row0) / CH), dim3(64), 0, S_(stream), lanes, n, reinterpret_cast<const uint8_t*>(d_target),
-                     reinterpret_cast<const uint8_t*>(d_ed), ed_stride, reinterpret_cast<const int32_t*>(d_tmp), reinterpret_cast<uint64_t*>(d_out),
-                     trace_elems(kind, n), row0 / CH);
+  const uint32_t lanes = n_proofs * n, chunks = (row1 - row0) / CH;
+  // batches per inversion.  Measured per 256-proof batch (ladders): 1 -> 6.80 ms, 2 -> 6.58, 4 -> 8.25, 8 -> 7.47: the inversion is 35 % of the
+  // pass's instructions, but the pass is latency-bound at two waves per SIMD -- a thread that does four batches in a row loses more to the
+  // longer chain and the thinner launch than it saves.  TMX_TRACE_GCH overrides.
+#define TMX_TRACE_P2(G)                                                                                                                        \
+  hipLaunchKernelGGL((k_trace_ladder_pass2<G>), dim3((2 * lanes + 63) / 64, chunks / G), dim3(64), 0, S_(stream), lanes, n,                       \
+                     reinterpret_cast<const uint8_t*>(d_target), reinterpret_cast<const uint8_t*>(d_ed), ed_stride,                             \
+                     reinterpret_cast<const int32_t*>(d_tmp), reinterpret_cast<uint64_t*>(d_out), trace_elems(kind, n), row0 / CH)
+  static const int g_env = std::getenv("TMX_TRACE_GCH") ? std::atoi(std::getenv("TMX_TRACE_GCH")) : 2;
+  if (g_env >= 8 && chunks % 8 == 0) TMX_TRACE_P2(8);
+  else if (g_env >= 4 && chunks % 4 == 0) TMX_TRACE_P2(4);
+  else if (g_env >= 2 && chunks % 2 == 0) TMX_TRACE_P2(2);
+  else TMX_TRACE_P2(1);
+#undef TMX_TRACE_P2
   return (int)hipGetLastError();
 }
 
