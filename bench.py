@@ -86,13 +86,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    # TMX_BENCH_SHARE_GPU=1 (development aid for 1-GPU boxes): every rank on cuda:0 with gloo as the control backend, so that the
+    # multi-rank control flow (sharding of the proofs, barrier, max over ranks, one JSON line) can be exercised without a second GPU.
+    # The numbers of such a run mean nothing (the ranks share one device) and the line says so.
+    share_gpu = os.environ.get("TMX_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.mode == "c5"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
@@ -109,7 +118,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -226,7 +235,7 @@ def main():
     # every proof of this rank must have verified (synthetic inputs are well-formed)
     rep = d_rep.cpu().numpy().reshape(-1, 64)[:P]
     all_ok = int(rep[:, 32:36].copy().view(np.uint32).sum())
-    ok_flag = torch.tensor([1 if all_ok == P else 0], device=dev)
+    ok_flag = torch.tensor([1 if all_ok == P else 0], device="cpu" if share_gpu else dev)
     if world > 1:
         dist.all_reduce(ok_flag, op=dist.ReduceOp.MIN)
 
@@ -250,6 +259,7 @@ def main():
             "throughput": {"proofs_per_s": round(P_total / (ms_per_step * 1e-3), 1), "lanes_per_s": round(P_total * n / (ms_per_step * 1e-3), 1)},
             "kernels_ms": dict({k: round(v, 4) for k, v in kms.items()}, step_events=round(step_ms_events, 4)),
             "all_proofs_ok": bool(int(ok_flag.item())),
+            **({"debug_shared_gpu": "TMX_BENCH_SHARE_GPU=1: every rank ran on cuda:0 (control-flow test, timings meaningless)"} if share_gpu else {}),
             "dedup": {"lanes": lanes, "distinct_keys": n_unique, "per_key_tables": used_tables},
         }
         if gather_ms is not None:
