@@ -292,6 +292,9 @@ struct tmx_ctx {
   uint32_t k_mul_split = 0;
   bool k_no_wide = false;
   uint32_t k_proof_threads = 0;
+  int32_t k_ser_in_wgs = -1;  // TMX_SER_IN_WGS: workgroups of the serializer launches that run beside the EdDSA chain (0: one per four spans; default by size)
+  uint32_t k_ser_wgs = 0;     // TMX_SER_WGS: the same for every other serializer launch
+  uint32_t k_ntt_tile_log = 0;  // TMX_NTT_TILE_LOG (0: by sub-transform length)
   // Goldilocks NTT: twiddle tables per transform size (built on first use), scratch for the four-step split / LDE
   void* d_ntt_w[TMX_NTT_MAX_LOG + 1] = {};
   void* d_ntt_m[2][TMX_NTT_MAX_LOG + 1] = {};  // four-step twiddle matrices omega_N^(+- n2 k1) (forward, inverse), built on first use
@@ -344,12 +347,13 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   src.base[SRC_TL] = tl; src.base[SRC_LR] = (const uint8_t*)c->d_lr; src.base[SRC_PF] = (const uint8_t*)c->d_pf;
   src.nodes_t = (const uint8_t*)c->d_nodes_t; src.nodes_r = (const uint8_t*)c->d_nodes_r;
   const Program& prog = c->prog[kind];
-  auto serialize = [&](uint32_t mask, hipStream_t on) -> int32_t {
+  auto serialize = [&](uint32_t mask, hipStream_t on, uint32_t max_wgs = 0xffffffffu) -> int32_t {
     if (!d_out_elems) return TMX_OK;
+    if (max_wgs == 0xffffffffu) max_wgs = c->k_ser_wgs;
     // (sections the caller did not ask for are not written; the seam spans are few and always written)
     mask &= ((c->sections & TMX_SEC_HINT) ? prog.mask_hint : 0u) | ((c->sections & TMX_SEC_DERIVED) ? prog.mask_derived : 0u) | (1u << 31);
     int r = launch_serialize(prog.sp, src, c->d_lut[kind], c->d_wave_sec[kind], c->d_seams[kind], (uint32_t)prog.seam_waves.size(), n_proofs,
-                             d_out_elems, mask, on);
+                             d_out_elems, mask, on, max_wgs);
     if (r) return fail(c, TMX_ERR_HIP, std::string("k_serialize launch: ") + hipGetErrorString((hipError_t)r));
     return TMX_OK;
   };
@@ -369,8 +373,14 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // instructions) and the high-priority placement only moves the time around: 1.894 vs 1.895 ms; at 256 proofs it costs 8 %.)
   const bool inputs_hi = c->quad && c->ser_split && c->k_inputs_side2;
   hipStream_t in_stream = inputs_hi ? c->side2 : c->side3;
+  // Launches that run beside the EdDSA latency chain are walked by a fixed number of workgroups (k_serialize_few): a memory-bound grid of
+  // half a million short waves keeps every wave slot of the chip taken, and the chain's workgroups then wait for a slot whatever their
+  // priority (a pure store stream beside the EdDSA stage: k_ed_keys 50 -> 103 us, the stage 0.42 -> 0.72 ms).  Four workgroups per CU
+  // still write at the rate these sections need.  Measured (TMX_SER_IN_WGS=0|n): step -3 % at 256 proofs x 128 (1024 or 1280 workgroups;
+  // 512: the EdDSA stage -48 us but the sections end after it), -4.5 % at 512, -3 % at 1024 (1536), -1 % at 64, +-0 at 32.
+  const uint32_t beside_chain_wgs = c->k_ser_in_wgs >= 0 ? (uint32_t)c->k_ser_in_wgs : ((uint64_t)n_proofs * n >= 131072 ? 1536u : 1024u);
   auto inputs_on_side3 = [&]() -> int32_t {
-    const int32_t r = c->ser_split ? serialize(prog.mask_inputs, in_stream) : TMX_OK;
+    const int32_t r = c->ser_split ? serialize(prog.mask_inputs, in_stream, beside_chain_wgs) : TMX_OK;
     if (r) return r;
     HIPCK(c, hipEventRecord(c->ev_join3, in_stream));
     return TMX_OK;
@@ -393,7 +403,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_leaves launch: ") + hipGetErrorString((hipError_t)rc));
     if (!c->k_ext_events) HIPCK(c, hipEventRecord(c->ev_leaves, c->side));
     HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_leaves, 0));
-    if ((st0 = serialize(prog.mask_leaves, c->side3))) return st0;
+    if ((st0 = serialize(prog.mask_leaves, c->side3, beside_chain_wgs))) return st0;
   }
   rc = launch_proof(proof_params(c, kind, leaves_first), n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf, c->d_nodes_t,
                         c->d_nodes_r, reports, c->side);
@@ -418,7 +428,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   if (leaves_first) {  // side3, behind the input sections and D.2a: D.1a as soon as phase 1 is done; ev_join3 moves behind it
     if (!c->ev_hash_recorded) HIPCK(c, hipEventRecord(c->ev_hash, s));  // (a producer without a phase-1 event: everything it enqueued)
     HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_hash, 0));
-    if ((st0 = serialize(prog.mask_p1, c->side3))) return st0;
+    if ((st0 = serialize(prog.mask_p1, c->side3, beside_chain_wgs))) return st0;
     HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
   }
   st0 = c->ser_split ? serialize(prog.mask_proof | (leaves_first ? 0u : prog.mask_leaves), c->side) : TMX_OK;
@@ -430,7 +440,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   const bool p1_early = leaves_first || (c->ser_split && c->ev_hash_recorded && (c->k_p1_early >= 0 ? c->k_p1_early != 0 : (uint64_t)n_proofs * n >= 131072));
   if (p1_early && !leaves_first) {
     HIPCK(c, hipStreamWaitEvent(c->side, c->ev_hash, 0));
-    if ((st0 = serialize(prog.mask_p1, c->side))) return st0;
+    if ((st0 = serialize(prog.mask_p1, c->side, beside_chain_wgs))) return st0;
   }
   HIPCK(c, hipStreamWaitEvent(c->side, c->ev_join3, 0));  // ev_join = both low-priority streams done
   HIPCK(c, hipEventRecord(c->ev_join, c->side));
@@ -819,6 +829,9 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     c->k_walk_parts = (v = std::getenv("TMX_WALK_PARTS")) ? (v[0] == '1' ? 1 : 0) : -1;
     c->k_mul_split = (v = std::getenv("TMX_MUL_SPLIT")) ? (v[0] == '1' ? 1u : (v[0] == '4' ? 4u : 2u)) : 0u;
     c->k_no_wide = (v = std::getenv("TMX_PROOF_WIDE")) && v[0] == '0';
+    c->k_ntt_tile_log = (v = std::getenv("TMX_NTT_TILE_LOG")) && std::atoi(v) >= 12 && std::atoi(v) <= 14 ? (uint32_t)std::atoi(v) : 0u;
+    c->k_ser_in_wgs = (v = std::getenv("TMX_SER_IN_WGS")) ? std::max(0, std::atoi(v)) : -1;
+    c->k_ser_wgs = (v = std::getenv("TMX_SER_WGS")) ? (uint32_t)std::max(0, std::atoi(v)) : 0u;
     c->k_proof_threads = (v = std::getenv("TMX_PROOF_THREADS")) && (std::atoi(v) == 64 || std::atoi(v) == 128 || std::atoi(v) == 256) ? (uint32_t)std::atoi(v) : 0u;
     c->k_p1_early = (v = std::getenv("TMX_P1_EARLY")) ? (v[0] != '0' ? 1 : 0) : -1;
     c->k_leaves = (v = std::getenv("TMX_LEAVES")) ? (v[0] != '0' ? 1 : 0) : -1;
@@ -1278,8 +1291,7 @@ static int32_t ntt_run(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const void* 
   // tiles of the two strided passes: T >= 8 sub-transforms side by side (runs of >= 64 B along the unit-stride dimension; with T = 4 at
   // N1 = 2^10, FETCH_SIZE was 4x the data), in the smallest tile that allows it (2^12 .. 2^14 elements: three, two or one workgroup per
   // CU's LDS).  Measured at 2^16 / 2^20 / 2^22: tiles of 2^12 / 2^13 / 2^14 elements are each the fastest there.
-  const char* tl_env = std::getenv("TMX_NTT_TILE_LOG");
-  auto tile_log_of = [&](uint32_t log_l) { return tl_env ? (uint32_t)std::atoi(tl_env) : std::min(14u, std::max(12u, log_l + 3u)); };
+  auto tile_log_of = [&](uint32_t log_l) { return c->k_ntt_tile_log ? c->k_ntt_tile_log : std::min(14u, std::max(12u, log_l + 3u)); };
   P.log_l = a; P.log_t = std::min(tile_log_of(a) - a, b); P.n_sub = N2; P.tiles_per_col = (uint32_t)(N2 >> P.log_t);
   P.col_stride_in = in_stride; P.t_stride_in = 1; P.j_stride_in = N2;
   P.col_stride_out = N; P.t_stride_out = 1; P.j_stride_out = N2;

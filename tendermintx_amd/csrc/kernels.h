@@ -66,7 +66,8 @@ int launch_verdict(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_e
                    void* started = nullptr, void* done = nullptr);
 // sec_mask: bit s = section s, bit 31 = waves straddling a section boundary / the row end
 int launch_serialize(const SerializeProgram& S, const SerializeSources& src, const void* d_lut, const void* d_wave_sec, const void* d_seam_waves,
-                     uint32_t n_seams, uint32_t n_proofs, void* d_out, uint32_t sec_mask, void* stream);
+                     uint32_t n_seams, uint32_t n_proofs, void* d_out, uint32_t sec_mask, void* stream, uint32_t max_wgs = 0);
+// (max_wgs != 0: at most that many workgroups walk the spans -- launches that run beside the EdDSA latency chain must not fill every wave slot)
 // packs elements [first, first + row_elems) of every row densely into d_out as u64 or u32 (transfer formats of the host entry point)
 int launch_pack_rows(const void* d_rows, void* d_out, uint32_t elem_stride, uint32_t first, uint32_t row_elems, uint32_t n_proofs, bool as_u32,
                      void* stream);
