@@ -292,6 +292,9 @@ struct tmx_ctx {
   uint32_t k_mul_split = 0;
   bool k_no_wide = false;
   uint32_t k_proof_threads = 0;
+  int k_tail_split = -1;  // TMX_TAIL_SPLIT: 1 / 0, default by batch size
+  uint32_t split_req = 0, split_lane = 0;  // run_batch asks (split_req), run_eddsa answers: != 0: the lanes [0, split_lane) were finished on side3 (ev_fin_a)
+  hipEvent_t ev_half = nullptr, ev_fin_a = nullptr;
   int32_t k_ser_in_wgs = -1;  // TMX_SER_IN_WGS: workgroups of the serializer launches that run beside the EdDSA chain (0: one per four spans; default by size)
   uint32_t k_ser_wgs = 0;     // TMX_SER_WGS: the same for every other serializer launch
   uint32_t k_ntt_tile_log = 0;  // TMX_NTT_TILE_LOG (0: by sub-transform length)
@@ -347,13 +350,14 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   src.base[SRC_TL] = tl; src.base[SRC_LR] = (const uint8_t*)c->d_lr; src.base[SRC_PF] = (const uint8_t*)c->d_pf;
   src.nodes_t = (const uint8_t*)c->d_nodes_t; src.nodes_r = (const uint8_t*)c->d_nodes_r;
   const Program& prog = c->prog[kind];
-  auto serialize = [&](uint32_t mask, hipStream_t on, uint32_t max_wgs = 0xffffffffu) -> int32_t {
+  auto serialize = [&](uint32_t mask, hipStream_t on, uint32_t max_wgs = 0xffffffffu, uint32_t proof0 = 0, uint32_t count = 0) -> int32_t {
     if (!d_out_elems) return TMX_OK;
     if (max_wgs == 0xffffffffu) max_wgs = c->k_ser_wgs;
+    if (count == 0) count = n_proofs - proof0;
     // (sections the caller did not ask for are not written; the seam spans are few and always written)
     mask &= ((c->sections & TMX_SEC_HINT) ? prog.mask_hint : 0u) | ((c->sections & TMX_SEC_DERIVED) ? prog.mask_derived : 0u) | (1u << 31);
-    int r = launch_serialize(prog.sp, src, c->d_lut[kind], c->d_wave_sec[kind], c->d_seams[kind], (uint32_t)prog.seam_waves.size(), n_proofs,
-                             d_out_elems, mask, on, max_wgs);
+    int r = launch_serialize(prog.sp, src, c->d_lut[kind], c->d_wave_sec[kind], c->d_seams[kind], (uint32_t)prog.seam_waves.size(), count,
+                             d_out_elems, mask, on, max_wgs, proof0);
     if (r) return fail(c, TMX_ERR_HIP, std::string("k_serialize launch: ") + hipGetErrorString((hipError_t)r));
     return TMX_OK;
   };
@@ -418,9 +422,19 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     c->fin_done_attached = false;
   }
   c->ev_hash_recorded = false;
+  {  // the tail in two halves (see run_eddsa).  Measured TMX_TAIL_SPLIT=1|0 at N = 128: -1.7 % step at 1024 proofs, +-0 at 512, but +10 % at
+    // 256 and +6 % at 64 (two walks of half the lanes hide their table fetches worse than one: the EdDSA stage 0.49 -> 0.54 ms) -> by size
+    const bool want = c->k_tail_split >= 0 ? c->k_tail_split != 0 : (uint64_t)n_proofs * n >= 131072;
+    const bool tail_aside_ = c->ser_split && (uint64_t)n_proofs * n >= 4096;
+    c->split_req = (want && d_out_elems && tail_aside_ && n_proofs >= 2) ? (n_proofs / 2) * n : 0u;
+    c->split_lane = 0;
+  }
   int32_t st = ed_producer(s);
   c->fin_done = nullptr;
   if (st) return st;
+  c->split_req = 0;
+  const uint32_t split_proofs = c->split_lane / n;  // != 0: the first split_proofs proofs are finished on side3 (ev_fin_a)
+  c->split_lane = 0;
   if (inputs_late && (st0 = inputs_on_side3())) return st0;
   // TMX_PROOFSER_HOLD=1 keeps these launches back until the table walk is done (with the 80 KB 4-bit key tables they doubled its run
   // time; with the 6-bit tables and the short finish they are better off right behind k_proof: -2 % step at 256 proofs)
@@ -442,6 +456,11 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     HIPCK(c, hipStreamWaitEvent(c->side, c->ev_hash, 0));
     if ((st0 = serialize(prog.mask_p1, c->side, beside_chain_wgs))) return st0;
   }
+  if (split_proofs) {  // (side3 is behind k_ed_fin of the first half already: its D.1 rows need that and k_proof)
+    HIPCK(c, hipStreamWaitEvent(c->side3, evs[1], 0));
+    if ((st0 = serialize(prog.mask_final | (p1_early ? 0u : prog.mask_p1), c->side3, 0xffffffffu, 0, split_proofs))) return st0;
+    HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
+  }
   HIPCK(c, hipStreamWaitEvent(c->side, c->ev_join3, 0));  // ev_join = both low-priority streams done
   HIPCK(c, hipEventRecord(c->ev_join, c->side));
   if (!c->fin_done_attached) HIPCK(c, hipEventRecord(ev[1], s));
@@ -461,6 +480,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     // verdict and the few sections that carry it go through the high-priority side stream.  (ev[2] = ev[1] here: every packet
     // between k_ed_fin and the serializer is latency on the critical path.)
     HIPCK(c, hipStreamWaitEvent(c->side2, ev[1], 0));
+    if (split_proofs) HIPCK(c, hipStreamWaitEvent(c->side2, c->ev_fin_a, 0));
     HIPCK(c, hipStreamWaitEvent(c->side2, evs[1], 0));  // k_proof itself, not the serializer launches queued behind it
     HIPCK(c, hipEventRecord(evs[2], c->side2));
     rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, c->side2);
@@ -470,7 +490,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     HIPCK(c, hipStreamWaitEvent(c->side2, c->ev_join, 0));  // ev_tail = every side stream done
     HIPCK(c, hipEventRecord(c->ev_tail, c->side2));
     HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
-    if ((st0 = serialize(prog.mask_final | (p1_early ? 0u : prog.mask_p1), s))) return st0;
+    if ((st0 = serialize(prog.mask_final | (p1_early ? 0u : prog.mask_p1), s, 0xffffffffu, split_proofs, 0))) return st0;
     HIPCK(c, hipStreamWaitEvent(s, c->ev_tail, 0));
   } else {
     HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
@@ -515,6 +535,8 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   {
     c->last_tiny = n_lanes != 0 && n_lanes <= 512 && c->keys16 && c->mul16 && c->k_tiny;
   }
+  const uint32_t split_req = c->split_req;
+  c->split_req = 0; c->split_lane = 0;
   if (c->last_tiny) {
     Q.mode = 0;
     if ((e = hipEventRecord(c->ev_fork2, s)) != hipSuccess) return (int)e;
@@ -611,9 +633,28 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
       if (rc) return rc;
     }
   }
+  // Tail in two halves (c->split_lane != 0: the walk is one launch, the tables are used, run_batch serializes): the walk of the first
+  // half of the lanes, then -- on the low-priority stream -- their finish (a latency chain of a few hundred waves) and their D.1 rows
+  // beside the walk of the second half; the step then ends with half a finish-and-D.1 behind the last walk instead of a whole one.
+  const uint32_t split_lane = (!walk_parts && split_req && split_req < n_lanes && Q.mode != 0 && Q.key_cap != 0) ? split_req : 0u;
+  c->split_lane = split_lane;
   if (!walk_parts) {
-    rc = launch_ed_mul_tab(Q, 0, 1, s);
-    if (rc) return rc;
+    if (split_lane) {
+      rc = launch_ed_mul_tab(Q, 0, 1, s, 0, split_lane);
+      if (rc) return rc;
+      if ((e = hipEventRecord(c->ev_half, s)) != hipSuccess) return (int)e;
+      if ((e = hipStreamWaitEvent(c->side3, c->ev_half, 0)) != hipSuccess) return (int)e;
+      EdQuad Qa = Q;
+      Qa.fin_done = nullptr;
+      rc = launch_ed_fin(Qa, c->side3, 0, split_lane);
+      if (rc) return rc;
+      if ((e = hipEventRecord(c->ev_fin_a, c->side3)) != hipSuccess) return (int)e;
+      rc = launch_ed_mul_tab(Q, 0, 1, s, split_lane, n_lanes);
+      if (rc) return rc;
+    } else {
+      rc = launch_ed_mul_tab(Q, 0, 1, s);
+      if (rc) return rc;
+    }
   }
   // (run_batch can hold the serializer launches of the side stream back until the walk is done: TMX_PROOFSER_HOLD)
   if (c->want_ev_mul) {
@@ -621,7 +662,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     c->ev_mul_recorded = true;
   }
   if (wait_p1_late && (e = hipStreamWaitEvent(s, c->ev_p1, 0)) != hipSuccess) return (int)e;
-  rc = launch_ed_fin(Q, s);
+  rc = launch_ed_fin(Q, s, split_lane, n_lanes);
   c->fin_done_attached = rc == 0 && Q.fin_done != nullptr && n_lanes != 0;
   return rc;
 }
@@ -754,6 +795,8 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   if (c->ev_leaves) (void)hipEventDestroy(c->ev_leaves);
   if (c->ev_hash_clean) (void)hipEventDestroy(c->ev_hash_clean);
   if (c->ev_mul) (void)hipEventDestroy(c->ev_mul);
+  if (c->ev_half) (void)hipEventDestroy(c->ev_half);
+  if (c->ev_fin_a) (void)hipEventDestroy(c->ev_fin_a);
   if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
   for (hipEvent_t e : c->ev_trace)
     if (e) (void)hipEventDestroy(e);
@@ -794,6 +837,8 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   HIPCK(c, hipEventCreateWithFlags(&c->ev_leaves, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_hash_clean, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_mul, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_half, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_fin_a, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   for (auto& set : c->ev_side)
     for (auto& ev : set) HIPCK(c, hipEventCreate(&ev));
@@ -832,6 +877,7 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     c->k_ntt_tile_log = (v = std::getenv("TMX_NTT_TILE_LOG")) && std::atoi(v) >= 12 && std::atoi(v) <= 14 ? (uint32_t)std::atoi(v) : 0u;
     c->k_ser_in_wgs = (v = std::getenv("TMX_SER_IN_WGS")) ? std::max(0, std::atoi(v)) : -1;
     c->k_ser_wgs = (v = std::getenv("TMX_SER_WGS")) ? (uint32_t)std::max(0, std::atoi(v)) : 0u;
+    c->k_tail_split = (v = std::getenv("TMX_TAIL_SPLIT")) ? (v[0] != '0' ? 1 : 0) : -1;
     c->k_proof_threads = (v = std::getenv("TMX_PROOF_THREADS")) && (std::atoi(v) == 64 || std::atoi(v) == 128 || std::atoi(v) == 256) ? (uint32_t)std::atoi(v) : 0u;
     c->k_p1_early = (v = std::getenv("TMX_P1_EARLY")) ? (v[0] != '0' ? 1 : 0) : -1;
     c->k_leaves = (v = std::getenv("TMX_LEAVES")) ? (v[0] != '0' ? 1 : 0) : -1;

@@ -53,8 +53,9 @@ int launch_ed_tab_mult(const EdQuad& Q, uint32_t part, uint32_t parts, void* str
 int launch_ed_mul_direct(const EdQuad& Q, void* stream, bool fuse_fin = false);
 // roles: 0 = both (SHA-512 + mod l, then s*B), 1 = the hash role only, 2 = s*B only
 int launch_ed_phase1(const EdQuad& Q, void* stream, void* done = nullptr, int roles = 0);
-int launch_ed_mul_tab(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream);
-int launch_ed_fin(const EdQuad& Q, void* stream);
+// (lane0 .. lane_end - 1: the lanes of this launch; lane_end = 0: to the end)
+int launch_ed_mul_tab(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream, uint32_t lane0 = 0, uint32_t lane_end = 0);
+int launch_ed_fin(const EdQuad& Q, void* stream, uint32_t lane0 = 0, uint32_t lane_end = 0);
 int launch_proof(const ProofParams& P, uint32_t n_proofs, const void* d_proofs, const void* d_target, const void* d_trusted, void* d_lt,
                  uint32_t lt_stride, void* d_lr, void* d_pf, void* d_nodes_t, void* d_nodes_r, void* d_reports, void* stream);
 // marshalled validators + leaf hashes of both sets as a launch of its own; k_proof then reads them (ProofParams::leaves_done)
@@ -66,7 +67,7 @@ int launch_verdict(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_e
                    void* started = nullptr, void* done = nullptr);
 // sec_mask: bit s = section s, bit 31 = waves straddling a section boundary / the row end
 int launch_serialize(const SerializeProgram& S, const SerializeSources& src, const void* d_lut, const void* d_wave_sec, const void* d_seam_waves,
-                     uint32_t n_seams, uint32_t n_proofs, void* d_out, uint32_t sec_mask, void* stream, uint32_t max_wgs = 0);
+                     uint32_t n_seams, uint32_t n_proofs, void* d_out, uint32_t sec_mask, void* stream, uint32_t max_wgs = 0, uint32_t proof0 = 0);
 // (max_wgs != 0: at most that many workgroups walk the spans -- launches that run beside the EdDSA latency chain must not fill every wave slot)
 // packs elements [first, first + row_elems) of every row densely into d_out as u64 or u32 (transfer formats of the host entry point)
 int launch_pack_rows(const void* d_rows, void* d_out, uint32_t elem_stride, uint32_t first, uint32_t row_elems, uint32_t n_proofs, bool as_u32,

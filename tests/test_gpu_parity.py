@@ -551,7 +551,7 @@ def test_validator_sharded_single_proof(tmx, oracle):
     {"TMX_TAB_PARTS": "1"}, {"TMX_PROOFSER_HOLD": "1"}, {"TMX_EXT_EVENTS": "0"}, {"TMX_ANCHOR16": "0"}, {"TMX_KEYS16": "0"}, {"TMX_MUL16": "0"},
     {"TMX_P1_SIDE": "1"}, {"TMX_P1_SIDE": "2"}, {"TMX_DEDUP": "0"}, {"TMX_DEDUP": "2"},
     {"TMX_LEAVES": "1"}, {"TMX_LEAVES": "0", "TMX_P1_EARLY": "1"}, {"TMX_LEAVES": "1", "TMX_SER_SPLIT": "0"},
-    {"TMX_SER_SPLIT": "0"}, {"TMX_SER_IN_WGS": "0"}, {"TMX_SER_IN_WGS": "7", "TMX_SER_WGS": "5"}, {"TMX_SER_SPAN": "128", "TMX_SER_WGS": "33"}, {"TMX_SER_SPAN": "128"}, {"TMX_SER_SPAN": "512"}, {"TMX_EDDSA": "mono"}], ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+    {"TMX_SER_SPLIT": "0"}, {"TMX_TAIL_SPLIT": "1"}, {"TMX_TAIL_SPLIT": "1", "TMX_DEDUP": "0"}, {"TMX_SER_IN_WGS": "0"}, {"TMX_SER_IN_WGS": "7", "TMX_SER_WGS": "5"}, {"TMX_SER_SPAN": "128", "TMX_SER_WGS": "33"}, {"TMX_SER_SPAN": "128"}, {"TMX_SER_SPAN": "512"}, {"TMX_EDDSA": "mono"}], ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
 def test_schedule_knobs_give_the_same_bits(tmx, oracle, monkeypatch, knobs):
     """Every tuning knob changes a schedule (window widths, table use, launch splitting, the first-generation kernel), never a value:
     a repeated-validator-set batch (tables, dummy lanes, a failing signature) is bit-exact vs the oracle under each of them."""
