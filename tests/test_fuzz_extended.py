@@ -1,0 +1,107 @@
+"""Extended differential fuzz of the HIP path against the oracle (opt-in depth: TMX_FUZZ_SEEDS=N, default 6 so that the suite stays short).
+Heavier than test_gpu_parity.py::test_random_shapes_and_bit_flips: whole bytes replaced by random and extreme values, field-aware
+extremes (lengths, powers, flags), duplicated keys across the two validator sets, several mutations per proof.  The verdicts are free to
+be anything; elements and reports must equal the oracle's bit for bit."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import _check_vs_oracle
+
+pytestmark = pytest.mark.gpu
+
+SEEDS = int(os.environ.get("TMX_FUZZ_SEEDS", "6"))
+EXTREME_BYTES = (0x00, 0x01, 0x7f, 0x80, 0xfe, 0xff)
+EXTREME_U64 = (0, 1, 2**62, 2**63 - 1, 2**63, 2**63 + 5, 2**64 - 1)
+
+
+def _pick(rng, seq):
+    return seq[int(rng.integers(0, len(seq)))]
+
+
+@pytest.fixture(scope="module")
+def tmx(built_lib):
+    import tendermintx_amd
+    return tendermintx_amd
+
+
+def _mutated_batch(seed):
+    from tendermintx_amd.synth import Workload
+    rng = np.random.default_rng(0x7E57 + 7919 * seed)
+    kind = int(rng.integers(0, 2))
+    n = _pick(rng, (1, 2, 4, 7, 16, 31, 32, 33, 64, 100, 128))
+    P = int(rng.integers(1, 24))
+    nb = int(rng.integers(1, n + 1))
+    wl = Workload(kind, n, P, nb, chain_id=b"celestia", seed=int(rng.integers(1, 2**31)), signed_permille=int(rng.integers(300, 1001)),
+                  rounds=(0, int(rng.integers(0, 7)), 0))
+    proofs, targets = bytearray(wl.proofs), bytearray(wl.targets)
+    trusteds = bytearray(wl.trusteds) if kind == 0 else None
+    for p in range(P):
+        if rng.random() < 0.25:
+            continue  # some proofs stay pristine
+        for _ in range(int(rng.integers(1, 7))):
+            mode = int(rng.integers(0, 10))
+            t0 = p * n * 256
+            lane = t0 + int(rng.integers(0, n)) * 256
+            if mode == 0:      # any byte of the proof record := random (the set sizes stay: nb > N is a host-side error, covered elsewhere)
+                off = int(rng.integers(0, 2336))
+                if off not in range(56, 64):
+                    proofs[p * 2336 + off] = int(rng.integers(0, 256))
+            elif mode == 1:    # ... := an extreme byte
+                off = int(rng.integers(0, 2336))
+                if off not in range(56, 64):
+                    proofs[p * 2336 + off] = _pick(rng, EXTREME_BYTES)
+            elif mode == 2:    # any byte of a target lane := random / extreme
+                targets[lane + int(rng.integers(0, 256))] = int(rng.integers(0, 256)) if rng.random() < 0.5 else _pick(rng, EXTREME_BYTES)
+            elif mode == 3:    # voting power extremes
+                targets[lane + 224:lane + 232] = struct.pack("<Q", _pick(rng, EXTREME_U64))
+            elif mode == 4:    # lengths and flags
+                which = int(rng.integers(0, 3))
+                if which == 0:
+                    targets[lane + 222] = _pick(rng, (0, 1, 33, 34, 45, 46, 47, 80, 255))
+                elif which == 1:
+                    targets[lane + 220:lane + 222] = struct.pack("<H", _pick(rng, (0, 1, 63, 64, 111, 112, 123, 124, 125, 300, 65535)))
+                else:
+                    targets[lane + 223] = int(rng.integers(0, 256))
+            elif mode == 5 and trusteds is not None:   # trusted lane: any byte, power extremes, a key copied from the target set
+                j = p * n * 48 + int(rng.integers(0, n)) * 48
+                which = int(rng.integers(0, 3))
+                if which == 0:
+                    trusteds[j + int(rng.integers(0, 48))] = int(rng.integers(0, 256))
+                elif which == 1:
+                    trusteds[j + 32:j + 40] = struct.pack("<Q", _pick(rng, EXTREME_U64))
+                else:
+                    trusteds[j:j + 32] = targets[lane:lane + 32]
+            elif mode == 6:    # a key duplicated inside the target set (and its signature, or not)
+                other = t0 + int(rng.integers(0, n)) * 256
+                targets[other:other + 32] = targets[lane:lane + 32]
+                if rng.random() < 0.5:
+                    targets[other + 32:other + 96] = targets[lane + 32:lane + 96]
+            elif mode == 7:    # signature bytes: the s half at and above the group order, R := small-order / non-canonical encodings
+                which = int(rng.integers(0, 4))
+                if which == 0:
+                    targets[lane + 64:lane + 96] = bytes([0xff] * 32)
+                elif which == 1:
+                    targets[lane + 64:lane + 96] = (2**252 + 27742317777372353535851937790883648493).to_bytes(32, "little")  # s = l
+                elif which == 2:
+                    targets[lane + 32:lane + 64] = bytes([1] + [0] * 31)   # R = the identity
+                else:
+                    targets[lane + 32:lane + 64] = bytes([0xed] + [0xff] * 30 + [0x7f])  # y = p (non-canonical zero)
+            elif mode == 8:    # public key: small order / non-canonical / not on the curve
+                keys = (bytes([1] + [0] * 31), bytes([0] * 32), bytes([0xec] + [0xff] * 30 + [0x7f]), bytes([0xee] + [0xff] * 30 + [0x7f]),
+                        bytes([2] + [0] * 31), bytes([0xff] * 32))
+                targets[lane:lane + 32] = keys[int(rng.integers(0, len(keys)))]
+            else:              # a run of bytes of the sign-bytes message zeroed or randomized
+                a = int(rng.integers(96, 220))
+                b = min(220, a + int(rng.integers(1, 24)))
+                targets[lane + a:lane + b] = bytes(b - a) if rng.random() < 0.5 else rng.integers(0, 256, b - a, dtype=np.uint8).tobytes()
+    assert len(targets) == len(wl.targets) and len(proofs) == len(wl.proofs)
+    return kind, n, bytes(proofs), bytes(targets), bytes(trusteds) if trusteds is not None else None
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_fuzz_bytes_and_field_extremes(tmx, oracle, seed):
+    kind, n, proofs, targets, trusteds = _mutated_batch(seed)
+    _check_vs_oracle(tmx, oracle, kind, n, proofs, targets, trusteds, b"celestia")
