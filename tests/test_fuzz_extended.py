@@ -1,4 +1,4 @@
-"""Extended differential fuzz of the HIP path against the oracle (opt-in depth: TMX_FUZZ_SEEDS=N, default 6 so that the suite stays short).
+"""Extended differential fuzz of the HIP path against the oracle (opt-in depth: TMX_FUZZ_SEEDS=N, default 64: a second and a half on the GPU box).
 Heavier than test_gpu_parity.py::test_random_shapes_and_bit_flips: whole bytes replaced by random and extreme values, field-aware
 extremes (lengths, powers, flags), duplicated keys across the two validator sets, several mutations per proof.  The verdicts are free to
 be anything; elements and reports must equal the oracle's bit for bit."""
@@ -12,7 +12,7 @@ from test_gpu_parity import _check_vs_oracle
 
 pytestmark = pytest.mark.gpu
 
-SEEDS = int(os.environ.get("TMX_FUZZ_SEEDS", "6"))
+SEEDS = int(os.environ.get("TMX_FUZZ_SEEDS", "64"))
 EXTREME_BYTES = (0x00, 0x01, 0x7f, 0x80, 0xfe, 0xff)
 EXTREME_U64 = (0, 1, 2**62, 2**63 - 1, 2**63, 2**63 + 5, 2**64 - 1)
 

@@ -360,6 +360,25 @@ def test_adversarial_mutations(tmx, oracle):
         assert reps[0]["all_ok"] and sum(1 for r in reps if not r["all_ok"]) >= P // 2
 
 
+@pytest.mark.parametrize("kind", [0, 1])
+def test_header_field_length_edges(tmx, oracle, kind):
+    """Every field-length byte of both headers set to 0, 1, 2, 33, 79, 80 and 255 (one proof per combination): empty and oversized
+    fields, among them the EMPTY height field whose re-encoded leaf `00 08 varint9` is then hashed over one byte only -- the kernel
+    hashed the 08 tag along (found by test_fuzz_extended.py, seed 1452; the oracle had it right)."""
+    from tendermintx_amd.synth import Workload
+    n, values = 8, (0, 1, 2, 33, 79, 80, 255)
+    P = 2 * 14 * len(values)
+    wl = Workload(kind, n, P, 7, chain_id=b"celestia", seed=4242 + kind, signed_permille=1000, rounds=(0, 2))
+    proofs = bytearray(wl.proofs)
+    p = 0
+    for hdr in range(2):
+        for field in range(14):
+            for v in values:
+                proofs[p * 2336 + 64 + hdr * 1136 + field] = v
+                p += 1
+    _check_vs_oracle(tmx, oracle, kind, n, bytes(proofs), wl.targets, wl.trusteds if kind == 0 else None, b"celestia")
+
+
 def test_threshold_edges(tmx, oracle):
     """exactly 2/3 is not enough (strict >, voting.rs:108); one more unit is"""
     from tendermintx_amd.synth import Workload
