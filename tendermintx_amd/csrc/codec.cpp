@@ -279,7 +279,7 @@ int32_t encode_header(const JVal* h, tmx_header_rec* out) {
   for (int i = 0; i < 14; i++) {
     if (leaves[i].size() > 79) return TMX_ERR_PARSE;
     out->leaf_len[i] = (uint8_t)leaves[i].size();
-    std::memcpy(out->leaf[i], leaves[i].data(), leaves[i].size());
+    if (!leaves[i].empty()) std::memcpy(out->leaf[i], leaves[i].data(), leaves[i].size());  // (an empty vector's data() may be null)
   }
   return TMX_OK;
 }
