@@ -13,6 +13,9 @@ from test_gpu_parity import _check_vs_oracle
 pytestmark = pytest.mark.gpu
 
 SEEDS = int(os.environ.get("TMX_FUZZ_SEEDS", "64"))
+NSET = tuple(int(v) for v in os.environ.get("TMX_FUZZ_NSET", "1,2,4,7,16,31,32,33,64,100,128").split(","))   # e.g. 200,256,300,512: the wide k_proof
+CHAIN_IDS = (b"celestia", b"mocha-4", b"a", b"thirteen-char")          # what the synthetic sign-bytes can carry
+CTX_CHAIN_IDS = CHAIN_IDS + (b"x" * 50, b"celestia-but-longer")              # what a context can be configured for
 EXTREME_BYTES = (0x00, 0x01, 0x7f, 0x80, 0xfe, 0xff)
 EXTREME_U64 = (0, 1, 2**62, 2**63 - 1, 2**63, 2**63 + 5, 2**64 - 1)
 
@@ -31,10 +34,13 @@ def _mutated_batch(seed):
     from tendermintx_amd.synth import Workload
     rng = np.random.default_rng(0x7E57 + 7919 * seed)
     kind = int(rng.integers(0, 2))
-    n = _pick(rng, (1, 2, 4, 7, 16, 31, 32, 33, 64, 100, 128))
+    n = _pick(rng, NSET)
     P = int(rng.integers(1, 24))
     nb = int(rng.integers(1, n + 1))
-    wl = Workload(kind, n, P, nb, chain_id=b"celestia", seed=int(rng.integers(1, 2**31)), signed_permille=int(rng.integers(300, 1001)),
+    wl_chain = _pick(rng, CHAIN_IDS)
+    ctx_chain = wl_chain if rng.random() < 0.8 else _pick(rng, CTX_CHAIN_IDS)   # (a context configured for another chain: checks fail, parity holds)
+    skip_max = _pick(rng, (1, 2, 1000, 100800, 2**40))
+    wl = Workload(kind, n, P, nb, chain_id=wl_chain, seed=int(rng.integers(1, 2**31)), signed_permille=int(rng.integers(300, 1001)),
                   rounds=(0, int(rng.integers(0, 7)), 0))
     proofs, targets = bytearray(wl.proofs), bytearray(wl.targets)
     trusteds = bytearray(wl.trusteds) if kind == 0 else None
@@ -98,10 +104,10 @@ def _mutated_batch(seed):
                 b = min(220, a + int(rng.integers(1, 24)))
                 targets[lane + a:lane + b] = bytes(b - a) if rng.random() < 0.5 else rng.integers(0, 256, b - a, dtype=np.uint8).tobytes()
     assert len(targets) == len(wl.targets) and len(proofs) == len(wl.proofs)
-    return kind, n, bytes(proofs), bytes(targets), bytes(trusteds) if trusteds is not None else None
+    return kind, n, bytes(proofs), bytes(targets), bytes(trusteds) if trusteds is not None else None, ctx_chain, skip_max
 
 
 @pytest.mark.parametrize("seed", range(SEEDS))
 def test_fuzz_bytes_and_field_extremes(tmx, oracle, seed):
-    kind, n, proofs, targets, trusteds = _mutated_batch(seed)
-    _check_vs_oracle(tmx, oracle, kind, n, proofs, targets, trusteds, b"celestia")
+    kind, n, proofs, targets, trusteds, chain_id, skip_max = _mutated_batch(seed)
+    _check_vs_oracle(tmx, oracle, kind, n, proofs, targets, trusteds, chain_id, skip_max)
