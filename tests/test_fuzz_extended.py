@@ -111,3 +111,26 @@ def _mutated_batch(seed):
 def test_fuzz_bytes_and_field_extremes(tmx, oracle, seed):
     kind, n, proofs, targets, trusteds, chain_id, skip_max = _mutated_batch(seed)
     _check_vs_oracle(tmx, oracle, kind, n, proofs, targets, trusteds, chain_id, skip_max)
+
+
+TRACE_SEEDS = int(os.environ.get("TMX_FUZZ_TRACE_SEEDS", "4"))
+
+
+@pytest.mark.parametrize("seed", range(TRACE_SEEDS))
+def test_fuzz_trace_rows(tmx, oracle, seed):
+    """The Level-2 rows of mutated batches (undecodable and small-order keys, non-canonical scalars, duplicated keys ...): bit-exact vs the
+    oracle's generator and accepted by its constraint checker."""
+    from test_trace import _gpu_trace
+    for s in range(1000 * seed, 1000 * seed + 40):   # the first batch of this seed's range that is small enough for the generator
+        kind, n, proofs, targets, trusteds, _, _ = _mutated_batch(s)
+        P = len(proofs) // 2336
+        if n <= 16 and P <= 8:
+            break
+    else:
+        pytest.skip("no small batch in this seed range")
+    got = _gpu_trace(tmx, kind, n, proofs, targets, trusteds)
+    for p in range(P):
+        t = targets[p * n * 256:(p + 1) * n * 256]
+        r = trusteds[p * n * 48:(p + 1) * n * 48] if kind == 0 else None
+        assert np.array_equal(got[p], oracle.trace(kind, t, r, n)), (s, p)
+        assert oracle.trace_check(kind, t, r, n, got[p]) == 0, (s, p)
