@@ -108,6 +108,25 @@ def test_ntt_noncanonical_and_extreme_inputs(env, log_n, cols, fill):
         assert np.array_equal(_to_host(out), oc.ntt(x, inverse=inverse)), (fill, inverse)
 
 
+@pytest.mark.parametrize("log_n", range(0, 19))
+def test_ntt_every_size_and_odd_column_counts(env, log_n):
+    """Every transform size up to 2^18 with 1, 2, 3, 5 and 17 columns: every instantiation of the tile kernel (sub-transform lengths 2^0 ..
+    2^11, the fixed tile shapes and the generic one that few columns fall back to, partially filled tiles), forward and inverse."""
+    torch, ctx, oc = env
+    s = torch.cuda.current_stream().cuda_stream
+    for cols in (1, 2, 3, 5, 17):
+        if log_n >= 17 and cols > 3:
+            continue
+        rng = np.random.default_rng(31 * log_n + cols)
+        x = _rand(rng, (cols, 1 << log_n))
+        d = _to_dev(torch, x)
+        out = torch.empty_like(d)
+        for inverse in (False, True):
+            ctx.ntt_device(log_n, cols, d.data_ptr(), out.data_ptr(), inverse, s)
+            torch.cuda.synchronize()
+            assert np.array_equal(_to_host(out), oc.ntt(x, inverse=inverse)), (log_n, cols, inverse)
+
+
 @pytest.mark.parametrize("log_n,log_blowup,cols", [(0, 1, 2), (3, 3, 3), (8, 2, 5), (10, 3, 2), (12, 1, 3), (13, 3, 1)])
 def test_lde_matches_oracle(env, log_n, log_blowup, cols):
     torch, ctx, oc = env
