@@ -116,6 +116,10 @@ def verify_trace(pk32, sig64, msg):
     R = decompress(r32)
     out = dict(digest=dig, h=h, s=s, A=A, R=R, sB=None, hA=None, sum=None, ok=False)
     if A is None or R is None:
+        # one convention for the whole lane (oracle/c tmxo_eddsa_trace_lane, the kernels): if either point does not decode, NO point of
+        # the lane is reported (all zero), not even the one that did decode.  (Found by the C-vs-model fuzz, round 2: this model used to
+        # keep the decodable one.)
+        out.update(A=None, R=None)
         return out
     sB = scalarmult(s, B)
     hA = scalarmult(h, A)

@@ -62,9 +62,17 @@ def pack_header(leaves):
     return bytes(len(l) for l in leaves) + b"\0\0" + b"".join(l.ljust(80, b"\0") for l in leaves)
 
 
+class _Leaves(list):
+    raw_len = None
+
+
 def unpack_header(rec):
     lens = rec[:14]
-    return [rec[16 + 80 * i: 16 + 80 * i + lens[i]] for i in range(14)]
+    # (a length byte above 79 is clamped -- the record carries 80 bytes per field, 79 is the longest leaf a two-block SHA-256 of
+    # 00 | leaf can take; same rule as oracle/c and the kernels.  Found by tests/test_oracle_cross_fuzz.py: this model read on into the next field)
+    leaves = _Leaves(rec[16 + 80 * i: 16 + 80 * i + min(lens[i], 79)] for i in range(14))
+    leaves.raw_len = list(lens)   # the length bytes as given: the hint elements carry them unclamped (as oracle/c and the kernels do)
+    return leaves
 
 
 def pack_proof(block_a, block_b, hash32, round_, nb_a, nb_b, header_a, header_b):
@@ -315,11 +323,11 @@ def _emit_hash_proof_h(E, aunts, leaf, leaf_size):
 def _emit_chain_height_h(E, leaves, proofs, height_value):
     for a in proofs[1]:
         E.bytes(a)
-    E.u32(len(leaves[1]))
+    E.u32(leaves.raw_len[1] if getattr(leaves, "raw_len", None) else len(leaves[1]))
     E.bytes(leaves[1][:CHAIN_ID_PB_MAX].ljust(CHAIN_ID_PB_MAX, b"\0"))
     for a in proofs[2]:
         E.bytes(a)
-    E.u32(len(leaves[2]))
+    E.u32(leaves.raw_len[2] if getattr(leaves, "raw_len", None) else len(leaves[2]))
     E.u64(height_value)
 
 
