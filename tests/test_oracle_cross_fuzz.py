@@ -20,7 +20,7 @@ def test_c_oracle_equals_python_model_on_mutated_batches(oracle, monkeypatch):
         stub._check_vs_oracle = None
         monkeypatch.setitem(sys.modules, "test_gpu_parity", stub)
     fz = importlib.import_module("test_fuzz_extended")
-    monkeypatch.setattr(fz, "NSET", (1, 2, 4))
+    monkeypatch.setattr(fz, "NSET", tuple(int(v) for v in os.environ.get("TMX_CROSS_NSET", "1,2,4").split(",")))
     checked = 0
     for seed in range(N_SEEDS):
         kind, n, proofs, targets, trusteds, chain, skip_max = fz._mutated_batch(seed)
