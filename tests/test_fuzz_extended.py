@@ -134,3 +134,55 @@ def test_fuzz_trace_rows(tmx, oracle, seed):
         r = trusteds[p * n * 48:(p + 1) * n * 48] if kind == 0 else None
         assert np.array_equal(got[p], oracle.trace(kind, t, r, n)), (s, p)
         assert oracle.trace_check(kind, t, r, n, got[p]) == 0, (s, p)
+
+
+def test_one_context_many_different_calls(tmx, oracle):
+    """State carried between calls of ONE context (hash-table parity, cleared-table event, tiny-launch path vs per-key tables, scratch buffers,
+    the events of the stream schedule): 80 calls of random kind, batch size (1 .. 96 proofs: both sides of every size threshold), mutation
+    and entry point -- host rows, hint-only u32 rows, device rows on two alternating streams -- each checked against the oracle."""
+    import torch
+    from tendermintx_amd import _lib
+    n = 64
+    rng = np.random.default_rng(77)
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    with tmx.Context(n, b"celestia", 100800, max_batch=96) as ctx:
+        sizes = set()
+        for it in range(80):
+            s0 = int(rng.integers(0, 20000))
+            saved = NSET
+            try:   # up to four mutated batches of one kind glued together: 1 .. 92 proofs = 64 .. 5888 lanes
+                globals()["NSET"] = (n,)
+                kind, _, proofs, targets, trusteds, _, _ = _mutated_batch(s0)
+                for extra in range(int(rng.integers(0, 4))):
+                    for s1 in range(s0 + 1 + 50 * extra, s0 + 50 * (extra + 1)):
+                        k2, _, p2, t2, r2, _, _ = _mutated_batch(s1)
+                        if k2 == kind:
+                            proofs, targets = proofs + p2, targets + t2
+                            trusteds = trusteds + r2 if trusteds is not None else None
+                            break
+            finally:
+                globals()["NSET"] = saved
+            P = len(proofs) // 2336
+            sizes.add(P)
+            want, oreps = oracle.witness_batch(kind, P, proofs, targets, trusteds, n, b"celestia", 100800, n_threads=8)
+            mode = int(rng.integers(0, 3))
+            if mode == 0:
+                elems, reps = ctx.witness_batch(kind, proofs, targets, trusteds)
+                assert np.array_equal(elems, want) and reps == oreps, (it, s0)
+            elif mode == 1:
+                rows, reps = ctx.witness_batch_hint(kind, proofs, targets, trusteds)
+                h = ctx.hint_elem_count(kind)
+                assert np.array_equal(rows.astype(np.uint64), want[:, :h]) and reps == oreps, (it, s0)
+            else:
+                st = streams[it & 1]
+                d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) if b else None for b in (proofs, targets, trusteds)]
+                out = torch.zeros((P, ctx.elem_stride(kind)), dtype=torch.int64, device=dev)
+                rep = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize(dev)   # (calls of one context on different streams must be ordered by the caller: include/tmx.h)
+                ctx.witness_batch_device(kind, P, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr() if d[2] is not None else None,
+                                         out.data_ptr(), rep.data_ptr(), st.cuda_stream)
+                st.synchronize()
+                got = out.cpu().numpy().view(np.uint64)[:, :want.shape[1]]
+                assert np.array_equal(got, want), (it, s0)
+        assert min(sizes) <= 8 and max(sizes) >= 64   # (both the tiny-launch path and the split tail were on)
