@@ -186,3 +186,26 @@ def test_one_context_many_different_calls(tmx, oracle):
                 got = out.cpu().numpy().view(np.uint64)[:, :want.shape[1]]
                 assert np.array_equal(got, want), (it, s0)
         assert min(sizes) <= 8 and max(sizes) >= 64   # (both the tiny-launch path and the split tail were on)
+
+
+@pytest.mark.parametrize("n_proofs", [int(os.environ.get("TMX_FUZZ_BIG", "300"))])
+def test_big_mutated_batch(tmx, oracle, n_proofs):
+    """Mutated proofs at N = 128 glued into one large batch: the size-dependent schedules (walk in parts, tail aside, leaves first, the
+    split tail and the larger serializer cap from 131 072 lanes: TMX_FUZZ_BIG=1100) see hostile inputs too."""
+    n = 128
+    saved = NSET
+    try:
+        globals()["NSET"] = (n,)
+        kind0, parts = 0, []
+        s = 0
+        while sum(len(p[0]) // 2336 for p in parts) < n_proofs:
+            kind, _, proofs, targets, trusteds, _, _ = _mutated_batch(50000 + s)
+            s += 1
+            if kind == kind0:
+                parts.append((proofs, targets, trusteds))
+    finally:
+        globals()["NSET"] = saved
+    proofs = b"".join(p[0] for p in parts)[:n_proofs * 2336]
+    targets = b"".join(p[1] for p in parts)[:n_proofs * n * 256]
+    trusteds = b"".join(p[2] for p in parts)[:n_proofs * n * 48]
+    _check_vs_oracle(tmx, oracle, kind0, n, proofs, targets, trusteds, b"celestia", threads=16)
