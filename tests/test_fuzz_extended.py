@@ -107,7 +107,10 @@ def _mutated_batch(seed):
     return kind, n, bytes(proofs), bytes(targets), bytes(trusteds) if trusteds is not None else None, ctx_chain, skip_max
 
 
-@pytest.mark.parametrize("seed", range(SEEDS))
+SEED0 = int(os.environ.get("TMX_FUZZ_SEED0", "0"))
+
+
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + SEEDS))
 def test_fuzz_bytes_and_field_extremes(tmx, oracle, seed):
     kind, n, proofs, targets, trusteds, chain_id, skip_max = _mutated_batch(seed)
     _check_vs_oracle(tmx, oracle, kind, n, proofs, targets, trusteds, chain_id, skip_max)
