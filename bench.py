@@ -385,7 +385,7 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
         if pmc["config"] == {"n_max": n, "proofs_per_gpu": P, "workload": args.workload}:
-            pk = pmc["kernels"]
+            pk = {g: v for g, v in pmc["kernels"].items() if g != "setup"}   # (setup = the once-per-context table of B)
             roofline["traffic"] = int(sum(pk[g].get("fetch_kb", 0) + pk[g].get("write_kb", 0) for g in pk) * 1024)
             roofline["k_serialize"]["traffic"] = int((pk["k_serialize"]["fetch_kb"] + pk["k_serialize"]["write_kb"]) * 1024)
 

@@ -18,6 +18,8 @@ def group(name):
         return "k_proof"
     if "k_verdict" in name:
         return "k_verdict"
+    if "k_init_base" in name:
+        return "setup"  # built once per context (the table of B): not part of a batch
     if "tmx::" in name:
         return "k_eddsa"
     return None
@@ -27,6 +29,8 @@ res = {"source": f"tools/collect_profiles.sh: rocprofv3 --pmc passes (separate r
        "config": {"n_max": int(os.environ.get("N", "128")), "proofs_per_gpu": int(os.environ.get("P", "256")), "workload": os.environ.get("WORKLOAD", "survey8d")},
        "unit_note": "fetch_kb / write_kb: FETCH_SIZE / WRITE_SIZE (KB) per batch, uncorrected (MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by 2x; "
                     "the reads here are mostly 1- and 4-byte accesses).  valu_insts / salu_insts: wave-level instructions per batch.",
+       "setup_note": "`setup` = k_init_base / k_init_base_quad: run once per context, listed per profiled run / batches, NOT part of a batch's k_eddsa sum "
+                     "(until r02d these 9e6 instructions per profiled batch were counted into k_eddsa)",
        "kernels": {}, "per_kernel": {}}
 for db_path in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*.db"), recursive=True)):
     db = sqlite3.connect(db_path)
