@@ -566,7 +566,7 @@ def test_validator_sharded_single_proof(tmx, oracle):
 
 
 @pytest.mark.parametrize("knobs", [
-    {"TMX_BASE_W": "4"}, {"TMX_BASE_W": "8"}, {"TMX_BASE_W": "10"}, {"TMX_MUL_SPLIT": "1"}, {"TMX_MUL_SPLIT": "4"}, {"TMX_TINY": "0"}, {"TMX_FUSE_FIN": "0"}, {"TMX_KEY_W": "4"}, {"TMX_KEY_W": "4", "TMX_MUL_SPLIT": "1"}, {"TMX_WALK_PARTS": "1"}, {"TMX_WALK_PARTS": "1", "TMX_TAB_PARTS": "4"},
+    {"TMX_BASE_W": "4"}, {"TMX_BASE_W": "8"}, {"TMX_BASE_W": "10"}, {"TMX_MUL_SPLIT": "1"}, {"TMX_MUL_SPLIT": "2"}, {"TMX_MUL_SPLIT": "4"}, {"TMX_TINY": "0"}, {"TMX_FUSE_FIN": "0"}, {"TMX_KEY_W": "4"}, {"TMX_KEY_W": "4", "TMX_MUL_SPLIT": "1"}, {"TMX_WALK_PARTS": "1"}, {"TMX_WALK_PARTS": "1", "TMX_TAB_PARTS": "4"},
     {"TMX_TAB_PARTS": "1"}, {"TMX_PROOFSER_HOLD": "1"}, {"TMX_EXT_EVENTS": "0"}, {"TMX_ANCHOR16": "0"}, {"TMX_KEYS16": "0"}, {"TMX_MUL16": "0"},
     {"TMX_P1_SIDE": "1"}, {"TMX_P1_SIDE": "2"}, {"TMX_DEDUP": "0"}, {"TMX_DEDUP": "2"},
     {"TMX_LEAVES": "1"}, {"TMX_LEAVES": "0", "TMX_P1_EARLY": "1"}, {"TMX_LEAVES": "1", "TMX_SER_SPLIT": "0"},
