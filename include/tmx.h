@@ -197,9 +197,28 @@ int32_t tmx_last_kernel_ms(tmx_ctx* ctx, float ms[TMX_N_KERNELS]);
  * a whole region without synchronising inside it */
 int32_t tmx_kernel_ms_mean(tmx_ctx* ctx, uint32_t last_k, float ms[TMX_N_KERNELS]);
 int32_t tmx_sync(tmx_ctx* ctx);
-/* EdDSA stage bookkeeping of the last launch: number of distinct (effective) public keys among its lanes and whether h*A used the
- * per-key fixed-base tables (>= 8 lanes per key on average; TMX_DEDUP=0|1|2 forces never / automatic / always).  Blocks. */
+/* EdDSA stage bookkeeping of the last launch: number of distinct (effective) public keys among its lanes and whether h*A of any lane
+ * walked a per-key table (a key resident in the key cache, or a new key with >= 8 lanes per key on average; TMX_DEDUP=0|1|2 forces
+ * never / automatic / whenever a table fits).  Blocks. */
 int32_t tmx_last_dedup(tmx_ctx* ctx, uint32_t* n_unique, uint32_t* used_tables);
+
+/* ---- persistent per-key table cache.  h*A of a lane is 43 additions from a 215-KB window table of its public key instead of 252
+ * doublings + 64 additions; the context keeps those tables in a content-addressed cache in HBM (key = the 32 public-key bytes, all 32
+ * compared on a hit), so that a validator set that was seen by an earlier call -- a light client re-verifies the same, slowly changing set
+ * for days (reference bin/tendermintx.rs:171) -- skips the decode -> doubling chain -> table build entirely.  New keys are inserted by the
+ * call that first sees them (a single-proof call builds their tables off its critical path, for the next call); when the cache runs full
+ * the least recently used keys are evicted.  Exact group arithmetic on every path: the witness is bit-identical with the cache on, off,
+ * cold or warm.  Default capacity: 1024 .. 16384 keys by max_batch * n_max (TMX_KEY_CACHE_KEYS overrides; TMX_KEY_CACHE=0 disables).
+ * All three calls block until the context's work in flight is done. */
+typedef struct {
+  uint32_t capacity_keys, resident_keys, enabled, epoch;
+  uint64_t bytes_per_key;
+  uint32_t last_new_keys, last_hit_keys, last_hit_lanes, last_built_keys; /* the last EdDSA launch */
+  uint64_t hit_lanes, miss_lanes, built_keys, evicted_keys, evictions, launches; /* since the cache was created / flushed */
+} tmx_key_cache_info;
+int32_t tmx_key_cache_stats(tmx_ctx* ctx, tmx_key_cache_info* out);
+int32_t tmx_key_cache_flush(tmx_ctx* ctx);                                      /* forget every key */
+int32_t tmx_key_cache_config(tmx_ctx* ctx, uint32_t enabled, uint32_t max_keys); /* max_keys = 0 keeps the capacity; a new capacity flushes */
 
 /* ---- Level-2 trace rows (SURVEY 8a "Level-2", 8f rank 2): the row-level execution trace behind the Level-1 values -- what the reference
  * produces inside Curta's trace generators for `curta_eddsa_verify_sigs_conditional` (reference circuits/builder/verify.rs:248-259) and

@@ -41,12 +41,22 @@ class ProofRec(C.Structure):
 class Report(C.Structure):
     _fields_ = [("header", C.c_uint8 * 32), ("all_ok", C.c_uint32), ("fail_mask", C.c_uint32),
                 ("first_bad_sig", C.c_int32), ("gt_target", C.c_uint32), ("gt_trusted", C.c_uint32),
-                ("dist_ok", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+                ("dist_ok", C.c_uint32), ("precond", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return dict(header=bytes(self.header), all_ok=bool(self.all_ok), fail_mask=self.fail_mask,
                     first_bad_sig=self.first_bad_sig, gt_target=bool(self.gt_target),
-                    gt_trusted=bool(self.gt_trusted), dist_ok=bool(self.dist_ok), precond=int(self.reserved[0]))
+                    gt_trusted=bool(self.gt_trusted), dist_ok=bool(self.dist_ok), precond=int(self.precond))
+
+
+class KeyCacheInfo(C.Structure):
+    _fields_ = [("capacity_keys", C.c_uint32), ("resident_keys", C.c_uint32), ("enabled", C.c_uint32), ("epoch", C.c_uint32),
+                ("bytes_per_key", C.c_uint64), ("last_new_keys", C.c_uint32), ("last_hit_keys", C.c_uint32),
+                ("last_hit_lanes", C.c_uint32), ("last_built_keys", C.c_uint32), ("hit_lanes", C.c_uint64), ("miss_lanes", C.c_uint64),
+                ("built_keys", C.c_uint64), ("evicted_keys", C.c_uint64), ("evictions", C.c_uint64), ("launches", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
 class AddrRec(C.Structure):
@@ -149,6 +159,9 @@ def lib():
     L.tmx_ctx_stream.argtypes = [C.c_void_p]
     L.tmx_sync.argtypes = [C.c_void_p]
     L.tmx_last_dedup.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.tmx_key_cache_stats.argtypes = [C.c_void_p, C.POINTER(KeyCacheInfo)]
+    L.tmx_key_cache_flush.argtypes = [C.c_void_p]
+    L.tmx_key_cache_config.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     L.tmx_eddsa_lanes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.tmx_skip_inputs_from_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64,
                                             C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]

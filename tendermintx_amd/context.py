@@ -198,5 +198,18 @@ class Context:
         check(self._L.tmx_last_dedup(self._h, C.byref(u), C.byref(t)), self._h)
         return int(u.value), bool(t.value)
 
+    # ---- persistent per-key table cache (tmx_key_cache_*)
+    def key_cache_stats(self):
+        info = _lib.KeyCacheInfo()
+        check(self._L.tmx_key_cache_stats(self._h, C.byref(info)), self._h)
+        return info.as_dict()
+
+    def key_cache_flush(self):
+        check(self._L.tmx_key_cache_flush(self._h), self._h)
+
+    def key_cache_config(self, enabled=True, max_keys=0):
+        """enabled=False: tables do not survive a call (every call cold); max_keys != 0: new capacity (flushes)."""
+        check(self._L.tmx_key_cache_config(self._h, 1 if enabled else 0, int(max_keys)), self._h)
+
     def sync(self):
         check(self._L.tmx_sync(self._h), self._h)

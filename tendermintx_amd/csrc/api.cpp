@@ -208,8 +208,7 @@ Program build_program(int kind, uint32_t n) {
   P.sp.n = n;
   P.sp.tree_nodes = tn;
   P.lut = std::move(L.v);
-  const char* sp_env = std::getenv("TMX_SER_SPAN");  // tuning knob; 256 measured best on MI355X
-  const uint32_t span = sp_env && (std::atoi(sp_env) == 128 || std::atoi(sp_env) == 512) ? (uint32_t)std::atoi(sp_env) : 256u;
+  const uint32_t span = 256;  // elements per wave: 128 and 512 measured slower on MI355X (tools/ser_span_ab.py, round 1)
   P.sp.span = span;
   for (uint32_t w = 0; w * span < P.sp.elem_stride; w++) {
     const uint32_t first = w * span, last = first + span - 1;
@@ -229,8 +228,38 @@ Program build_program(int kind, uint32_t n) {
 
 // ------------------------------------------------------------------------------------------------ context
 constexpr int EV_RING_DECL = 128;
+// Schedule knobs, read ONCE at context creation (getenv is not safe against a concurrent setenv, and the enqueue path is
+// latency-critical).  Each selects a schedule, never a value (tests/test_gpu_parity.py::test_schedule_knobs_give_the_same_bits); the A/B
+// harness that measured the alternatives no longer in the product lives in tools/ (DESIGN.md appendix "measured and dropped").
+struct Knobs {
+  uint32_t dedup_mode = 1;   // TMX_DEDUP=0|1|2: never use per-key tables / automatic / whenever they fit
+  bool key_cache = true;     // TMX_KEY_CACHE=0: the per-key tables do not survive a call (every call cold)
+  uint32_t key_cache_keys = 0;  // TMX_KEY_CACHE_KEYS: capacity of the cache in keys (0: by max_batch * n_max)
+  bool ser_split = true;     // TMX_SER_SPLIT=0: one k_serialize launch at the end of the step (times the kernel on its own)
+  int leaves = -1;           // TMX_LEAVES=0|1: leaf hashes as a launch of their own in front of k_proof (default: from 131072 lanes)
+  int p1_early = -1;         // TMX_P1_EARLY=0|1: D.1a behind k_proof's sections instead of behind k_ed_fin (default: from 131072 lanes)
+  int walk_parts = -1;       // TMX_WALK_PARTS=0|1: the table walk follows the table build part by part (default: from 65536 lanes)
+  uint32_t tab_parts = 2;    // TMX_TAB_PARTS=1|2|4: launches the anchor chain of new keys is cut into
+  bool ext_events = true;    // TMX_EXT_EVENTS=0: record packets instead of completion signals on the chain kernels
+};
+static Knobs read_knobs() {
+  Knobs k;
+  const char* v;
+  if ((v = std::getenv("TMX_DEDUP")) && v[0] >= '0' && v[0] <= '2') k.dedup_mode = (uint32_t)(v[0] - '0');
+  k.key_cache = !((v = std::getenv("TMX_KEY_CACHE")) && v[0] == '0');
+  if ((v = std::getenv("TMX_KEY_CACHE_KEYS")) && std::atoll(v) > 0) k.key_cache_keys = (uint32_t)std::min<long long>(std::atoll(v), 1 << 20);
+  k.ser_split = !((v = std::getenv("TMX_SER_SPLIT")) && v[0] == '0');
+  k.leaves = (v = std::getenv("TMX_LEAVES")) ? (v[0] != '0' ? 1 : 0) : -1;
+  k.p1_early = (v = std::getenv("TMX_P1_EARLY")) ? (v[0] != '0' ? 1 : 0) : -1;
+  k.walk_parts = (v = std::getenv("TMX_WALK_PARTS")) ? (v[0] == '1' ? 1 : 0) : -1;
+  if ((v = std::getenv("TMX_TAB_PARTS")) && (std::atoi(v) == 1 || std::atoi(v) == 2 || std::atoi(v) == 4)) k.tab_parts = (uint32_t)std::atoi(v);
+  k.ext_events = !((v = std::getenv("TMX_EXT_EVENTS")) && v[0] == '0');
+  return k;
+}
+
 struct tmx_ctx {
   tmx_config cfg;
+  Knobs knobs;
   std::string err;
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;  // k_proof runs here, concurrently with the EdDSA kernels of the caller's stream
@@ -238,14 +267,11 @@ struct tmx_ctx {
   hipEvent_t ev_side[EV_RING_DECL][4] = {};
   hipEvent_t ev_hash = nullptr;  // phase 1 is done: the SHA-512 digest and h of every lane are in the lane records
   bool ev_hash_recorded = false;
-  int k_p1_early = -1;  // TMX_P1_EARLY: 1 / 0, default by batch size
-  int k_leaves = -1;    // TMX_LEAVES: 1 / 0, default by batch size
   hipEvent_t ev_leaves = nullptr;
-  hipEvent_t ev_p1 = nullptr, ev_tail = nullptr, ev_fork2 = nullptr, ev_hash_clean = nullptr, ev_keys = nullptr, ev_mul = nullptr;
-  bool ev_mul_recorded = false, want_ev_mul = false, fin_done_attached = false, ext_events = true;
+  hipEvent_t ev_tail = nullptr, ev_fork2 = nullptr, ev_hash_clean = nullptr, ev_keys = nullptr;
+  bool fin_done_attached = false;
   void* fin_done = nullptr;  // set by run_batch around the EdDSA producer: the event k_ed_fin signals
   hipEvent_t ev_part[4] = {};
-  uint32_t tab_parts = 2;  // TMX_TAB_PARTS=1|2|4
   bool have_streams = false;
   // ring of HIP-event sets: one set (TMX_N_KERNELS + 1 events) per enqueued batch, so that kernel durations can be
   // averaged over a whole timed region afterwards without synchronising inside it
@@ -255,26 +281,25 @@ struct tmx_ctx {
   hipStream_t last_stream = nullptr;  // stream and end event of the previous batch (cross-stream callers are ordered behind it)
   bool last_stream_valid = false;
   hipEvent_t ev_done = nullptr;
+  int32_t last_kind = -1;       // kind and size of the last Level-1 batch (tmx_trace_rows_device reads its lane records)
+  uint32_t last_n_proofs = 0;
   Program prog[2];
   void* d_lut[2] = {nullptr, nullptr};
   void* d_wave_sec[2] = {nullptr, nullptr};
   void* d_seams[2] = {nullptr, nullptr};
   void* d_table = nullptr;
-  uint32_t base_w = 10, key_w = 6;
   void *d_qtable = nullptr, *d_pre = nullptr, *d_mulout = nullptr;
-  void *d_hash = nullptr, *d_cnt = nullptr, *d_owner_of = nullptr, *d_uid_of_owner = nullptr, *d_owners = nullptr, *d_keyrec = nullptr,
-       *d_anchors = nullptr, *d_keytab = nullptr;
-  uint32_t anchor16 = 1, keys16 = 1, mul16 = 1;
-  bool last_tiny = false;
-  uint32_t p1_side = 3;
-  uint32_t hash_mask = 0, key_cap = 0, dedup_mode = 1;  // TMX_DEDUP=0|1|2: never / automatic / always build per-key tables
-  hipStream_t side2 = nullptr;  // distinct-key pipeline, concurrent with phase 1
+  // EdDSA stage: the launch's own dedup structures, the key records (cache slots, then one per lane for keys without a slot), the
+  // anchor scratch of the tables being built, and the persistent key cache
+  void *d_hash = nullptr, *d_cnt = nullptr, *d_owner_of = nullptr, *d_slot_of_owner = nullptr, *d_slot_of_uid = nullptr, *d_owners = nullptr,
+       *d_keyrec = nullptr, *d_anchors = nullptr, *d_keytab = nullptr;
+  KeyCache kc = {};
+  uint32_t hash_mask = 0;
+  hipStream_t side2 = nullptr;  // new-key pipeline, concurrent with phase 1
   hipStream_t side3 = nullptr;  // early serialization of the input-only sections
   hipEvent_t ev_join3 = nullptr;
-  uint32_t parity = 0;  // which of the two key counters this launch uses
+  uint32_t parity = 0;  // which of the two counter sets this launch uses
   uint64_t last_lanes = 0;
-  bool ser_split = true;  // TMX_SER_SPLIT=0: one k_serialize launch at the end (used to time the kernel on its own)
-  bool quad = true;  // TMX_EDDSA=mono selects the first-generation one-lane-per-thread kernel (kept for A/B runs)
   // scratch sized for cfg.max_batch proofs
   void *d_ed = nullptr, *d_tl = nullptr, *d_lr = nullptr, *d_pf = nullptr, *d_nodes_t = nullptr, *d_nodes_r = nullptr, *d_reports = nullptr;
   // staging for the host-buffer entry points
@@ -285,19 +310,6 @@ struct tmx_ctx {
   void* d_pack = nullptr;  // dense / narrowed rows for tmx_witness_batch_opts (allocated on first use)
   uint64_t d_pack_bytes = 0;
   uint32_t sections = 3;  // TMX_SEC_* of the batch being enqueued
-  // schedule knobs of the enqueue path, read ONCE at context creation (getenv is not safe against a concurrent setenv, and the enqueue
-  // path is latency-critical): TMX_INPUTS_ON, TMX_PROOFSER_HOLD, TMX_EXT_EVENTS, TMX_TINY, TMX_FUSE_FIN (-1 = by size), TMX_WALK_PARTS (-1 = by size)
-  bool k_inputs_side2 = false, k_proofser_hold = false, k_ext_events = true, k_tiny = true;
-  int k_fuse_fin = -1, k_walk_parts = -1;
-  uint32_t k_mul_split = 0;
-  bool k_no_wide = false;
-  uint32_t k_proof_threads = 0;
-  int k_tail_split = -1;  // TMX_TAIL_SPLIT: 1 / 0, default by batch size
-  uint32_t split_req = 0, split_lane = 0;  // run_batch asks (split_req), run_eddsa answers: != 0: the lanes [0, split_lane) were finished on side3 (ev_fin_a)
-  hipEvent_t ev_half = nullptr, ev_fin_a = nullptr;
-  int32_t k_ser_in_wgs = -1;  // TMX_SER_IN_WGS: workgroups of the serializer launches that run beside the EdDSA chain (0: one per four spans; default by size)
-  uint32_t k_ser_wgs = 0;     // TMX_SER_WGS: the same for every other serializer launch
-  uint32_t k_ntt_tile_log = 0;  // TMX_NTT_TILE_LOG (0: by sub-transform length)
   // Goldilocks NTT: twiddle tables per transform size (built on first use), scratch for the four-step split / LDE
   void* d_ntt_w[TMX_NTT_MAX_LOG + 1] = {};
   void* d_ntt_m[2][TMX_NTT_MAX_LOG + 1] = {};  // four-step twiddle matrices omega_N^(+- n2 k1) (forward, inverse), built on first use
@@ -324,21 +336,21 @@ static ProofParams proof_params(const tmx_ctx* c, int32_t kind, bool leaves_done
   P.leaves_done = leaves_done ? 1u : 0u;
   P.kind = (uint32_t)kind; P.n = c->cfg.n_max; P.tree_nodes = tree_nodes(c->cfg.n_max); P.chain_id_len = c->cfg.chain_id_len;
   P.skip_max = c->cfg.skip_max;
-  P.no_wide = c->k_no_wide ? 1u : 0u;
-  P.threads = c->k_proof_threads;
   std::memcpy(P.chain_id, c->cfg.chain_id, sizeof P.chain_id);
   return P;
 }
 
-// Launch sequence of one batch.  Main stream s:  [ev0] EdDSA kernels [ev1] (joins) [ev2] k_serialize of the EdDSA-dependent section [ev3]
-//                               side stream:      (after ev0) [side0] k_proof [side1] -> ev_join, waited on before the tail;
-//                               side2 (tail):     [side2] k_verdict [side3] k_serialize of the sections that carry the verdict -> ev_tail.
+// Launch sequence of one batch.  Caller's stream s: [ev0] EdDSA kernels [ev1] k_serialize of the EdDSA-dependent section [ev3]
+//                               side:   (after ev0) [side0] k_proof [side1], then the sections that only need it -> ev_join
+//                               side3:  (after ev0) the sections that only expand the input records -> ev_join3
+//                               side2:  the new-key pipeline of the EdDSA stage; the tail: k_verdict + the sections that carry it -> ev_tail
 // k_proof does not depend on the EdDSA results, so it overlaps with them; `ed_producer` enqueues whatever fills the ED part of
 // c->d_tl on s (the EdDSA kernels, or a strided copy of caller-provided lane records).
 template <typename EdProducer>
 static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets, const void* d_trusteds,
                          void* d_out_elems, void* d_reports, hipStream_t s, EdProducer ed_producer) {
   const uint32_t n = c->cfg.n_max;
+  const Knobs& K = c->knobs;
   uint8_t* tl = reinterpret_cast<uint8_t*>(c->d_tl);
   void* reports = d_reports ? d_reports : c->d_reports;
   const uint64_t slot = c->n_calls % tmx_ctx::EV_RING;
@@ -350,14 +362,12 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   src.base[SRC_TL] = tl; src.base[SRC_LR] = (const uint8_t*)c->d_lr; src.base[SRC_PF] = (const uint8_t*)c->d_pf;
   src.nodes_t = (const uint8_t*)c->d_nodes_t; src.nodes_r = (const uint8_t*)c->d_nodes_r;
   const Program& prog = c->prog[kind];
-  auto serialize = [&](uint32_t mask, hipStream_t on, uint32_t max_wgs = 0xffffffffu, uint32_t proof0 = 0, uint32_t count = 0) -> int32_t {
+  auto serialize = [&](uint32_t mask, hipStream_t on, uint32_t max_wgs = 0) -> int32_t {
     if (!d_out_elems) return TMX_OK;
-    if (max_wgs == 0xffffffffu) max_wgs = c->k_ser_wgs;
-    if (count == 0) count = n_proofs - proof0;
     // (sections the caller did not ask for are not written; the seam spans are few and always written)
     mask &= ((c->sections & TMX_SEC_HINT) ? prog.mask_hint : 0u) | ((c->sections & TMX_SEC_DERIVED) ? prog.mask_derived : 0u) | (1u << 31);
-    int r = launch_serialize(prog.sp, src, c->d_lut[kind], c->d_wave_sec[kind], c->d_seams[kind], (uint32_t)prog.seam_waves.size(), count,
-                             d_out_elems, mask, on, max_wgs, proof0);
+    int r = launch_serialize(prog.sp, src, c->d_lut[kind], c->d_wave_sec[kind], c->d_seams[kind], (uint32_t)prog.seam_waves.size(), n_proofs,
+                             d_out_elems, mask, on, max_wgs);
     if (r) return fail(c, TMX_ERR_HIP, std::string("k_serialize launch: ") + hipGetErrorString((hipError_t)r));
     return TMX_OK;
   };
@@ -369,43 +379,29 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   HIPCK(c, hipEventRecord(ev[0], s));
   HIPCK(c, hipStreamWaitEvent(c->side, ev[0], 0));
   HIPCK(c, hipStreamWaitEvent(c->side3, ev[0], 0));
-  // side3: the sections that are a pure expansion of the input records (42 % of a skip row) -- HBM is idle while EdDSA runs
-  // (with phase 1 on side3 these launches are enqueued behind it, after the EdDSA producer)
   int32_t st0 = TMX_OK;
-  // (TMX_INPUTS_ON=side2 puts them behind the key chain on the high-priority stream instead.  At 1024 proofs the low-priority launch
-  // is starved -- it runs from 0 to 1.8 ms and ends the step -- but the step is VALU-bound there (the serializer is 21 % of all VALU
-  // instructions) and the high-priority placement only moves the time around: 1.894 vs 1.895 ms; at 256 proofs it costs 8 %.)
-  const bool inputs_hi = c->quad && c->ser_split && c->k_inputs_side2;
-  hipStream_t in_stream = inputs_hi ? c->side2 : c->side3;
+  // side3: the sections that are a pure expansion of the input records (42 % of a skip row) -- HBM is idle while EdDSA runs.
   // Launches that run beside the EdDSA latency chain are walked by a fixed number of workgroups (k_serialize_few): a memory-bound grid of
   // half a million short waves keeps every wave slot of the chip taken, and the chain's workgroups then wait for a slot whatever their
   // priority (a pure store stream beside the EdDSA stage: k_ed_keys 50 -> 103 us, the stage 0.42 -> 0.72 ms).  Four workgroups per CU
-  // still write at the rate these sections need.  Measured (TMX_SER_IN_WGS=0|n): step -3 % at 256 proofs x 128 (1024 or 1280 workgroups;
-  // 512: the EdDSA stage -48 us but the sections end after it), -4.5 % at 512, -3 % at 1024 (1536), -1 % at 64, +-0 at 32.
-  const uint32_t beside_chain_wgs = c->k_ser_in_wgs >= 0 ? (uint32_t)c->k_ser_in_wgs : ((uint64_t)n_proofs * n >= 131072 ? 1536u : 1024u);
-  auto inputs_on_side3 = [&]() -> int32_t {
-    const int32_t r = c->ser_split ? serialize(prog.mask_inputs, in_stream, beside_chain_wgs) : TMX_OK;
-    if (r) return r;
-    HIPCK(c, hipEventRecord(c->ev_join3, in_stream));
-    return TMX_OK;
-  };
-  const bool inputs_late = (c->p1_side == 1 || inputs_hi) && c->quad;
-  if (!inputs_late && (st0 = inputs_on_side3())) return st0;
+  // still write at the rate these sections need: step -3 % at 256 proofs x 128 (1024 workgroups; 512: the EdDSA stage -48 us but the
+  // sections end after it), -4.5 % at 512, -3 % at 1024 (1536), -1 % at 64, +-0 at 32.
+  const uint32_t beside_chain_wgs = (uint64_t)n_proofs * n >= 131072 ? 1536u : 1024u;
+  if (K.ser_split && (st0 = serialize(prog.mask_inputs, c->side3, beside_chain_wgs))) return st0;
+  HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
   // Leaves first (TMX_LEAVES=1|0, default by size): marshalled validators + leaf hashes as a 10-us launch of their own in front of k_proof,
   // so that the byte fields of the two per-lane derived sections (D.2a: the leaves; D.1a: the leaves + phase 1 -- 42 % of a skip row) are
   // written by the low-priority stream behind the input sections instead of behind k_proof (which ends at ~300 us inside a step) / k_ed_fin.
-  // Measured (TMX_LEAVES=1|0, N = 128): -5 % step at 1024 proofs (on top of the -6 % of D.1a behind k_proof's sections), but +1.5 % at 256,
-  // +4.5 % at 512, +8 % at 64, +6.5 % on the one-set batch at 256: below ~1000 proofs every extra concurrent launch stretches the EdDSA
-  // chain by more than the tail it removes.  On from 131072 lanes.
-  const bool leaves_first = c->ser_split && d_out_elems && c->quad && !inputs_late &&
-                            (c->k_leaves >= 0 ? c->k_leaves != 0 : (uint64_t)n_proofs * n >= 131072);
+  // Measured at N = 128: -5 % step at 1024 proofs (on top of the -6 % of D.1a behind k_proof's sections), but +1.5 % at 256, +4.5 % at 512,
+  // +8 % at 64: below ~1000 proofs every extra concurrent launch stretches the EdDSA chain by more than the tail it removes.
+  const bool leaves_first = K.ser_split && d_out_elems && (K.leaves >= 0 ? K.leaves != 0 : (uint64_t)n_proofs * n >= 131072);
   // side: k_proof, then the sections that only need its results
   HIPCK(c, hipEventRecord(evs[0], c->side));
   int rc = 0;
   if (leaves_first) {
-    rc = launch_leaves((uint32_t)kind, n, n_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->side, c->k_ext_events ? c->ev_leaves : nullptr);
+    rc = launch_leaves((uint32_t)kind, n, n_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->side, K.ext_events ? c->ev_leaves : nullptr);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_leaves launch: ") + hipGetErrorString((hipError_t)rc));
-    if (!c->k_ext_events) HIPCK(c, hipEventRecord(c->ev_leaves, c->side));
+    if (!K.ext_events) HIPCK(c, hipEventRecord(c->ev_leaves, c->side));
     HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_leaves, 0));
     if ((st0 = serialize(prog.mask_leaves, c->side3, beside_chain_wgs))) return st0;
   }
@@ -414,73 +410,48 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_proof launch: ") + hipGetErrorString((hipError_t)rc));
   HIPCK(c, hipEventRecord(evs[1], c->side));
 
-  c->ev_mul_recorded = false;
-  c->want_ev_mul = c->k_proofser_hold;
-  {  // ev[1] rides on the k_ed_fin dispatch itself when the quad path runs (TMX_EXT_EVENTS=0: a record packet behind it)
-    c->ext_events = c->k_ext_events;
-    c->fin_done = c->ext_events ? ev[1] : nullptr;
-    c->fin_done_attached = false;
-  }
+  // ev[1] rides on the k_ed_fin dispatch itself (TMX_EXT_EVENTS=0: a record packet behind it)
+  c->fin_done = K.ext_events ? ev[1] : nullptr;
+  c->fin_done_attached = false;
   c->ev_hash_recorded = false;
-  {  // the tail in two halves (see run_eddsa).  Measured TMX_TAIL_SPLIT=1|0 at N = 128: -1.7 % step at 1024 proofs, +-0 at 512, but +10 % at
-    // 256 and +6 % at 64 (two walks of half the lanes hide their table fetches worse than one: the EdDSA stage 0.49 -> 0.54 ms) -> by size
-    const bool want = c->k_tail_split >= 0 ? c->k_tail_split != 0 : (uint64_t)n_proofs * n >= 131072;
-    const bool tail_aside_ = c->ser_split && (uint64_t)n_proofs * n >= 4096;
-    c->split_req = (want && d_out_elems && tail_aside_ && n_proofs >= 2) ? (n_proofs / 2) * n : 0u;
-    c->split_lane = 0;
-  }
   int32_t st = ed_producer(s);
   c->fin_done = nullptr;
   if (st) return st;
-  c->split_req = 0;
-  const uint32_t split_proofs = c->split_lane / n;  // != 0: the first split_proofs proofs are finished on side3 (ev_fin_a)
-  c->split_lane = 0;
-  if (inputs_late && (st0 = inputs_on_side3())) return st0;
-  // TMX_PROOFSER_HOLD=1 keeps these launches back until the table walk is done (with the 80 KB 4-bit key tables they doubled its run
-  // time; with the 6-bit tables and the short finish they are better off right behind k_proof: -2 % step at 256 proofs)
-  if (c->ev_mul_recorded) HIPCK(c, hipStreamWaitEvent(c->side, c->ev_mul, 0));
   if (leaves_first) {  // side3, behind the input sections and D.2a: D.1a as soon as phase 1 is done; ev_join3 moves behind it
     if (!c->ev_hash_recorded) HIPCK(c, hipEventRecord(c->ev_hash, s));  // (a producer without a phase-1 event: everything it enqueued)
     HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_hash, 0));
     if ((st0 = serialize(prog.mask_p1, c->side3, beside_chain_wgs))) return st0;
     HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
   }
-  st0 = c->ser_split ? serialize(prog.mask_proof | (leaves_first ? 0u : prog.mask_leaves), c->side) : TMX_OK;
+  st0 = K.ser_split ? serialize(prog.mask_proof | (leaves_first ? 0u : prog.mask_leaves), c->side) : TMX_OK;
   if (st0) return st0;
   // D.1a (the byte fields of the per-target-lane derived values: a quarter of the row) needs k_proof and phase 1, not k_ed_fin: behind
   // k_proof's sections on the side stream, i.e. while the table walk and the finish run.  Measured (TMX_P1_EARLY=1|0): -6.3 % step at 1024
-  // proofs x 128; +-0.5 % at 256 and 64, +4 % on the one-validator-set batch at 256 (the side stream, not k_ed_fin, ends the step there) ->
-  // (and +1 ... +2 % at 512 proofs): on from 131072 lanes
-  const bool p1_early = leaves_first || (c->ser_split && c->ev_hash_recorded && (c->k_p1_early >= 0 ? c->k_p1_early != 0 : (uint64_t)n_proofs * n >= 131072));
+  // proofs x 128; +-0.5 % at 256 and 64, +1 ... +2 % at 512 proofs: on from 131072 lanes
+  const bool p1_early = leaves_first || (K.ser_split && c->ev_hash_recorded && (K.p1_early >= 0 ? K.p1_early != 0 : (uint64_t)n_proofs * n >= 131072));
   if (p1_early && !leaves_first) {
     HIPCK(c, hipStreamWaitEvent(c->side, c->ev_hash, 0));
     if ((st0 = serialize(prog.mask_p1, c->side, beside_chain_wgs))) return st0;
-  }
-  if (split_proofs) {  // (side3 is behind k_ed_fin of the first half already: its D.1 rows need that and k_proof)
-    HIPCK(c, hipStreamWaitEvent(c->side3, evs[1], 0));
-    if ((st0 = serialize(prog.mask_final | (p1_early ? 0u : prog.mask_p1), c->side3, 0xffffffffu, 0, split_proofs))) return st0;
-    HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
   }
   HIPCK(c, hipStreamWaitEvent(c->side, c->ev_join3, 0));  // ev_join = both low-priority streams done
   HIPCK(c, hipEventRecord(c->ev_join, c->side));
   if (!c->fin_done_attached) HIPCK(c, hipEventRecord(ev[1], s));
   // (a small batch is pure latency: its tail stays on s, two cross-stream hops cost more than the overlap gains)
-  const bool tail_aside = c->ser_split && (uint64_t)n_proofs * n >= 4096;
-  if (c->ser_split && !tail_aside) {
+  const bool tail_aside = K.ser_split && (uint64_t)n_proofs * n >= 4096;
+  if (K.ser_split && !tail_aside) {
     HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
-    const bool xv = c->ext_events && n_proofs != 0;  // the verdict's two timing events ride on its dispatch
+    const bool xv = K.ext_events && n_proofs != 0;  // the verdict's two timing events ride on its dispatch
     if (!xv) HIPCK(c, hipEventRecord(evs[2], s));
     rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, s, xv ? evs[2] : nullptr, xv ? evs[3] : nullptr);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
     if (!xv) HIPCK(c, hipEventRecord(evs[3], s));
     if ((st0 = serialize(prog.mask_final | prog.mask_p1 | prog.mask_tail, s))) return st0;
     HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
-  } else if (c->ser_split) {
+  } else if (K.ser_split) {
     // tail: the per-lane derived section (a quarter of the row) only needs k_ed_fin + k_proof, so it is written on s while the
     // verdict and the few sections that carry it go through the high-priority side stream.  (ev[2] = ev[1] here: every packet
     // between k_ed_fin and the serializer is latency on the critical path.)
     HIPCK(c, hipStreamWaitEvent(c->side2, ev[1], 0));
-    if (split_proofs) HIPCK(c, hipStreamWaitEvent(c->side2, c->ev_fin_a, 0));
     HIPCK(c, hipStreamWaitEvent(c->side2, evs[1], 0));  // k_proof itself, not the serializer launches queued behind it
     HIPCK(c, hipEventRecord(evs[2], c->side2));
     rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, c->side2);
@@ -490,7 +461,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     HIPCK(c, hipStreamWaitEvent(c->side2, c->ev_join, 0));  // ev_tail = every side stream done
     HIPCK(c, hipEventRecord(c->ev_tail, c->side2));
     HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
-    if ((st0 = serialize(prog.mask_final | (p1_early ? 0u : prog.mask_p1), s, 0xffffffffu, split_proofs, 0))) return st0;
+    if ((st0 = serialize(prog.mask_final | (p1_early ? 0u : prog.mask_p1), s))) return st0;
     HIPCK(c, hipStreamWaitEvent(s, c->ev_tail, 0));
   } else {
     HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
@@ -504,6 +475,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   HIPCK(c, hipEventRecord(ev[3], s));
   c->last_stream = s; c->last_stream_valid = true;
   c->ev_done = ev[3];
+  c->last_kind = kind; c->last_n_proofs = n_proofs;
   c->n_calls++;
   return TMX_OK;
 }
@@ -516,55 +488,35 @@ static int32_t check_batch_args(tmx_ctx* c, int32_t kind, uint32_t n_proofs, con
 }
 
 // EdDSA stage: begins and ends on stream s.
+//   s:      k_ed_dedup -> k_ed_phase1 -> [keys done] k_ed_mul* (table-free lanes) -> [tables done] k_ed_mul_tab -> k_ed_fin
+//   side2:  (after the dedup) k_ed_keys -> k_ed_tab_anchor16 / k_ed_tab_mult of the new keys -> k_kc_epilogue
+// With a warm key cache (every lane's key resident) the side2 kernels are empty launches that end long before phase 1 does and the
+// chain on s is dedup -> phase 1 -> walk -> finish.
 static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_ed, uint32_t ed_stride, hipStream_t s) {
-  if (!c->quad) return launch_eddsa(n_lanes, d_lanes, d_ed, ed_stride, c->d_table, s);
+  const Knobs& K = c->knobs;
   EdQuad Q;
-  Q.n_lanes = n_lanes; Q.d_target = d_lanes; Q.d_ed = d_ed; Q.ed_stride = ed_stride; Q.d_qtable = c->d_qtable; Q.base_w = c->base_w; Q.d_pre = c->d_pre;
+  Q.n_lanes = n_lanes; Q.d_target = d_lanes; Q.d_ed = d_ed; Q.ed_stride = ed_stride; Q.d_qtable = c->d_qtable; Q.d_pre = c->d_pre;
   Q.d_mulout = c->d_mulout; Q.d_hash = c->d_hash; Q.hash_mask = c->hash_mask; Q.d_owner_of = c->d_owner_of;
-  Q.d_uid_of_owner = c->d_uid_of_owner; Q.d_owners = c->d_owners; Q.d_keyrec = c->d_keyrec; Q.d_anchors = c->d_anchors; Q.d_keytab = c->d_keytab;
-  Q.key_cap = c->key_cap; Q.key_w = c->key_w; Q.mode = c->dedup_mode;
+  Q.d_slot_of_owner = c->d_slot_of_owner; Q.d_slot_of_uid = c->d_slot_of_uid; Q.d_owners = c->d_owners; Q.d_keyrec = c->d_keyrec;
+  Q.d_anchors = c->d_anchors; Q.d_keytab = c->d_keytab;
+  Q.kc = c->kc; Q.mode = K.dedup_mode;
   Q.fin_done = c->fin_done; c->fin_done = nullptr;
-  Q.anchor16 = c->anchor16; Q.keys16 = c->keys16; Q.mul16 = c->mul16; Q.mul_split = c->k_mul_split;
   c->last_lanes = n_lanes;
   Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * c->parity;
   Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1);
-  hipError_t e;
-  // Tiny launches (a single proof, up to 512 lanes): tables never pay there (measured: direct h*A wins up to ~6 proofs x 128) and the
-  // dedup kernel, its hop to side2 and the empty table launches are 30 us of a 0.31 ms step.  Every lane is its own key: k_ed_keys starts
-  // at once on side2 (it writes the identity maps itself), phase 1 on s, then h*A one wave per lane and the finish.  TMX_TINY=0: off.
-  {
-    c->last_tiny = n_lanes != 0 && n_lanes <= 512 && c->keys16 && c->mul16 && c->k_tiny;
-  }
-  const uint32_t split_req = c->split_req;
-  c->split_req = 0; c->split_lane = 0;
-  if (c->last_tiny) {
-    Q.mode = 0;
-    if ((e = hipEventRecord(c->ev_fork2, s)) != hipSuccess) return (int)e;
-    if ((e = hipStreamWaitEvent(c->side2, c->ev_fork2, 0)) != hipSuccess) return (int)e;
-    int rc = launch_ed_keys(Q, c->side2, c->ext_events ? c->ev_keys : nullptr, n_lanes);
-    if (rc) return rc;
-    if (!c->ext_events && (e = hipEventRecord(c->ev_keys, c->side2)) != hipSuccess) return (int)e;
-    rc = launch_ed_phase1(Q, s);
-    if (rc) return rc;
-    if ((e = hipStreamWaitEvent(s, c->ev_keys, 0)) != hipSuccess) return (int)e;
-    // (up to 256 lanes: at 512 the 512 waves of the fused kernel slow k_proof, the longer of the two there, by more than they save)
-    const bool fuse = c->k_fuse_fin >= 0 ? c->k_fuse_fin != 0 : n_lanes <= 256;
-    rc = launch_ed_mul_direct(Q, s, fuse);
-    if (rc) return rc;
-    if (!fuse) rc = launch_ed_fin(Q, s);
-    c->fin_done_attached = rc == 0 && Q.fin_done != nullptr;
-    return rc;
-  }
   c->parity ^= 1;
-  // dedup on s, then the distinct-key pipeline (decode -> anchors -> table: a latency chain of a few waves) on the high-priority
-  // stream side2 beside phase 1 on s; both join before h*A.  (Queue priority also decides which waves issue first on a shared
-  // SIMD: with the chain on a normal-priority queue k_ed_keys alone takes 230 us instead of 100.)
-  // (cleared on side2 by the previous launch.  Skipping this wait when s has already waited for side2's tail was measured: k_proof
-  // 0.45 -> 0.52 ms beside it and the step +2 % at 256 proofs -- the packet stays.)
+  // Tiny launches (a single proof, up to 512 lanes) are pure latency: they never wait for tables -- lanes whose key is resident walk its
+  // table, the others take the limb-parallel table-free form (one wave per lane, the finish fused), and the tables of their keys are built
+  // on side2 off the critical path, for the next call.
+  const bool tiny = n_lanes != 0 && n_lanes <= 512;
+  Q.use_new = tiny ? 0u : 1u;
+  hipError_t e;
+  // (the launch's hash table was cleared, and the cache committed, on side2 by the previous launch.  Skipping this wait when s has
+  // already waited for side2's tail was measured: k_proof 0.45 -> 0.52 ms beside it and the step +2 % at 256 proofs -- the packet stays.)
   if ((e = hipStreamWaitEvent(s, c->ev_hash_clean, 0)) != hipSuccess) return (int)e;
   // Events that mark the end of one kernel ride on its dispatch (completion signal) instead of a record packet behind it: on the
   // chain every packet is latency.  `x` = that is on and the kernel really is launched.
-  const bool x = c->ext_events && n_lanes != 0, xt = x && Q.mode != 0 && Q.key_cap != 0;
+  const bool x = K.ext_events && n_lanes != 0, xt = x && Q.mode != 0 && Q.kc.cap != 0;
   int rc = launch_ed_dedup(Q, s, x ? c->ev_fork2 : nullptr);
   if (rc) return rc;
   if (!x && (e = hipEventRecord(c->ev_fork2, s)) != hipSuccess) return (int)e;
@@ -574,8 +526,8 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   if (!x && (e = hipEventRecord(c->ev_keys, c->side2)) != hipSuccess) return (int)e;
   // The anchor chain is cut into `parts` launches on side2; the cached multiples of part p are built on s (idle once phase 1 is
   // done) while side2 doubles part p+1, so that only the multiples of the last part follow the chain.
-  // (small launches: one part -- nothing to overlap, and without tables every part is one more empty launch on s)
-  const uint32_t parts = n_lanes <= 2048 ? 1u : c->tab_parts;
+  // (small launches: one part -- nothing to overlap, and every part is one more launch on s)
+  const uint32_t parts = n_lanes <= 2048 ? 1u : K.tab_parts;
   for (uint32_t p = 0; p < parts; p++) {
     const bool last = p + 1 == parts;
     rc = launch_ed_tab_anchor(Q, p, parts, c->side2, xt && !last ? c->ev_part[p] : nullptr);
@@ -587,41 +539,34 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     if (!xt && (e = hipEventRecord(c->ev_part[p], c->side2)) != hipSuccess) return (int)e;
   }
   if ((e = hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, c->side2)) != hipSuccess) return (int)e;  // for the next launch
+  // (with parts > 1 the multiples of the earlier parts run on s: the epilogue only needs the counters k_ed_keys left, not the tables)
+  rc = launch_kc_epilogue(Q, c->side2);
+  if (rc) return rc;
   if ((e = hipEventRecord(c->ev_hash_clean, c->side2)) != hipSuccess) return (int)e;
-  // Phase 1 (SHA-512, s*B: throughput work for every lane) goes to the low-priority stream side3: on s it would sit in front of the
-  // table multiples of the first part, which then start when phase 1 ends instead of when their anchors are ready.
-  // (measured at 256 / 1024 proofs x 128: mode 1 +3 % / +8 % step time, mode 2 +0.7 % / -1.3 %: the walk starts 55 us earlier but shares
-  // the SIMDs with s*B -- the span is VALU-throughput-bound either way.  Round 2, with the two roles as kernels of their own (s*B then
-  // runs at 73 instead of 186 VGPRs): s*B on s + hash in front of the input sections on side3 +4 % / +4 %, both on s one after the other
-  // +-0 % / -0.3 % at 256 / 1024 proofs and +11 % on the one-validator-set batch and at 32 proofs; the combined launch stays)
-  const uint32_t p1_side = c->p1_side == 3 ? 0u : c->p1_side;
-  bool wait_p1_late = false;
-  if (p1_side == 1) {
-    if ((e = hipStreamWaitEvent(c->side3, c->ev_fork2, 0)) != hipSuccess) return (int)e;
-    rc = launch_ed_phase1(Q, c->side3, x ? c->ev_p1 : nullptr);
+  // phase 1 (SHA-512 mod l, s*B: throughput work for every lane) on s
+  rc = launch_ed_phase1(Q, s, x ? c->ev_hash : nullptr);
+  if (rc) return rc;
+  if (!x && (e = hipEventRecord(c->ev_hash, s)) != hipSuccess) return (int)e;
+  c->ev_hash_recorded = true;
+  if (tiny) {
+    rc = launch_ed_mul_tab(Q, 0, 1, s);  // resident keys only: no wait for side2
     if (rc) return rc;
-    if (!x && (e = hipEventRecord(c->ev_p1, c->side3)) != hipSuccess) return (int)e;
-    if ((e = hipStreamWaitEvent(s, c->ev_p1, 0)) != hipSuccess) return (int)e;
-  } else if (p1_side == 2) {  // hash role on s (the walk needs it), s*B behind the input sections on side3 (only k_ed_fin needs it)
-    rc = launch_ed_phase1(Q, s, nullptr, 1);
+    if ((e = hipStreamWaitEvent(s, c->ev_keys, 0)) != hipSuccess) return (int)e;
+    // (up to 256 lanes the finish of the table-free lanes is fused into their kernel: at 512 the 512 waves of the fused kernel slow
+    // k_proof, the longer of the two there, by more than they save)
+    const bool fuse = n_lanes <= 256;
+    rc = launch_ed_mul_direct(Q, s, fuse);
     if (rc) return rc;
-    if ((e = hipStreamWaitEvent(c->side3, c->ev_fork2, 0)) != hipSuccess) return (int)e;
-    rc = launch_ed_phase1(Q, c->side3, x ? c->ev_p1 : nullptr, 2);
-    if (rc) return rc;
-    if (!x && (e = hipEventRecord(c->ev_p1, c->side3)) != hipSuccess) return (int)e;
-    wait_p1_late = true;
-  } else {
-    rc = launch_ed_phase1(Q, s, x ? c->ev_hash : nullptr);
-    if (rc) return rc;
-    if (!x && (e = hipEventRecord(c->ev_hash, s)) != hipSuccess) return (int)e;
-    c->ev_hash_recorded = true;
+    rc = launch_ed_fin(Q, s, fuse);
+    c->fin_done_attached = rc == 0 && Q.fin_done != nullptr;
+    return rc;
   }
   if ((e = hipStreamWaitEvent(s, c->ev_keys, 0)) != hipSuccess) return (int)e;
-  rc = launch_ed_mul_direct(Q, s);  // empty when the tables are used: enqueued before the wait for them
+  rc = launch_ed_mul_direct(Q, s);  // exits at once for the lanes that walk a table: enqueued before the wait for the tables
   if (rc) return rc;
   // The table walk can follow the table build part by part (partial sums in mulout).  Measured: +4 % step time at 256-512 proofs (the
   // parts sit on the caller's normal-priority queue beside the chain), -2.7 % at 1024, where the walk dominates -> by batch size.
-  const bool walk_parts = c->k_walk_parts >= 0 ? c->k_walk_parts == 1 : n_lanes >= 65536;
+  const bool walk_parts = parts > 1 && (K.walk_parts >= 0 ? K.walk_parts == 1 : n_lanes >= 65536);
   for (uint32_t p = 0; p < parts; p++) {
     if ((e = hipStreamWaitEvent(s, c->ev_part[p], 0)) != hipSuccess) return (int)e;
     if (p + 1 < parts) {
@@ -633,36 +578,11 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
       if (rc) return rc;
     }
   }
-  // Tail in two halves (c->split_lane != 0: the walk is one launch, the tables are used, run_batch serializes): the walk of the first
-  // half of the lanes, then -- on the low-priority stream -- their finish (a latency chain of a few hundred waves) and their D.1 rows
-  // beside the walk of the second half; the step then ends with half a finish-and-D.1 behind the last walk instead of a whole one.
-  const uint32_t split_lane = (!walk_parts && split_req && split_req < n_lanes && Q.mode != 0 && Q.key_cap != 0) ? split_req : 0u;
-  c->split_lane = split_lane;
   if (!walk_parts) {
-    if (split_lane) {
-      rc = launch_ed_mul_tab(Q, 0, 1, s, 0, split_lane);
-      if (rc) return rc;
-      if ((e = hipEventRecord(c->ev_half, s)) != hipSuccess) return (int)e;
-      if ((e = hipStreamWaitEvent(c->side3, c->ev_half, 0)) != hipSuccess) return (int)e;
-      EdQuad Qa = Q;
-      Qa.fin_done = nullptr;
-      rc = launch_ed_fin(Qa, c->side3, 0, split_lane);
-      if (rc) return rc;
-      if ((e = hipEventRecord(c->ev_fin_a, c->side3)) != hipSuccess) return (int)e;
-      rc = launch_ed_mul_tab(Q, 0, 1, s, split_lane, n_lanes);
-      if (rc) return rc;
-    } else {
-      rc = launch_ed_mul_tab(Q, 0, 1, s);
-      if (rc) return rc;
-    }
+    rc = launch_ed_mul_tab(Q, 0, 1, s);
+    if (rc) return rc;
   }
-  // (run_batch can hold the serializer launches of the side stream back until the walk is done: TMX_PROOFSER_HOLD)
-  if (c->want_ev_mul) {
-    if ((e = hipEventRecord(c->ev_mul, s)) != hipSuccess) return (int)e;
-    c->ev_mul_recorded = true;
-  }
-  if (wait_p1_late && (e = hipStreamWaitEvent(s, c->ev_p1, 0)) != hipSuccess) return (int)e;
-  rc = launch_ed_fin(Q, s, split_lane, n_lanes);
+  rc = launch_ed_fin(Q, s);
   c->fin_done_attached = rc == 0 && Q.fin_done != nullptr && n_lanes != 0;
   return rc;
 }
@@ -719,17 +639,13 @@ hipError_t acquire_streams(int device, DeviceStreams** out) {
     // The key pipeline is on the critical path (high priority); the early serialization only fills otherwise idle HBM cycles and
     // must not starve the caller's stream (low priority).  k_proof's stream is at the caller's priority: the sections that wait for
     // it are the last thing a step writes, and at low priority the kernel stretched from 0.30 ms (alone) to 0.5 ms (measured:
-    // normal -2 % step time at 256 proofs, -0.8 % at 1024; high +40 %: two high-priority queues fight).  TMX_SIDE_PRIO=low|normal|high.
+    // normal -2 % step time at 256 proofs, -0.8 % at 1024; high +40 %: two high-priority queues fight).
     int prio_low = 0, prio_high = 0;
     hipError_t e;
     if ((e = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high)) != hipSuccess) return e;
-    int prio_side = (prio_low + prio_high) / 2;
-    if (const char* sp = std::getenv("TMX_SIDE_PRIO")) prio_side = sp[0] == 'h' ? prio_high : (sp[0] == 'l' ? prio_low : prio_side);
-    if ((e = hipStreamCreateWithPriority(&d.side, hipStreamNonBlocking, prio_side)) != hipSuccess) return e;
+    if ((e = hipStreamCreateWithPriority(&d.side, hipStreamNonBlocking, (prio_low + prio_high) / 2)) != hipSuccess) return e;
     if ((e = hipStreamCreateWithPriority(&d.side2, hipStreamNonBlocking, prio_high)) != hipSuccess) return e;
-    int prio_side3 = prio_low;
-    if (const char* sp = std::getenv("TMX_SIDE3_PRIO")) prio_side3 = sp[0] == 'h' ? prio_high : (sp[0] == 'n' ? (prio_low + prio_high) / 2 : prio_low);
-    if ((e = hipStreamCreateWithPriority(&d.side3, hipStreamNonBlocking, prio_side3)) != hipSuccess) return e;
+    if ((e = hipStreamCreateWithPriority(&d.side3, hipStreamNonBlocking, prio_low)) != hipSuccess) return e;
   }
   d.refs++;
   *out = &d;
@@ -760,6 +676,34 @@ void release_streams(int device) {
 }
 }  // namespace
 
+// (re)allocate the key cache for `keys` slots and empty it.  The caller has made sure nothing of this context is in flight.
+static int32_t alloc_key_cache(tmx_ctx* c, uint32_t keys) {
+  void** bufs[] = {(void**)&c->kc.d_hash, (void**)&c->kc.d_pk, (void**)&c->kc.d_used, (void**)&c->kc.d_free, (void**)&c->kc.d_state, &c->d_keyrec,
+                   &c->d_anchors, &c->d_keytab};
+  for (void** b : bufs)
+    if (*b) { (void)hipFree(*b); *b = nullptr; }
+  const size_t lanes = (size_t)c->cfg.max_batch * c->cfg.n_max;
+  if (keys > (1u << 20)) keys = 1u << 20;
+  if (keys == 0) keys = 1;
+  uint64_t hsz = 1;
+  while (hsz < 4 * (uint64_t)keys) hsz <<= 1;
+  c->kc.cap = keys;
+  c->kc.hash_mask = (uint32_t)(hsz - 1);
+  c->kc.new_cap = (uint32_t)std::min<size_t>(std::min<size_t>(keys, 4096), lanes);  // tables one launch builds at most: the anchor scratch
+  c->kc.persist = c->knobs.key_cache ? 1u : 0u;
+  HIPCK(c, hipMalloc((void**)&c->kc.d_hash, hsz * 4));
+  HIPCK(c, hipMalloc((void**)&c->kc.d_pk, (size_t)keys * 32));
+  HIPCK(c, hipMalloc((void**)&c->kc.d_used, (size_t)keys * 4));
+  HIPCK(c, hipMalloc((void**)&c->kc.d_free, (size_t)keys * 4));
+  HIPCK(c, hipMalloc((void**)&c->kc.d_state, KC_STATE_WORDS * 4));
+  HIPCK(c, hipMalloc(&c->d_keyrec, ((size_t)keys + lanes) * key_bytes_per_key()));
+  HIPCK(c, hipMalloc(&c->d_anchors, (size_t)c->kc.new_cap * anchor_bytes_per_key()));
+  HIPCK(c, hipMalloc(&c->d_keytab, (size_t)keys * keytab_bytes_per_key()));
+  int rc = launch_kc_reset(c->kc, c->side2);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_kc_reset launch: ") + hipGetErrorString((hipError_t)rc));
+  return TMX_OK;
+}
+
 extern "C" {
 
 void tmx_ctx_destroy(tmx_ctx* c) {
@@ -768,8 +712,8 @@ void tmx_ctx_destroy(tmx_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipDeviceSynchronize();
   }
-  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_owner_of, c->d_uid_of_owner, c->d_owners, c->d_keyrec,
-                  c->d_anchors, c->d_keytab, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
+  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_owner_of, c->d_slot_of_owner, c->d_slot_of_uid, c->d_owners, c->d_keyrec,
+                  c->d_anchors, c->d_keytab, c->kc.d_hash, c->kc.d_pk, c->kc.d_used, c->kc.d_free, c->kc.d_state, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
                   c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out, c->d_pack, c->d_trace_tmp};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -790,13 +734,9 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   for (hipEvent_t ev : c->ev_part)
     if (ev) (void)hipEventDestroy(ev);
   if (c->ev_keys) (void)hipEventDestroy(c->ev_keys);
-  if (c->ev_p1) (void)hipEventDestroy(c->ev_p1);
   if (c->ev_hash) (void)hipEventDestroy(c->ev_hash);
   if (c->ev_leaves) (void)hipEventDestroy(c->ev_leaves);
   if (c->ev_hash_clean) (void)hipEventDestroy(c->ev_hash_clean);
-  if (c->ev_mul) (void)hipEventDestroy(c->ev_mul);
-  if (c->ev_half) (void)hipEventDestroy(c->ev_half);
-  if (c->ev_fin_a) (void)hipEventDestroy(c->ev_fin_a);
   if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
   for (hipEvent_t e : c->ev_trace)
     if (e) (void)hipEventDestroy(e);
@@ -826,19 +766,11 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   HIPCK(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming));
   for (auto& ev : c->ev_part) HIPCK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  {
-    const char* tp = std::getenv("TMX_TAB_PARTS");
-    const int v = tp ? std::atoi(tp) : 2;
-    c->tab_parts = (v == 1 || v == 2 || v == 4) ? (uint32_t)v : 2u;
-  }
+  c->knobs = read_knobs();
   HIPCK(c, hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
-  HIPCK(c, hipEventCreateWithFlags(&c->ev_p1, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_hash, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_leaves, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_hash_clean, hipEventDisableTiming));
-  HIPCK(c, hipEventCreateWithFlags(&c->ev_mul, hipEventDisableTiming));
-  HIPCK(c, hipEventCreateWithFlags(&c->ev_half, hipEventDisableTiming));
-  HIPCK(c, hipEventCreateWithFlags(&c->ev_fin_a, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   for (auto& set : c->ev_side)
     for (auto& ev : set) HIPCK(c, hipEventCreate(&ev));
@@ -846,6 +778,7 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     for (auto& ev : set) HIPCK(c, hipEventCreate(&ev));
   const uint32_t n = cfg->n_max;
   const size_t B = cfg->max_batch, lanes = B * n;
+  if (lanes > ((size_t)1 << 30)) return fail(c, TMX_ERR_CAPACITY, "max_batch * n_max exceeds 2^30 lanes");
   for (int k = 0; k < 2; k++) {
     c->prog[k] = build_program(k, n);
     if (c->prog[k].sp.elem_count != tmx_elem_count(k, n)) return fail(c, TMX_ERR_BAD_ARG, "internal: layout size mismatch");
@@ -864,80 +797,36 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   HIPCK(c, hipMalloc(&c->d_nodes_t, B * (tn + 1) * 32));
   HIPCK(c, hipMalloc(&c->d_nodes_r, B * (tn + 1) * 32));
   HIPCK(c, hipMalloc(&c->d_reports, B * sizeof(tmx_report)));
-  {
-    const char* v;
-    c->k_inputs_side2 = (v = std::getenv("TMX_INPUTS_ON")) && std::string(v) == "side2";
-    c->k_proofser_hold = (v = std::getenv("TMX_PROOFSER_HOLD")) && v[0] == '1';
-    c->k_ext_events = !((v = std::getenv("TMX_EXT_EVENTS")) && v[0] == '0');
-    c->k_tiny = !((v = std::getenv("TMX_TINY")) && v[0] == '0');
-    c->k_fuse_fin = (v = std::getenv("TMX_FUSE_FIN")) ? (v[0] != '0' ? 1 : 0) : -1;
-    c->k_walk_parts = (v = std::getenv("TMX_WALK_PARTS")) ? (v[0] == '1' ? 1 : 0) : -1;
-    c->k_mul_split = (v = std::getenv("TMX_MUL_SPLIT")) ? (v[0] == '1' ? 1u : (v[0] == '4' ? 4u : 2u)) : 0u;
-    c->k_no_wide = (v = std::getenv("TMX_PROOF_WIDE")) && v[0] == '0';
-    c->k_ntt_tile_log = (v = std::getenv("TMX_NTT_TILE_LOG")) && std::atoi(v) >= 12 && std::atoi(v) <= 14 ? (uint32_t)std::atoi(v) : 0u;
-    c->k_ser_in_wgs = (v = std::getenv("TMX_SER_IN_WGS")) ? std::max(0, std::atoi(v)) : -1;
-    c->k_ser_wgs = (v = std::getenv("TMX_SER_WGS")) ? (uint32_t)std::max(0, std::atoi(v)) : 0u;
-    c->k_tail_split = (v = std::getenv("TMX_TAIL_SPLIT")) ? (v[0] != '0' ? 1 : 0) : -1;
-    c->k_proof_threads = (v = std::getenv("TMX_PROOF_THREADS")) && (std::atoi(v) == 64 || std::atoi(v) == 128 || std::atoi(v) == 256) ? (uint32_t)std::atoi(v) : 0u;
-    c->k_p1_early = (v = std::getenv("TMX_P1_EARLY")) ? (v[0] != '0' ? 1 : 0) : -1;
-    c->k_leaves = (v = std::getenv("TMX_LEAVES")) ? (v[0] != '0' ? 1 : 0) : -1;
-  }
-  const char* ss = std::getenv("TMX_SER_SPLIT");
-  c->ser_split = !(ss && ss[0] == '0');
-  const char* mode = std::getenv("TMX_EDDSA");
-  c->quad = !(mode && std::string(mode) == "mono");
-  // fixed-base table of B: signed windows of base_w bits (the one-thread-per-lane kernel keeps the 4-bit table it was written for).
-  // 10 bits = 26 additions per s*B from a 2.1 MB table (13313 entries) that stays in every XCD's 4 MB L2; 8 bits: 32 additions, 655 KB.
-  const char* bw = std::getenv("TMX_BASE_W");
-  // (13-bit windows: 20 table additions per s*B instead of 26 with 10-bit ones, from a 23 MB table instead of 1.2 MB: step -1.5 % at 256
-  // proofs x 128, -1.7 % on the one-set batch, +-0 at 32 and 1024 proofs; TMX_BASE_W=4|8|10|13)
-  c->base_w = !c->quad ? 4u : (bw && std::atoi(bw) == 4) ? 4u : (bw && std::atoi(bw) == 8) ? 8u : (bw && std::atoi(bw) == 10) ? 10u : 13u;
-  HIPCK(c, hipMalloc(&c->d_table, base_table_bytes(c->base_w)));
-  int rc = launch_init_base(c->d_table, c->base_w, c->side2);
+  // fixed-base table of B (13-bit signed windows: kernels.hip BASE_W), affine form, then the quad layout the kernels read
+  HIPCK(c, hipMalloc(&c->d_table, base_table_bytes()));
+  int rc = launch_init_base(c->d_table, c->side2);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_init_base launch: ") + hipGetErrorString((hipError_t)rc));
-  HIPCK(c, hipMalloc(&c->d_qtable, quad_table_bytes(c->base_w)));
+  HIPCK(c, hipMalloc(&c->d_qtable, quad_table_bytes()));
   HIPCK(c, hipMalloc(&c->d_pre, lanes * pre_bytes_per_lane()));
   HIPCK(c, hipMalloc(&c->d_mulout, lanes * mulout_bytes_per_lane()));
   {
-    const char* dm = std::getenv("TMX_DEDUP");
-    if (dm && dm[0] >= '0' && dm[0] <= '2') c->dedup_mode = (uint32_t)(dm[0] - '0');
-    if (lanes > ((size_t)1 << 30)) return fail(c, TMX_ERR_CAPACITY, "max_batch * n_max exceeds 2^30 lanes");
     uint64_t cap = 1;
-    while (cap < 2 * (uint64_t)lanes) cap <<= 1;  // <= 2^31: the open-addressing table of the key deduplication
+    while (cap < 2 * (uint64_t)lanes) cap <<= 1;  // <= 2^31: the open-addressing table of the launch's own key deduplication
     c->hash_mask = (uint32_t)(cap - 1);
-    // tables pay off from ~4 lanes per key; automatic mode asks for 8, so lanes/8 keys suffice (mode 2: as many as fit)
-    size_t kc = c->dedup_mode == 2 ? lanes : (lanes + 7) / 8;
-    if (kc < 16) kc = lanes < 16 ? lanes : 16;
-    if (kc > 4096) kc = 4096;
-    c->key_cap = (uint32_t)kc;
     HIPCK(c, hipMalloc(&c->d_hash, (size_t)cap * 4));
     HIPCK(c, hipMalloc(&c->d_cnt, 32));
     HIPCK(c, hipMemsetAsync(c->d_hash, 0xff, (size_t)cap * 4, c->side2));
-    HIPCK(c, hipEventRecord(c->ev_hash_clean, c->side2));
     HIPCK(c, hipMemsetAsync(c->d_cnt, 0, 32, c->side2));
     HIPCK(c, hipMalloc(&c->d_owner_of, lanes * 4));
-    HIPCK(c, hipMalloc(&c->d_uid_of_owner, lanes * 4));
+    HIPCK(c, hipMalloc(&c->d_slot_of_owner, lanes * 4));
+    HIPCK(c, hipMalloc(&c->d_slot_of_uid, lanes * 4));
     HIPCK(c, hipMalloc(&c->d_owners, lanes * 4));
-    HIPCK(c, hipMalloc(&c->d_keyrec, lanes * key_bytes_per_key()));
-    {
-      const char* kw = std::getenv("TMX_KEY_W");  // window width of the per-key tables
-      c->key_w = (kw && std::atoi(kw) == 4) ? 4u : 6u;
-      const char* a16 = std::getenv("TMX_ANCHOR16");  // 0: the doubling chain of the tables in the quad form (one quad per key)
-      c->anchor16 = (a16 && a16[0] == '0') ? 0u : 1u;
-      const char* p1s = std::getenv("TMX_P1_SIDE");
-      // 0: phase 1 on the caller's stream, 1: on side3 (input sections behind it), 2: its s*B role on side3; default: by batch size
-      c->p1_side = p1s ? (uint32_t)(p1s[0] - '0') : 3u;
-      if (c->p1_side > 3) c->p1_side = 3;
-      const char* m16 = std::getenv("TMX_MUL16");
-      c->mul16 = (m16 && m16[0] == '0') ? 0u : 1u;
-      const char* k16 = std::getenv("TMX_KEYS16");
-      c->keys16 = (k16 && k16[0] == '0') ? 0u : 1u;
-    }
-    HIPCK(c, hipMalloc(&c->d_anchors, kc * anchor_bytes_per_key(c->key_w)));
-    HIPCK(c, hipMalloc(&c->d_keytab, kc * keytab_bytes_per_key(c->key_w)));
   }
-  rc = launch_init_base_quad(c->d_table, c->d_qtable, c->base_w, c->side2);
+  // key cache: by default room for the keys of 4 x max_batch x n_max lanes at 8 lanes per key, between 1024 and 16384 keys (215 KB each:
+  // 0.2 - 3.5 GB of the 288 GB); TMX_KEY_CACHE_KEYS / tmx_key_cache_resize choose another capacity
+  {
+    size_t keys = c->knobs.key_cache_keys ? c->knobs.key_cache_keys : std::min<size_t>(16384, std::max<size_t>(1024, lanes / 2));
+    int32_t st = alloc_key_cache(c, (uint32_t)keys);
+    if (st) return st;
+  }
+  rc = launch_init_base_quad(c->d_table, c->d_qtable, c->side2);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_init_base_quad launch: ") + hipGetErrorString((hipError_t)rc));
+  HIPCK(c, hipEventRecord(c->ev_hash_clean, c->side2));
   HIPCK(c, hipStreamSynchronize(c->side2));
   return TMX_OK;
 }
@@ -950,17 +839,75 @@ static int32_t ensure_host_stream(tmx_ctx* c) {
 }
 void* tmx_ctx_stream(tmx_ctx* c) { return c && ensure_host_stream(c) == TMX_OK ? reinterpret_cast<void*>(c->stream) : nullptr; }
 
-// distinct public keys seen by the last EdDSA launch and whether the per-key table path was taken (blocks until that launch is done)
+// Nothing of this context may be in flight when the cache is reshaped: wait for the last batch and the side streams' tails.
+static int32_t quiesce(tmx_ctx* c) {
+  HIPCK(c, hipSetDevice(c->cfg.device));
+  if (c->last_stream_valid) HIPCK(c, hipEventSynchronize(c->ev_done));
+  HIPCK(c, hipStreamSynchronize(c->side2));
+  HIPCK(c, hipStreamSynchronize(c->side));
+  HIPCK(c, hipStreamSynchronize(c->side3));
+  if (c->stream) HIPCK(c, hipStreamSynchronize(c->stream));
+  return TMX_OK;
+}
+static int32_t read_kc_state(tmx_ctx* c, uint32_t st[KC_STATE_WORDS]) {
+  int32_t q = quiesce(c);
+  if (q) return q;
+  HIPCK(c, hipMemcpy(st, c->kc.d_state, KC_STATE_WORDS * 4, hipMemcpyDeviceToHost));
+  return TMX_OK;
+}
+
+// distinct effective public keys among the lanes of the last EdDSA launch (resident ones that were hit + new ones) and whether any lane
+// walked a per-key table (blocks until that launch is done)
 int32_t tmx_last_dedup(tmx_ctx* c, uint32_t* n_unique, uint32_t* used_tables) {
   if (!c || !n_unique || !used_tables) return TMX_ERR_BAD_ARG;
   *n_unique = 0; *used_tables = 0;
-  if (!c->quad || !c->d_cnt) return TMX_OK;
-  if (c->last_tiny) { *n_unique = c->last_lanes; return TMX_OK; }  // no deduplication in a tiny launch: every lane its own key
-  HIPCK(c, hipDeviceSynchronize());
-  uint32_t v = 0;
-  HIPCK(c, hipMemcpy(&v, reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1), 4, hipMemcpyDeviceToHost));
-  *n_unique = v;
-  *used_tables = (c->dedup_mode != 0 && v <= c->key_cap && (c->dedup_mode == 2 || (uint64_t)v * 8 <= c->last_lanes)) ? 1u : 0u;
+  if (c->last_lanes == 0) return TMX_OK;
+  uint32_t st[KC_STATE_WORDS];
+  int32_t r = read_kc_state(c, st);
+  if (r) return r;
+  *n_unique = st[KC_LAST_NEW] + st[KC_LAST_HIT_KEYS];
+  *used_tables = (c->knobs.dedup_mode != 0 && (st[KC_LAST_HIT_LANES] != 0 || (st[KC_LAST_BUILT] != 0 && st[KC_LAST_USE_NEW] != 0))) ? 1u : 0u;
+  return TMX_OK;
+}
+
+int32_t tmx_key_cache_stats(tmx_ctx* c, tmx_key_cache_info* out) {
+  if (!c || !out) return TMX_ERR_BAD_ARG;
+  uint32_t st[KC_STATE_WORDS];
+  int32_t r = read_kc_state(c, st);
+  if (r) return r;
+  uint64_t tot[8];
+  std::memcpy(tot, st + KC_TOTALS, sizeof(uint64_t) * 6);
+  std::memset(out, 0, sizeof *out);
+  out->capacity_keys = c->kc.cap; out->resident_keys = st[KC_RESIDENT]; out->enabled = c->kc.persist; out->epoch = st[KC_EPOCH];
+  out->bytes_per_key = keytab_bytes_per_key() + key_bytes_per_key() + 32;
+  out->last_new_keys = st[KC_LAST_NEW]; out->last_hit_keys = st[KC_LAST_HIT_KEYS]; out->last_hit_lanes = st[KC_LAST_HIT_LANES];
+  out->last_built_keys = st[KC_LAST_BUILT];
+  out->hit_lanes = tot[KC_TOT_HIT_LANES]; out->miss_lanes = tot[KC_TOT_MISS_LANES]; out->built_keys = tot[KC_TOT_BUILT];
+  out->evicted_keys = tot[KC_TOT_EVICTED]; out->evictions = tot[KC_TOT_GC_RUNS]; out->launches = tot[KC_TOT_LAUNCHES];
+  return TMX_OK;
+}
+
+int32_t tmx_key_cache_flush(tmx_ctx* c) {
+  if (!c) return TMX_ERR_BAD_ARG;
+  int32_t q = quiesce(c);
+  if (q) return q;
+  int rc = launch_kc_reset(c->kc, c->side2);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_kc_reset launch: ") + hipGetErrorString((hipError_t)rc));
+  HIPCK(c, hipStreamSynchronize(c->side2));
+  return TMX_OK;
+}
+
+int32_t tmx_key_cache_config(tmx_ctx* c, uint32_t enabled, uint32_t max_keys) {
+  if (!c) return TMX_ERR_BAD_ARG;
+  int32_t q = quiesce(c);
+  if (q) return q;
+  c->knobs.key_cache = enabled != 0;
+  if (max_keys != 0 && max_keys != c->kc.cap) {
+    int32_t st = alloc_key_cache(c, max_keys);
+    if (st) return st;
+    HIPCK(c, hipStreamSynchronize(c->side2));
+  }
+  c->kc.persist = enabled ? 1u : 0u;
   return TMX_OK;
 }
 
@@ -1020,7 +967,10 @@ int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const
   if (kind == TMX_KIND_SKIP && !d_trusteds) return fail(c, TMX_ERR_BAD_ARG, "skip needs the trusted hash fields");
   if (n_proofs > c->cfg.max_batch) return fail(c, TMX_ERR_CAPACITY, "n_proofs exceeds the context's max_batch");
   if (n_proofs == 0) return TMX_OK;
-  if ((sections & TMX_TRACE_LADDERS) && !c->d_trace_tmp) {  // 61 KB per ladder between the two ladder passes: allocated on first use
+  // the trace kernels read the Level-1 lane records of the context: they must be those of a batch of this kind and at least this size
+  if (c->last_kind != kind || c->last_n_proofs < n_proofs)
+    return fail(c, TMX_ERR_BAD_ARG, "tmx_trace_rows_device: call tmx_witness_batch_device for the same batch (kind, >= n_proofs) first");
+  if ((sections & TMX_TRACE_LADDERS) && !c->d_trace_tmp) {  // 61 KB per ladder between the two ladder passes: allocated (blocking) on the first call
     HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, hipMalloc(&c->d_trace_tmp, trace_tmp_bytes(c->cfg.n_max, c->cfg.max_batch)));
   }
@@ -1030,32 +980,28 @@ int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const
   int rc = 0;
   if (sections & TMX_TRACE_LADDERS) {
     // The chain (pass 1: 1024 latency-bound waves per 256 proofs) in four segments of 64 rows on the caller's stream; the affine rows of a
-    // segment (pass 2: issue-bound) follow on the side stream while the next segment is being doubled.  TMX_TRACE_SEGMENTS=1: one after the other.
-    const char* sg = std::getenv("TMX_TRACE_SEGMENTS");
-    const uint32_t segs = sg && sg[0] == '1' ? 1u : 4u;
+    // segment (pass 2: issue-bound) follow on the side stream while the next segment is being doubled (one after the other: 7.25 vs 6.7 ms).
+    const uint32_t segs = 4;
     for (auto& e : c->ev_trace)
       if (!e) HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (uint32_t g = 0; g < segs && !rc; g++) {
       const uint32_t r0 = TR_LADDER_ROWS * g / segs, r1 = TR_LADDER_ROWS * (g + 1) / segs;
       rc = launch_trace_ladder_pass1(n, n_proofs, d_targets, edr, TL_STRIDE, c->d_trace_tmp, r0, r1, s);
       if (rc) break;
-      hipStream_t p2 = segs > 1 ? c->side : s;
-      if (segs > 1) {
+      hipStream_t p2 = c->side;
+      {
         HIPCK(c, hipEventRecord(c->ev_trace[g], s));
         HIPCK(c, hipStreamWaitEvent(p2, c->ev_trace[g], 0));
       }
       rc = launch_trace_ladder_pass2((uint32_t)kind, n, n_proofs, d_targets, edr, TL_STRIDE, c->d_trace_tmp, d_trace_out, r0, r1, p2);
     }
-    if (!rc && segs > 1) {
+    if (!rc) {
       HIPCK(c, hipEventRecord(c->ev_trace[4], c->side));
     }
   }
   if (!rc && (sections & ~(uint32_t)TMX_TRACE_LADDERS)) rc = launch_trace_rest((uint32_t)kind, n, n_proofs, d_targets, d_trusteds, d_trace_out, sections, s);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_trace launch: ") + hipGetErrorString((hipError_t)rc));
-  if ((sections & TMX_TRACE_LADDERS) && c->ev_trace[4]) {
-    const char* sg = std::getenv("TMX_TRACE_SEGMENTS");
-    if (!(sg && sg[0] == '1')) HIPCK(c, hipStreamWaitEvent(s, c->ev_trace[4], 0));  // the call ends on the caller's stream
-  }
+  if ((sections & TMX_TRACE_LADDERS) && c->ev_trace[4]) HIPCK(c, hipStreamWaitEvent(s, c->ev_trace[4], 0));  // the call ends on the caller's stream
   return TMX_OK;
 }
 
@@ -1074,7 +1020,7 @@ int32_t tmx_kernel_ms_mean(tmx_ctx* c, uint32_t last_k, float ms[TMX_N_KERNELS])
     HIPCK(c, hipEventElapsedTime(&t, ev[0], ev[1])); acc[TMX_K_EDDSA] += t;
     HIPCK(c, hipEventElapsedTime(&t, evs[0], evs[1])); acc[TMX_K_PROOF] += t;
     HIPCK(c, hipEventElapsedTime(&t, evs[2], evs[3])); acc[TMX_K_VERDICT] += t;
-    HIPCK(c, hipEventElapsedTime(&t, c->ser_split ? ev[1] : ev[2], ev[3])); acc[TMX_K_SERIALIZE] += t;
+    HIPCK(c, hipEventElapsedTime(&t, c->knobs.ser_split ? ev[1] : ev[2], ev[3])); acc[TMX_K_SERIALIZE] += t;
   }
   for (int k = 0; k < TMX_N_KERNELS; k++) ms[k] = (float)(acc[k] / last_k);
   return TMX_OK;
@@ -1115,7 +1061,7 @@ static int32_t witness_batch_host(tmx_ctx* c, int32_t kind, uint32_t n_proofs, c
   if (out && opts && cap_bytes < (uint64_t)n_proofs * row_elems * esz) return fail(c, TMX_ERR_CAPACITY, "out buffer too small");
   if (out && !opts && cap_bytes < ((uint64_t)(n_proofs - 1) * stride + count) * 8) return fail(c, TMX_ERR_CAPACITY, "out_elems too small");
   for (uint32_t p = 0; p < n_proofs; p++)  // reference input/mod.rs:439-444, 338-342
-    if (proofs[p].nb_a > n || proofs[p].nb_b > n) return fail(c, TMX_ERR_SET_TOO_LARGE, "validator set larger than VALIDATOR_SET_SIZE_MAX");
+    if (proofs[p].nb_a > n || (kind == TMX_KIND_SKIP && proofs[p].nb_b > n)) return fail(c, TMX_ERR_SET_TOO_LARGE, "validator set larger than VALIDATOR_SET_SIZE_MAX");
   int32_t st = ensure_staging(c);
   if (st) return st;
   const size_t lanes = (size_t)n_proofs * n;
@@ -1339,7 +1285,7 @@ static int32_t ntt_run(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const void* 
   // tiles of the two strided passes: T >= 8 sub-transforms side by side (runs of >= 64 B along the unit-stride dimension; with T = 4 at
   // N1 = 2^10, FETCH_SIZE was 4x the data), in the smallest tile that allows it (2^12 .. 2^14 elements: three, two or one workgroup per
   // CU's LDS).  Measured at 2^16 / 2^20 / 2^22: tiles of 2^12 / 2^13 / 2^14 elements are each the fastest there.
-  auto tile_log_of = [&](uint32_t log_l) { return c->k_ntt_tile_log ? c->k_ntt_tile_log : std::min(14u, std::max(12u, log_l + 3u)); };
+  auto tile_log_of = [&](uint32_t log_l) { return std::min(14u, std::max(12u, log_l + 3u)); };
   P.log_l = a; P.log_t = std::min(tile_log_of(a) - a, b); P.n_sub = N2; P.tiles_per_col = (uint32_t)(N2 >> P.log_t);
   P.col_stride_in = in_stride; P.t_stride_in = 1; P.j_stride_in = N2;
   P.col_stride_out = N; P.t_stride_out = 1; P.j_stride_out = N2;

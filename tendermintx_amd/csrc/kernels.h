@@ -7,55 +7,64 @@
 
 namespace tmx {
 
-size_t base_table_bytes(uint32_t w_bits);
+// persistent per-key table cache of a context (DESIGN.md "Key cache"): device pointers + geometry, passed to the kernels by value
+struct KeyCache {
+  uint32_t cap;        // slots: decoded key record + 215-KB window table each
+  uint32_t hash_mask;  // open-addressing table of (hash_mask + 1) slot ids, >= 4 * cap
+  uint32_t new_cap;    // tables one launch builds at most (anchor scratch)
+  uint32_t persist;    // 1: keys stay resident across launches; 0: every launch starts from an empty cache (same code path)
+  uint32_t* d_hash;    // [hash_mask + 1] slot id or 0xffffffff
+  uint32_t* d_pk;      // [cap][8] the 32 key bytes of a resident slot (all compared on a probe)
+  uint32_t* d_used;    // [cap] epoch of the last launch that used the slot; 0 = free
+  uint32_t* d_free;    // [cap] free list: d_free[free_head .. n_free) are free slots
+  uint32_t* d_state;   // KC_STATE_WORDS words, indices below
+};
+enum : uint32_t { KC_FREE_HEAD = 0, KC_N_FREE = 1, KC_EPOCH = 2, KC_RESIDENT = 3, KC_LAST_NEW = 4, KC_LAST_HIT_KEYS = 5, KC_LAST_HIT_LANES = 6,
+                  KC_LAST_BUILT = 7, KC_LAST_USE_NEW = 8, KC_TOTALS = 16 /* u64 counters from this word on */, KC_STATE_WORDS = 32 };
+enum : uint32_t { KC_TOT_HIT_LANES = 0, KC_TOT_MISS_LANES = 1, KC_TOT_BUILT = 2, KC_TOT_EVICTED = 3, KC_TOT_GC_RUNS = 4, KC_TOT_LAUNCHES = 5 };
+
+size_t base_table_bytes();
 // each returns a hipError_t value (0 = success); all launches are asynchronous on `stream` (hipStream_t)
-int launch_init_base(void* d_table, uint32_t w_bits, void* stream);
+int launch_init_base(void* d_table, void* stream);
 int launch_selftest_invert(uint32_t n, const void* d_in, void* d_out, void* stream);
 int launch_selftest_f16(uint32_t n, uint32_t doublings, const void* d_in, void* d_out, void* stream);
-int launch_eddsa(uint32_t n_lanes, const void* d_target, void* d_ed, uint32_t ed_stride, const void* d_table, void* stream);
-// quad-parallel EdDSA path.  Three launch groups so that api.cpp can run the key pipeline on a side stream:
-//   keys pipeline (dedup -> decode distinct keys -> optional per-key tables)  ||  phase 1 (decode R, SHA-512 mod l, s*B)
-//   then h*A + finish
+// EdDSA stage.  Launch groups so that api.cpp can run the key pipeline on a side stream:
+//   key pipeline (dedup -> decode new keys -> their tables -> cache epilogue)  ||  phase 1 (SHA-512 mod l, s*B)
+//   then h*A (table walk for lanes whose key has a table, table-free form for the others) + finish
 struct EdQuad {
   uint32_t n_lanes;
   const void* d_target;
   void* d_ed;
   uint32_t ed_stride;
   const void* d_qtable;
-  uint32_t base_w;   // window width of the fixed-base table of B (4, 8 or 10 bits)
   void *d_pre, *d_mulout;
-  void* d_hash;
+  void* d_hash;       // the launch's own dedup hash table (lanes whose key is not resident)
   uint32_t hash_mask;
-  void *d_cnt, *d_cnt_next, *d_owner_of, *d_uid_of_owner, *d_owners, *d_keyrec, *d_anchors, *d_keytab;
-  uint32_t key_w;    // window width of the per-key tables (4 or 6 bits)
-  uint32_t key_cap;  // keys the table buffers can hold
-  uint32_t mode;     // 0 never build tables, 1 automatic (>= 8 lanes per key), 2 whenever they fit
-  uint32_t mul16;    // 1: h*A of small launches without tables in the limb-parallel form (one wave per lane)
-  uint32_t keys16;   // 1: keys are decoded in the limb-parallel form when there are few enough of them
-  uint32_t anchor16; // 1: the anchor chain runs in the limb-parallel form (one wave per key), 0: one quad per key
-  uint32_t mul_split; // quads per lane in the table walk: 1, 2, 4, or 0 = by launch size (TMX_MUL_SPLIT)
-  void* fin_done;    // event attached to the k_ed_fin dispatch as its completion signal (no separate record packet), or null
+  void *d_cnt, *d_cnt_next, *d_owner_of, *d_slot_of_owner, *d_slot_of_uid, *d_owners, *d_keyrec, *d_anchors, *d_keytab;
+  KeyCache kc;
+  uint32_t mode;      // 0 never use tables, 1 automatic, 2 whenever they fit (TMX_DEDUP)
+  uint32_t use_new;   // 1: the walk is enqueued behind the table build, lanes of new keys may use their fresh tables
+  void* fin_done;     // event attached to the k_ed_fin dispatch as its completion signal (no separate record packet), or null
 };
-size_t quad_table_bytes(uint32_t w_bits);
+size_t quad_table_bytes();
 size_t pre_bytes_per_lane();
 size_t mulout_bytes_per_lane();
 size_t key_bytes_per_key();
-size_t anchor_bytes_per_key(uint32_t key_w);
-size_t keytab_bytes_per_key(uint32_t key_w);
-int launch_init_base_quad(const void* d_table, void* d_qtable, uint32_t w_bits, void* stream);
+size_t anchor_bytes_per_key();
+size_t keytab_bytes_per_key();
+int launch_init_base_quad(const void* d_table, void* d_qtable, void* stream);
+int launch_kc_reset(const KeyCache& kc, void* stream);
 // (`done`: an event signalled by the dispatch itself when the kernel completes -- saves the record packet behind it; may be null)
 int launch_ed_dedup(const EdQuad& Q, void* stream, void* done = nullptr);
-// direct_n != 0: no dedup ran, lanes 0 .. direct_n-1 are their own keys (limb-parallel form only: direct_n <= 8192, Q.keys16 set)
-int launch_ed_keys(const EdQuad& Q, void* stream, void* done = nullptr, uint32_t direct_n = 0);
+int launch_ed_keys(const EdQuad& Q, void* stream, void* done = nullptr);
 int launch_ed_tab_anchor(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream, void* done = nullptr);
 int launch_ed_tab_mult(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream, void* done = nullptr);
-// fuse_fin (launches of <= MUL16_MAX_LANES lanes with Q.mul16 only): k_ed_fin's work in the same kernel, Q.fin_done on its dispatch
+int launch_kc_epilogue(const EdQuad& Q, void* stream);
+// fuse_fin (launches of <= 2048 lanes): k_ed_fin's work for the lanes this kernel multiplies, in the same kernel
 int launch_ed_mul_direct(const EdQuad& Q, void* stream, bool fuse_fin = false);
-// roles: 0 = both (SHA-512 + mod l, then s*B), 1 = the hash role only, 2 = s*B only
-int launch_ed_phase1(const EdQuad& Q, void* stream, void* done = nullptr, int roles = 0);
-// (lane0 .. lane_end - 1: the lanes of this launch; lane_end = 0: to the end)
-int launch_ed_mul_tab(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream, uint32_t lane0 = 0, uint32_t lane_end = 0);
-int launch_ed_fin(const EdQuad& Q, void* stream, uint32_t lane0 = 0, uint32_t lane_end = 0);
+int launch_ed_phase1(const EdQuad& Q, void* stream, void* done = nullptr);
+int launch_ed_mul_tab(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream);
+int launch_ed_fin(const EdQuad& Q, void* stream, bool fused_direct = false);
 int launch_proof(const ProofParams& P, uint32_t n_proofs, const void* d_proofs, const void* d_target, const void* d_trusted, void* d_lt,
                  uint32_t lt_stride, void* d_lr, void* d_pf, void* d_nodes_t, void* d_nodes_r, void* d_reports, void* stream);
 // marshalled validators + leaf hashes of both sets as a launch of its own; k_proof then reads them (ProofParams::leaves_done)

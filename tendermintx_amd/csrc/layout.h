@@ -94,8 +94,7 @@ constexpr uint32_t TR_LADDER_ROW = 65, TR_LADDER_ROWS = 256, TR_SHA512_ROW = 18,
 
 struct ProofParams {
   uint32_t kind, n, tree_nodes, chain_id_len;
-  uint32_t no_wide;      // 1: keep 256 threads per proof above N = 256 (TMX_PROOF_WIDE=0)
-  uint32_t threads;      // threads per workgroup, 0 = by N
+  uint32_t pad0_, pad1_;
   uint32_t pad2_;
   uint32_t leaves_done;  // 1: k_leaves has written the marshalled validators and leaf hashes of this batch
   uint64_t skip_max;

@@ -113,7 +113,7 @@ SEED0 = int(os.environ.get("TMX_FUZZ_SEED0", "0"))
 @pytest.mark.parametrize("seed", range(SEED0, SEED0 + SEEDS))
 def test_fuzz_bytes_and_field_extremes(tmx, oracle, seed):
     kind, n, proofs, targets, trusteds, chain_id, skip_max = _mutated_batch(seed)
-    _check_vs_oracle(tmx, oracle, kind, n, proofs, targets, trusteds, chain_id, skip_max)
+    _check_vs_oracle(tmx, oracle, kind, n, proofs, targets, trusteds, chain_id, skip_max, repeat=2)   # cold, then from the key cache
 
 
 TRACE_SEEDS = int(os.environ.get("TMX_FUZZ_TRACE_SEEDS", "4"))

@@ -27,21 +27,23 @@ def _case_inputs(c):
     return (bytes.fromhex(c["proof"]), bytes.fromhex(c["target"]), bytes.fromhex(c["trusted"]) if c["trusted"] else None)
 
 
-def _check_vs_oracle(tmx, oracle, kind, n, proofs, targets, trusteds, chain_id, skip_max=100800, ctx=None, threads=8):
+def _check_vs_oracle(tmx, oracle, kind, n, proofs, targets, trusteds, chain_id, skip_max=100800, ctx=None, threads=8, repeat=1):
+    """repeat > 1: the same call again on the same context (its key cache now holds the batch's keys): every run must equal the oracle"""
     P = len(proofs) // 2336
     own = ctx is None
     ctx = ctx or tmx.Context(n, chain_id, skip_max, max_batch=P)
     try:
-        elems, reps = ctx.witness_batch(kind, proofs, targets, trusteds)
+        runs = [ctx.witness_batch(kind, proofs, targets, trusteds) for _ in range(repeat)]
     finally:
         if own:
             ctx.close()
     want, oreps = oracle.witness_batch(kind, P, proofs, targets, trusteds, n, chain_id, skip_max, n_threads=threads)
-    if not np.array_equal(elems, want):
-        bad = np.argwhere(elems != want)
-        raise AssertionError(f"GPU != oracle at (proof, element) {bad[:10].tolist()} ({len(bad)} differences)")
-    assert reps == oreps
-    return elems, reps
+    for k, (elems, reps) in enumerate(runs):
+        if not np.array_equal(elems, want):
+            bad = np.argwhere(elems != want)
+            raise AssertionError(f"GPU != oracle (run {k}) at (proof, element) {bad[:10].tolist()} ({len(bad)} differences)")
+        assert reps == oreps, f"run {k}"
+    return runs[0]
 
 
 # ------------------------------------------------------------------------------------------------ goldens
@@ -565,26 +567,31 @@ def test_validator_sharded_single_proof(tmx, oracle):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("knobs", [
-    {"TMX_BASE_W": "4"}, {"TMX_BASE_W": "8"}, {"TMX_BASE_W": "10"}, {"TMX_MUL_SPLIT": "1"}, {"TMX_MUL_SPLIT": "2"}, {"TMX_MUL_SPLIT": "4"}, {"TMX_TINY": "0"}, {"TMX_FUSE_FIN": "0"}, {"TMX_KEY_W": "4"}, {"TMX_KEY_W": "4", "TMX_MUL_SPLIT": "1"}, {"TMX_WALK_PARTS": "1"}, {"TMX_WALK_PARTS": "1", "TMX_TAB_PARTS": "4"},
-    {"TMX_TAB_PARTS": "1"}, {"TMX_PROOFSER_HOLD": "1"}, {"TMX_EXT_EVENTS": "0"}, {"TMX_ANCHOR16": "0"}, {"TMX_KEYS16": "0"}, {"TMX_MUL16": "0"},
-    {"TMX_P1_SIDE": "1"}, {"TMX_P1_SIDE": "2"}, {"TMX_DEDUP": "0"}, {"TMX_DEDUP": "2"},
-    {"TMX_LEAVES": "1"}, {"TMX_LEAVES": "0", "TMX_P1_EARLY": "1"}, {"TMX_LEAVES": "1", "TMX_SER_SPLIT": "0"},
-    {"TMX_SER_SPLIT": "0"}, {"TMX_TAIL_SPLIT": "1"}, {"TMX_TAIL_SPLIT": "1", "TMX_DEDUP": "0"}, {"TMX_SER_IN_WGS": "0"}, {"TMX_SER_IN_WGS": "7", "TMX_SER_WGS": "5"}, {"TMX_SER_SPAN": "128", "TMX_SER_WGS": "33"}, {"TMX_SER_SPAN": "128"}, {"TMX_SER_SPAN": "512"}, {"TMX_EDDSA": "mono"}], ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+KNOBS = [
+    {"TMX_DEDUP": "0"}, {"TMX_DEDUP": "2"}, {"TMX_KEY_CACHE": "0"}, {"TMX_KEY_CACHE": "0", "TMX_DEDUP": "2"}, {"TMX_KEY_CACHE_KEYS": "40"},
+    {"TMX_WALK_PARTS": "1"}, {"TMX_WALK_PARTS": "1", "TMX_TAB_PARTS": "4"}, {"TMX_TAB_PARTS": "1"}, {"TMX_TAB_PARTS": "4", "TMX_KEY_CACHE": "0"},
+    {"TMX_EXT_EVENTS": "0"}, {"TMX_LEAVES": "1"}, {"TMX_LEAVES": "0", "TMX_P1_EARLY": "1"}, {"TMX_LEAVES": "1", "TMX_SER_SPLIT": "0"},
+    {"TMX_SER_SPLIT": "0"}, {"TMX_SER_SPLIT": "0", "TMX_KEY_CACHE": "0"}]
+
+
+@pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
 def test_schedule_knobs_give_the_same_bits(tmx, oracle, monkeypatch, knobs):
-    """Every tuning knob changes a schedule (window widths, table use, launch splitting, the first-generation kernel), never a value:
-    a repeated-validator-set batch (tables, dummy lanes, a failing signature) is bit-exact vs the oracle under each of them."""
+    """Every knob the product keeps (api.cpp `Knobs`) changes a schedule -- table use, the key cache, launch splitting, the order of the
+    serializer launches -- never a value: a repeated-validator-set batch at N = 128 (new-key tables built in parts, dummy lanes, a failing
+    signature) is bit-exact vs the oracle under each of them, cold and then warm on the same context, followed by a single proof."""
     from tendermintx_amd.synth import Workload
     for k, v in knobs.items():
-        monkeypatch.setenv(k, v)      # read at context creation / launch time
-    n, P = 16, 20
-    wl = Workload(0, n, P, 13, chain_id=b"celestia", seed=4242, signed_permille=850)
+        monkeypatch.setenv(k, v)      # read at context creation
+    n, P = 128, 20                    # 2560 lanes: above the 2048 at which the table build is cut into parts
+    wl = Workload(0, n, P, 100, chain_id=b"celestia", seed=4242, signed_permille=850)
     targets = bytearray(wl.targets)
     lane = next(l for l in range(n) if targets[l * 256 + 223] & 1)   # a lane of proof 0 that did sign
     targets[lane * 256 + 40] ^= 0x10  # corrupt its signature (R): the equation must fail on exactly that lane
     with tmx.Context(n, b"celestia", max_batch=P) as ctx:
-        _, reps = _check_vs_oracle(tmx, oracle, 0, n, wl.proofs, bytes(targets), wl.trusteds, b"celestia", ctx=ctx)
-    assert reps[0]["first_bad_sig"] == lane and not reps[0]["all_ok"] and all(r["first_bad_sig"] == -1 for r in reps[1:])
+        for _ in range(2):
+            _, reps = _check_vs_oracle(tmx, oracle, 0, n, wl.proofs, bytes(targets), wl.trusteds, b"celestia", ctx=ctx)
+            assert reps[0]["first_bad_sig"] == lane and not reps[0]["all_ok"] and all(r["first_bad_sig"] == -1 for r in reps[1:])
+        _check_vs_oracle(tmx, oracle, 0, n, wl.proofs[2336:2 * 2336], bytes(targets[n * 256:2 * n * 256]), wl.trusteds[n * 48:2 * n * 48], b"celestia", ctx=ctx)
 
 
 def test_many_distinct_keys_take_the_throughput_forms(tmx, oracle):
@@ -601,25 +608,30 @@ def test_many_distinct_keys_take_the_throughput_forms(tmx, oracle):
     with tmx.Context(128, b"celestia", max_batch=(n_lanes + 127) // 128) as ctx:
         got = ctx.eddsa_lanes(lanes)
         uniq, tables = ctx.last_dedup()
-    assert uniq == n_lanes and not tables
+        assert uniq == n_lanes and not tables
+        # the same lanes again: the keys the cache had room for now walk their tables, the rest keep the table-free form -- same bits
+        again = ctx.eddsa_lanes(lanes)
+        uniq2, tables2 = ctx.last_dedup()
+        st = ctx.key_cache_stats()
+        assert uniq2 == n_lanes and tables2 and 0 < st["last_hit_lanes"] < n_lanes
+        assert np.array_equal(got, again)
     for i in list(range(0, n_lanes, 37)) + [n_lanes - 1]:
         want = _ed_record(oracle.eddsa_trace(pks[i].tobytes(), sigs[i].tobytes(), msgs[i].tobytes()))
         assert bytes(got[i]) == want, f"lane {i}"
 
 
 def test_key_dedup_paths(tmx, oracle):
-    if os.environ.get("TMX_EDDSA") == "mono":
-        pytest.skip("the first-generation kernel has no key deduplication")
-    """The EdDSA stage decodes every distinct public key once and, when keys repeat (>= 8 lanes per key), walks per-key fixed-base
-    tables instead of doubling: both schedules must give the same bits.  Batches: one validator set repeated (tables), every proof
-    with its own validator set (direct), and a mix just around the switch-over."""
+    """The EdDSA stage decodes every distinct public key once and walks per-key fixed-base tables instead of doubling when the key is
+    resident in the key cache or repeats inside the launch (>= 8 lanes per key): every schedule must give the same bits.  Batches: one
+    validator set repeated (fresh tables), every proof with its own validator set (table-free form; tables built for later), and a mix
+    of resident and new keys."""
     from tendermintx_amd.synth import Workload
     n = 16
 
     def cat(wls):
         return b"".join(w.proofs for w in wls), b"".join(w.targets for w in wls), b"".join(w.trusteds for w in wls)
 
-    same = Workload(0, n, 40, 16, chain_id=b"celestia", seed=1, signed_permille=1000)  # 640 lanes (launches of <= 512 lanes skip the dedup)
+    same = Workload(0, n, 40, 16, chain_id=b"celestia", seed=1, signed_permille=1000)  # 640 lanes (launches of <= 512 lanes never wait for fresh tables)
     distinct = [Workload(0, n, 1, 16, chain_id=b"celestia", seed=100 + i, signed_permille=1000) for i in range(24)]
     mixed = [Workload(0, n, 12, 16, chain_id=b"celestia", seed=7, signed_permille=900)] + distinct[:6]
     with tmx.Context(n, b"celestia", max_batch=40) as ctx:
@@ -631,7 +643,7 @@ def test_key_dedup_paths(tmx, oracle):
         _, reps = _check_vs_oracle(tmx, oracle, 0, n, p, t, r, b"celestia", ctx=ctx)
         assert all(x["all_ok"] for x in reps)
         uniq, tables = ctx.last_dedup()
-        assert uniq == 24 * 16 and not tables              # every key once: direct h*A
+        assert uniq == 24 * 16 and not tables              # every key new and seen once: table-free h*A
         p, t, r = cat(mixed)
         _, reps = _check_vs_oracle(tmx, oracle, 0, n, p, t, r, b"celestia", ctx=ctx)
         uniq, tables = ctx.last_dedup()
