@@ -73,6 +73,7 @@ struct Program {
   std::vector<uint32_t> seam_waves;  // indices of the spans that straddle a boundary (0xff entries of wave_sec)
   std::vector<uint8_t> wave_sec;  // per sp.span-element span of a row: its section, or 0xff if it straddles a boundary / the row end
   uint32_t hint_elems;
+  uint32_t d1b_start = 0;  // first element of D.1b in a row (the EdDSA finish writes that section directly: RowOut)
   uint32_t mask_hint = 0, mask_derived = 0;  // sections of H / of D (tmx_witness_batch_opts: a caller may ask for one of them only)
 };
 
@@ -160,6 +161,8 @@ Program build_program(int kind, uint32_t n) {
   for (int f = 0; f < 6; f++) L.u8(TL_OFF_LT + LN_OFF_FLAGS + f);
   L.u64(TL_OFF_LT + LN_OFF_TOT);
   L.u64(TL_OFF_LT + LN_OFF_ACC);
+  P.d1b_start = elem;
+  if ((uint32_t)L.v.size() - mark != D1B_LANE_ELEMS) P.d1b_start = 0xffffffffu;  // (caught by tmx_ctx_create: layout.h and this list must agree)
   add_section((uint32_t)L.v.size() - mark, n, mark, SEC_LUT, SRC_TL, 2);
 
   // D.2a / D.2b per trusted lane: byte fields (marshalled validator, leaf hash: ready with the leaves), word fields (flags, prefix sums: k_proof)
@@ -208,7 +211,7 @@ Program build_program(int kind, uint32_t n) {
   P.sp.n = n;
   P.sp.tree_nodes = tn;
   P.lut = std::move(L.v);
-  const uint32_t span = 256;  // elements per wave: 128 and 512 measured slower on MI355X (tools/ser_span_ab.py, round 1)
+  const uint32_t span = 256;  // elements per wave: 128 and 512 measured slower on MI355X (round 1)
   P.sp.span = span;
   for (uint32_t w = 0; w * span < P.sp.elem_stride; w++) {
     const uint32_t first = w * span, last = first + span - 1;
@@ -241,6 +244,7 @@ struct Knobs {
   int walk_parts = -1;       // TMX_WALK_PARTS=0|1: the table walk follows the table build part by part (default: from 65536 lanes)
   uint32_t tab_parts = 2;    // TMX_TAB_PARTS=1|2|4: launches the anchor chain of new keys is cut into
   bool ext_events = true;    // TMX_EXT_EVENTS=0: record packets instead of completion signals on the chain kernels
+  int warm_schedule = -1;    // TMX_SCHEDULE=warm|cold: the EdDSA schedule for resident / new keys (default: by what the last launch saw)
 };
 static Knobs read_knobs() {
   Knobs k;
@@ -254,6 +258,7 @@ static Knobs read_knobs() {
   k.walk_parts = (v = std::getenv("TMX_WALK_PARTS")) ? (v[0] == '1' ? 1 : 0) : -1;
   if ((v = std::getenv("TMX_TAB_PARTS")) && (std::atoi(v) == 1 || std::atoi(v) == 2 || std::atoi(v) == 4)) k.tab_parts = (uint32_t)std::atoi(v);
   k.ext_events = !((v = std::getenv("TMX_EXT_EVENTS")) && v[0] == '0');
+  k.warm_schedule = (v = std::getenv("TMX_SCHEDULE")) ? (v[0] == 'w' ? 1 : 0) : -1;
   return k;
 }
 
@@ -271,6 +276,9 @@ struct tmx_ctx {
   hipEvent_t ev_tail = nullptr, ev_fork2 = nullptr, ev_hash_clean = nullptr, ev_keys = nullptr;
   bool fin_done_attached = false;
   void* fin_done = nullptr;  // set by run_batch around the EdDSA producer: the event k_ed_fin signals
+  RowOut row = {};           // set by run_batch around the EdDSA producer: where the finish writes D.1b into the rows (or null)
+  hipEvent_t ev_direct = nullptr;  // the table-free lanes of a launch are done (side2)
+  volatile uint32_t* h_hint = nullptr;  // page-locked, written by k_kc_epilogue: [0] launches committed, [1] new keys of the last one
   hipEvent_t ev_part[4] = {};
   bool have_streams = false;
   // ring of HIP-event sets: one set (TMX_N_KERNELS + 1 events) per enqueued batch, so that kernel durations can be
@@ -348,7 +356,7 @@ static ProofParams proof_params(const tmx_ctx* c, int32_t kind, bool leaves_done
 // c->d_tl on s (the EdDSA kernels, or a strided copy of caller-provided lane records).
 template <typename EdProducer>
 static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets, const void* d_trusteds,
-                         void* d_out_elems, void* d_reports, hipStream_t s, EdProducer ed_producer) {
+                         void* d_out_elems, void* d_reports, hipStream_t s, bool eddsa_writes_rows, EdProducer ed_producer) {
   const uint32_t n = c->cfg.n_max;
   const Knobs& K = c->knobs;
   uint8_t* tl = reinterpret_cast<uint8_t*>(c->d_tl);
@@ -414,8 +422,18 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   c->fin_done = K.ext_events ? ev[1] : nullptr;
   c->fin_done_attached = false;
   c->ev_hash_recorded = false;
+  // D.1b (the word fields of the per-target-lane derived values: h, the ten coordinates, the verdict) goes straight from the EdDSA
+  // finish into the rows when the EdDSA kernels run here (and k_verdict adds the lane's ten k_proof-derived elements): no serializer
+  // launch behind the last kernel of the chain.  A producer that copies caller-provided lane records leaves the section to the serializer.
+  RowOut row = {};
+  if (eddsa_writes_rows && d_out_elems && (c->sections & TMX_SEC_DERIVED)) {
+    row.rows = reinterpret_cast<uint64_t*>(d_out_elems); row.elem_stride = prog.sp.elem_stride; row.n = n; row.d1b_start = prog.d1b_start;
+  }
+  const uint32_t mask_final = row.rows ? 0u : prog.mask_final;
+  c->row = row;
   int32_t st = ed_producer(s);
   c->fin_done = nullptr;
+  c->row = RowOut{};
   if (st) return st;
   if (leaves_first) {  // side3, behind the input sections and D.2a: D.1a as soon as phase 1 is done; ev_join3 moves behind it
     if (!c->ev_hash_recorded) HIPCK(c, hipEventRecord(c->ev_hash, s));  // (a producer without a phase-1 event: everything it enqueued)
@@ -442,10 +460,10 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
     const bool xv = K.ext_events && n_proofs != 0;  // the verdict's two timing events ride on its dispatch
     if (!xv) HIPCK(c, hipEventRecord(evs[2], s));
-    rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, s, xv ? evs[2] : nullptr, xv ? evs[3] : nullptr);
+    rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, row, s, xv ? evs[2] : nullptr, xv ? evs[3] : nullptr);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
     if (!xv) HIPCK(c, hipEventRecord(evs[3], s));
-    if ((st0 = serialize(prog.mask_final | prog.mask_p1 | prog.mask_tail, s))) return st0;
+    if ((st0 = serialize(mask_final | (p1_early ? 0u : prog.mask_p1) | prog.mask_tail, s))) return st0;
     HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
   } else if (K.ser_split) {
     // tail: the per-lane derived section (a quarter of the row) only needs k_ed_fin + k_proof, so it is written on s while the
@@ -454,23 +472,25 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     HIPCK(c, hipStreamWaitEvent(c->side2, ev[1], 0));
     HIPCK(c, hipStreamWaitEvent(c->side2, evs[1], 0));  // k_proof itself, not the serializer launches queued behind it
     HIPCK(c, hipEventRecord(evs[2], c->side2));
-    rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, c->side2);
+    rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, row, c->side2);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
     HIPCK(c, hipEventRecord(evs[3], c->side2));
     if ((st0 = serialize(prog.mask_tail, c->side2))) return st0;
     HIPCK(c, hipStreamWaitEvent(c->side2, c->ev_join, 0));  // ev_tail = every side stream done
     HIPCK(c, hipEventRecord(c->ev_tail, c->side2));
-    HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
-    if ((st0 = serialize(prog.mask_final | (p1_early ? 0u : prog.mask_p1), s))) return st0;
+    if (mask_final | (p1_early ? 0u : prog.mask_p1)) {
+      HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
+      if ((st0 = serialize(mask_final | (p1_early ? 0u : prog.mask_p1), s))) return st0;
+    }
     HIPCK(c, hipStreamWaitEvent(s, c->ev_tail, 0));
   } else {
     HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
     HIPCK(c, hipEventRecord(evs[2], s));
-    rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, s);
+    rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, row, s);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
     HIPCK(c, hipEventRecord(evs[3], s));
     HIPCK(c, hipEventRecord(ev[2], s));
-    if ((st0 = serialize(prog.mask_inputs | prog.mask_proof | prog.mask_leaves | prog.mask_final | prog.mask_p1 | prog.mask_tail, s))) return st0;
+    if ((st0 = serialize(prog.mask_inputs | prog.mask_proof | prog.mask_leaves | mask_final | prog.mask_p1 | prog.mask_tail, s))) return st0;
   }
   HIPCK(c, hipEventRecord(ev[3], s));
   c->last_stream = s; c->last_stream_valid = true;
@@ -487,11 +507,16 @@ static int32_t check_batch_args(tmx_ctx* c, int32_t kind, uint32_t n_proofs, con
   return TMX_OK;
 }
 
-// EdDSA stage: begins and ends on stream s.
-//   s:      k_ed_dedup -> k_ed_phase1 -> [keys done] k_ed_mul* (table-free lanes) -> [tables done] k_ed_mul_tab -> k_ed_fin
-//   side2:  (after the dedup) k_ed_keys -> k_ed_tab_anchor16 / k_ed_tab_mult of the new keys -> k_kc_epilogue
-// With a warm key cache (every lane's key resident) the side2 kernels are empty launches that end long before phase 1 does and the
-// chain on s is dedup -> phase 1 -> walk -> finish.
+// EdDSA stage: begins and ends on stream s.  The new-key pipeline (decode -> doubling chain -> window tables -> cache epilogue) runs on
+// the high-priority stream side2; what s does beside it depends on what the launch EXPECTS (the epilogue of the last finished launch left
+// a hint in page-locked memory: did it see new keys?) -- either schedule is correct for any input, the expectation only picks the faster:
+//   cold (new keys expected):  s: dedup -> phase 1 (hash | s*B) -> [keys] table-free lanes -> [tables, part by part] walk -> finish
+//   warm (keys resident):      s: dedup -> hash -> [tables] walk -> [s*B and the table-free lanes, on side2] -> finish
+//                              -- the walk waits for the hash role only, nothing empty is launched on s, the new-key kernels are
+//                              small grids that find nothing to do long before the hash role ends, and s*B (which only the finish
+//                              needs) fills the machine beside the 512 latency-bound waves of the hash role
+//   tiny (<= 512 lanes):       s: dedup -> phase 1 -> walk of the resident keys -> [table-free lanes + their finish, on side2] -> finish;
+//                              never waits for tables: the tables of new keys are built on side2 for the next call
 static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_ed, uint32_t ed_stride, hipStream_t s) {
   const Knobs& K = c->knobs;
   EdQuad Q;
@@ -501,15 +526,16 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   Q.d_anchors = c->d_anchors; Q.d_keytab = c->d_keytab;
   Q.kc = c->kc; Q.mode = K.dedup_mode;
   Q.fin_done = c->fin_done; c->fin_done = nullptr;
+  Q.row = c->row;
   c->last_lanes = n_lanes;
   Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * c->parity;
   Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1);
   c->parity ^= 1;
-  // Tiny launches (a single proof, up to 512 lanes) are pure latency: they never wait for tables -- lanes whose key is resident walk its
-  // table, the others take the limb-parallel table-free form (one wave per lane, the finish fused), and the tables of their keys are built
-  // on side2 off the critical path, for the next call.
   const bool tiny = n_lanes != 0 && n_lanes <= 512;
+  const bool warm = K.warm_schedule >= 0 ? K.warm_schedule != 0
+                                         : (c->kc.persist && Q.mode != 0 && c->h_hint && c->h_hint[0] != 0 && c->h_hint[1] == 0);
   Q.use_new = tiny ? 0u : 1u;
+  Q.warm = warm ? 1u : 0u;
   hipError_t e;
   // (the launch's hash table was cleared, and the cache committed, on side2 by the previous launch.  Skipping this wait when s has
   // already waited for side2's tail was measured: k_proof 0.45 -> 0.52 ms beside it and the step +2 % at 256 proofs -- the packet stays.)
@@ -524,6 +550,55 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   rc = launch_ed_keys(Q, c->side2, x ? c->ev_keys : nullptr);
   if (rc) return rc;
   if (!x && (e = hipEventRecord(c->ev_keys, c->side2)) != hipSuccess) return (int)e;
+  // the end of side2's part of a launch: the launch's hash table cleared for the next one, the cache committed
+  auto side2_tail = [&]() -> int {
+    hipError_t e2;
+    if ((e2 = hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, c->side2)) != hipSuccess) return (int)e2;
+    // (with parts > 1 the multiples of the earlier parts run on s: the epilogue only needs the counters k_ed_keys left, not the tables)
+    int r2 = launch_kc_epilogue(Q, c->side2);
+    if (r2) return r2;
+    return (int)hipEventRecord(c->ev_hash_clean, c->side2);
+  };
+  // the table-free lanes on side2, behind the hash role of s (their h) -- off s, where an empty launch costs ~10 us of the chain
+  auto direct_on_side2 = [&](bool fuse) -> int {
+    hipError_t e2;
+    if ((e2 = hipStreamWaitEvent(c->side2, c->ev_hash, 0)) != hipSuccess) return (int)e2;
+    int r2 = launch_ed_mul_direct(Q, c->side2, fuse, x ? c->ev_direct : nullptr);
+    if (r2) return r2;
+    if (!x && (e2 = hipEventRecord(c->ev_direct, c->side2)) != hipSuccess) return (int)e2;
+    return 0;
+  };
+
+  if (tiny || warm) {
+    // hash role (tiny: all of phase 1 -- a launch of a few waves is pure latency, its roles side by side) on s
+    rc = tiny ? launch_ed_phase1(Q, s, x ? c->ev_hash : nullptr) : launch_ed_hash(Q, s, x ? c->ev_hash : nullptr);
+    if (rc) return rc;
+    if (!x && (e = hipEventRecord(c->ev_hash, s)) != hipSuccess) return (int)e;
+    c->ev_hash_recorded = true;
+    // (up to 256 lanes the finish of the table-free lanes is fused into their kernel: at 512 the 512 waves of the fused kernel slow
+    // k_proof, the longer of the two there, by more than they save)
+    const bool fuse = tiny && n_lanes <= 256;
+    if (tiny && (rc = direct_on_side2(fuse))) return rc;  // first on side2: a cold single proof is this kernel's latency
+    rc = launch_ed_tab_anchor(Q, 0, 1, c->side2);
+    if (rc) return rc;
+    rc = launch_ed_tab_mult(Q, 0, 1, c->side2, xt ? c->ev_part[0] : nullptr);
+    if (rc) return rc;
+    if (!xt && (e = hipEventRecord(c->ev_part[0], c->side2)) != hipSuccess) return (int)e;
+    if (!tiny) {  // s*B (only the finish needs it) beside the hash role and the walk, then the table-free lanes: ev_direct = both done
+      rc = launch_ed_base(Q, c->side2);
+      if (rc) return rc;
+      if ((rc = direct_on_side2(false))) return rc;
+    }
+    if ((rc = side2_tail())) return rc;
+    if (!tiny && (e = hipStreamWaitEvent(s, c->ev_part[0], 0)) != hipSuccess) return (int)e;  // (an expectation that fails: s waits for the build)
+    rc = launch_ed_mul_tab(Q, 0, 1, s);
+    if (rc) return rc;
+    if ((e = hipStreamWaitEvent(s, c->ev_direct, 0)) != hipSuccess) return (int)e;
+    rc = launch_ed_fin(Q, s, fuse);
+    c->fin_done_attached = rc == 0 && Q.fin_done != nullptr;
+    return rc;
+  }
+
   // The anchor chain is cut into `parts` launches on side2; the cached multiples of part p are built on s (idle once phase 1 is
   // done) while side2 doubles part p+1, so that only the multiples of the last part follow the chain.
   // (small launches: one part -- nothing to overlap, and every part is one more launch on s)
@@ -538,29 +613,12 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     }
     if (!xt && (e = hipEventRecord(c->ev_part[p], c->side2)) != hipSuccess) return (int)e;
   }
-  if ((e = hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, c->side2)) != hipSuccess) return (int)e;  // for the next launch
-  // (with parts > 1 the multiples of the earlier parts run on s: the epilogue only needs the counters k_ed_keys left, not the tables)
-  rc = launch_kc_epilogue(Q, c->side2);
-  if (rc) return rc;
-  if ((e = hipEventRecord(c->ev_hash_clean, c->side2)) != hipSuccess) return (int)e;
+  if ((rc = side2_tail())) return rc;
   // phase 1 (SHA-512 mod l, s*B: throughput work for every lane) on s
   rc = launch_ed_phase1(Q, s, x ? c->ev_hash : nullptr);
   if (rc) return rc;
   if (!x && (e = hipEventRecord(c->ev_hash, s)) != hipSuccess) return (int)e;
   c->ev_hash_recorded = true;
-  if (tiny) {
-    rc = launch_ed_mul_tab(Q, 0, 1, s);  // resident keys only: no wait for side2
-    if (rc) return rc;
-    if ((e = hipStreamWaitEvent(s, c->ev_keys, 0)) != hipSuccess) return (int)e;
-    // (up to 256 lanes the finish of the table-free lanes is fused into their kernel: at 512 the 512 waves of the fused kernel slow
-    // k_proof, the longer of the two there, by more than they save)
-    const bool fuse = n_lanes <= 256;
-    rc = launch_ed_mul_direct(Q, s, fuse);
-    if (rc) return rc;
-    rc = launch_ed_fin(Q, s, fuse);
-    c->fin_done_attached = rc == 0 && Q.fin_done != nullptr;
-    return rc;
-  }
   if ((e = hipStreamWaitEvent(s, c->ev_keys, 0)) != hipSuccess) return (int)e;
   rc = launch_ed_mul_direct(Q, s);  // exits at once for the lanes that walk a table: enqueued before the wait for the tables
   if (rc) return rc;
@@ -691,6 +749,8 @@ static int32_t alloc_key_cache(tmx_ctx* c, uint32_t keys) {
   c->kc.hash_mask = (uint32_t)(hsz - 1);
   c->kc.new_cap = (uint32_t)std::min<size_t>(std::min<size_t>(keys, 4096), lanes);  // tables one launch builds at most: the anchor scratch
   c->kc.persist = c->knobs.key_cache ? 1u : 0u;
+  c->kc.hint = const_cast<uint32_t*>(c->h_hint);
+  c->h_hint[0] = 0; c->h_hint[1] = 0;
   HIPCK(c, hipMalloc((void**)&c->kc.d_hash, hsz * 4));
   HIPCK(c, hipMalloc((void**)&c->kc.d_pk, (size_t)keys * 32));
   HIPCK(c, hipMalloc((void**)&c->kc.d_used, (size_t)keys * 4));
@@ -734,6 +794,8 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   for (hipEvent_t ev : c->ev_part)
     if (ev) (void)hipEventDestroy(ev);
   if (c->ev_keys) (void)hipEventDestroy(c->ev_keys);
+  if (c->ev_direct) (void)hipEventDestroy(c->ev_direct);
+  if (c->h_hint) (void)hipHostFree((void*)c->h_hint);
   if (c->ev_hash) (void)hipEventDestroy(c->ev_hash);
   if (c->ev_leaves) (void)hipEventDestroy(c->ev_leaves);
   if (c->ev_hash_clean) (void)hipEventDestroy(c->ev_hash_clean);
@@ -768,6 +830,13 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   for (auto& ev : c->ev_part) HIPCK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   c->knobs = read_knobs();
   HIPCK(c, hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_direct, hipEventDisableTiming));
+  {
+    void* hp = nullptr;
+    HIPCK(c, hipHostMalloc(&hp, 64, hipHostMallocDefault));
+    std::memset(hp, 0, 64);
+    c->h_hint = reinterpret_cast<volatile uint32_t*>(hp);
+  }
   HIPCK(c, hipEventCreateWithFlags(&c->ev_hash, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_leaves, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_hash_clean, hipEventDisableTiming));
@@ -781,7 +850,7 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   if (lanes > ((size_t)1 << 30)) return fail(c, TMX_ERR_CAPACITY, "max_batch * n_max exceeds 2^30 lanes");
   for (int k = 0; k < 2; k++) {
     c->prog[k] = build_program(k, n);
-    if (c->prog[k].sp.elem_count != tmx_elem_count(k, n)) return fail(c, TMX_ERR_BAD_ARG, "internal: layout size mismatch");
+    if (c->prog[k].sp.elem_count != tmx_elem_count(k, n) || c->prog[k].d1b_start == 0xffffffffu) return fail(c, TMX_ERR_BAD_ARG, "internal: layout size mismatch");
     HIPCK(c, hipMalloc(&c->d_lut[k], c->prog[k].lut.size() * 4));
     HIPCK(c, hipMemcpyAsync(c->d_lut[k], c->prog[k].lut.data(), c->prog[k].lut.size() * 4, hipMemcpyHostToDevice, c->side2));
     HIPCK(c, hipMalloc(&c->d_wave_sec[k], c->prog[k].wave_sec.size()));
@@ -923,7 +992,7 @@ int32_t tmx_witness_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, co
   if (st) return st;
   if (n_proofs == 0) return TMX_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = the HIP default stream, exactly as passed
-  return run_batch(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out_elems, d_reports, s, [&](hipStream_t ss) -> int32_t {
+  return run_batch(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out_elems, d_reports, s, true, [&](hipStream_t ss) -> int32_t {
     int rc = run_eddsa(c, n_proofs * c->cfg.n_max, d_targets, reinterpret_cast<uint8_t*>(c->d_tl) + TL_OFF_ED, TL_STRIDE, ss);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("EdDSA kernel launch: ") + hipGetErrorString((hipError_t)rc));
     return TMX_OK;
@@ -947,7 +1016,7 @@ int32_t tmx_finish_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, con
   if (!d_ed) return TMX_ERR_BAD_ARG;
   if (n_proofs == 0) return TMX_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
-  return run_batch(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out_elems, d_reports, s, [&](hipStream_t ss) -> int32_t {
+  return run_batch(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out_elems, d_reports, s, false, [&](hipStream_t ss) -> int32_t {
     // caller's records are 448 B apart; place them into the ED part of the unified per-lane records
     HIPCK(c, hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(c->d_tl) + TL_OFF_ED, TL_STRIDE, d_ed, ED_STRIDE, ED_STRIDE,
                               (size_t)n_proofs * c->cfg.n_max, hipMemcpyDeviceToDevice, ss));

@@ -18,6 +18,7 @@ struct KeyCache {
   uint32_t* d_used;    // [cap] epoch of the last launch that used the slot; 0 = free
   uint32_t* d_free;    // [cap] free list: d_free[free_head .. n_free) are free slots
   uint32_t* d_state;   // KC_STATE_WORDS words, indices below
+  uint32_t* hint;      // page-locked host memory the epilogue writes for the NEXT enqueue to look at: [0] launches committed, [1] new keys of the last
 };
 enum : uint32_t { KC_FREE_HEAD = 0, KC_N_FREE = 1, KC_EPOCH = 2, KC_RESIDENT = 3, KC_LAST_NEW = 4, KC_LAST_HIT_KEYS = 5, KC_LAST_HIT_LANES = 6,
                   KC_LAST_BUILT = 7, KC_LAST_USE_NEW = 8, KC_TOTALS = 16 /* u64 counters from this word on */, KC_STATE_WORDS = 32 };
@@ -44,6 +45,8 @@ struct EdQuad {
   KeyCache kc;
   uint32_t mode;      // 0 never use tables, 1 automatic, 2 whenever they fit (TMX_DEDUP)
   uint32_t use_new;   // 1: the walk is enqueued behind the table build, lanes of new keys may use their fresh tables
+  uint32_t warm;      // 1: the launch expects (nearly) all of its keys to be resident: small grids for the new-key kernels (they loop)
+  RowOut row;         // where the finish writes D.1b straight into the witness rows (rows = null: lane records only)
   void* fin_done;     // event attached to the k_ed_fin dispatch as its completion signal (no separate record packet), or null
 };
 size_t quad_table_bytes();
@@ -61,9 +64,11 @@ int launch_ed_tab_anchor(const EdQuad& Q, uint32_t part, uint32_t parts, void* s
 int launch_ed_tab_mult(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream, void* done = nullptr);
 int launch_kc_epilogue(const EdQuad& Q, void* stream);
 // fuse_fin (launches of <= 2048 lanes): k_ed_fin's work for the lanes this kernel multiplies, in the same kernel
-int launch_ed_mul_direct(const EdQuad& Q, void* stream, bool fuse_fin = false);
+int launch_ed_mul_direct(const EdQuad& Q, void* stream, bool fuse_fin = false, void* done = nullptr);
 int launch_ed_phase1(const EdQuad& Q, void* stream, void* done = nullptr);
+int launch_ed_hash(const EdQuad& Q, void* stream, void* done = nullptr);
 int launch_ed_mul_tab(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream);
+int launch_ed_base(const EdQuad& Q, void* stream, void* done = nullptr);  // s*B alone (the hash role ran as k_ed_hash)
 int launch_ed_fin(const EdQuad& Q, void* stream, bool fused_direct = false);
 int launch_proof(const ProofParams& P, uint32_t n_proofs, const void* d_proofs, const void* d_target, const void* d_trusted, void* d_lt,
                  uint32_t lt_stride, void* d_lr, void* d_pf, void* d_nodes_t, void* d_nodes_r, void* d_reports, void* stream);
@@ -72,8 +77,9 @@ int launch_leaves(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_ta
                   void* stream, void* done = nullptr);
 int launch_valid_skip(uint32_t n_cand, uint32_t n_max, const void* d_start, uint32_t n_start, const void* d_targets, const void* d_nt, const void* d_sigs,
                       const void* d_ns, void* d_valid, void* d_shared, void* d_total, void* stream);
-int launch_verdict(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_ed, uint32_t ed_stride, void* d_pf, void* d_reports, void* stream,
-                   void* started = nullptr, void* done = nullptr);
+// (row.rows != null: d_ed is the ED part of the unified lane records, and the ten k_proof-derived D.1b elements of every lane are written)
+int launch_verdict(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_ed, uint32_t ed_stride, void* d_pf, void* d_reports, const RowOut& row,
+                   void* stream, void* started = nullptr, void* done = nullptr);
 // sec_mask: bit s = section s, bit 31 = waves straddling a section boundary / the row end
 int launch_serialize(const SerializeProgram& S, const SerializeSources& src, const void* d_lut, const void* d_wave_sec, const void* d_seam_waves,
                      uint32_t n_seams, uint32_t n_proofs, void* d_out, uint32_t sec_mask, void* stream, uint32_t max_wgs = 0, uint32_t proof0 = 0);

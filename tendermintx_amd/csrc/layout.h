@@ -89,6 +89,17 @@ struct SerializeSources {
   const uint8_t* nodes_r;
 };
 
+// ---- D.1b, the word fields of the per-target-lane derived values (DESIGN.md "Witness layout"): written straight into the witness rows by the
+// EdDSA finish (the first D1B_ED_ELEMS elements of a lane: h, ten coordinates, eddsa_ok) and by k_verdict (the other ten: k_proof's flags
+// and prefix sums) when the batch comes through run_eddsa; by the serializer when the lane records come from the caller
+constexpr uint32_t D1B_LANE_ELEMS = 99, D1B_ED_ELEMS = 89;
+struct RowOut {
+  uint64_t* rows;        // first element of the batch's first row, or null: no direct row writes
+  uint32_t elem_stride;  // elements between rows
+  uint32_t n;            // lanes per proof
+  uint32_t d1b_start;    // first element of the D.1b section within a row
+};
+
 // ---- Level-2 trace rows (trace.hip): row widths in elements
 constexpr uint32_t TR_LADDER_ROW = 65, TR_LADDER_ROWS = 256, TR_SHA512_ROW = 18, TR_SHA256_ROW = 9;
 

@@ -1,5 +1,9 @@
 """The C ABI driven from a compiled C host (no Python, no torch in the process): what a Rust/C maintainer's FFI sees.
-The host links libtmx.so and the ROCm HIP runtime itself (libtmx.so deliberately has no DT_NEEDED on it -- INTEGRATION.md)."""
+The host links libtmx.so and the ROCm HIP runtime itself (libtmx.so deliberately has no DT_NEEDED on it -- INTEGRATION.md).
+Every entry point a hint body would bind is driven from C and its FULL output compared with the oracle's, element by element:
+tmx_skip_witness (SkipOffchainInputs::hint, reference circuits/skip.rs:64-102), tmx_step_witness (StepOffchainInputs::hint,
+circuits/step.rs:56-89), tmx_witness_batch_opts(TMX_SEC_HINT, TMX_OUT_U32), and two host threads with a context each (the calling
+pattern of the reference's async hints on a tokio runtime, skip.rs:37-44)."""
 import os
 import subprocess
 
@@ -9,24 +13,78 @@ import pytest
 from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
+FX = os.path.join(GOLDEN, "fixtures", "mocha-4")
 
 
-def test_skip_from_c_host(built_lib, oracle, cases, tmp_path):
-    exe = str(tmp_path / "skip_host")
+@pytest.fixture(scope="module")
+def host(built_lib, tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("c_host") / "witness_host")
     libdir = os.path.join(ROOT, "tendermintx_amd")
-    subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(ROOT, "tests", "c_host", "skip_host.c"), "-I" + os.path.join(ROOT, "include"),
-                           "-L" + libdir, "-ltmx", "-L/opt/rocm/lib", "-lamdhip64", "-lstdc++", "-Wl,-rpath," + libdir + ":/opt/rocm/lib"])
-    fx = os.path.join(GOLDEN, "fixtures", "mocha-4")
-    for name, a, b, n in [("skip_10000_10500_n4", 10000, 10500, 4), ("skip_3000_3100_n4", 3000, 3100, 4), ("skip_10000_10500_n32", 10000, 10500, 32)]:
-        c = cases[name]
-        trusted_hash = c["proof"][32:96]  # bytes 16..48 of the proof record = the public trusted header hash
-        out = subprocess.check_output([exe, fx, str(a), trusted_hash, str(b), str(n), "mocha-4"]).decode().split("\n")
-        assert out[0] == "header " + c["header"]
-        fields = dict(zip(out[1].split()[::2], out[1].split()[1::2]))
-        assert fields["all_ok"] == "1" and fields["fail_mask"] == "0" and fields["first_bad_sig"] == "-1"
-        assert int(fields["elems"]) == c["elem_count"]
-        want, _ = oracle.witness(c["kind"], bytes.fromhex(c["proof"]), bytes.fromhex(c["target"]), bytes.fromhex(c["trusted"]), b"mocha-4", 100800)
-        s = 0
-        for v in want.tolist():
-            s = (s * 1099511628211 + v) & (2**64 - 1)
-        assert int(fields["checksum"]) == s
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "c_host", "witness_host.c"), "-I" + os.path.join(ROOT, "include"),
+                           "-L" + libdir, "-ltmx", "-L/opt/rocm/lib", "-lamdhip64", "-lstdc++", "-lpthread", "-Wl,-rpath," + libdir + ":/opt/rocm/lib"])
+    return exe
+
+
+def _fields(line):
+    f = line.split()
+    return dict(zip(f[::2], f[1::2]))
+
+
+def _oracle_row(oracle, c):
+    want, rep = oracle.witness(c["kind"], bytes.fromhex(c["proof"]), bytes.fromhex(c["target"]), bytes.fromhex(c["trusted"]) if c["trusted"] else None,
+                               c["chain_id"].encode(), c["skip_max"])
+    return want, rep
+
+
+@pytest.mark.parametrize("name,a,b,n", [("skip_10000_10500_n4", 10000, 10500, 4), ("skip_3000_3100_n4", 3000, 3100, 4),
+                                        ("skip_10000_10500_n32", 10000, 10500, 32), ("skip_10500_157001_n128", 10500, 157001, 128)])
+def test_skip_from_c_host(host, oracle, cases, tmp_path, name, a, b, n):
+    c = cases[name]
+    trusted_hash = c["proof"][32:96]  # bytes 16..48 of the proof record = the public trusted header hash
+    out = str(tmp_path / "row.bin")
+    lines = subprocess.check_output([host, "skip", FX, str(n), "mocha-4", out, str(a), trusted_hash, str(b)]).decode().split("\n")
+    assert lines[0] == "header " + c["header"]
+    f = _fields(lines[1])
+    assert (f["all_ok"], f["fail_mask"], f["first_bad_sig"]) == (str(int(c["all_ok"])), str(c["fail_mask"]), str(c["first_bad_sig"]))
+    want, _ = _oracle_row(oracle, c)
+    got = np.fromfile(out, dtype=np.uint64)
+    assert got.size == c["elem_count"] == int(f["elems"]) and np.array_equal(got, want)          # the full row, not a checksum
+    k = _fields(lines[2].replace("key_cache ", ""))
+    assert k["enabled"] == "1" and int(k["resident"]) == int(k["last_new"]) > 0                   # the cold call made its keys resident
+
+
+@pytest.mark.parametrize("name,prev,n", [("step_10000_n2", 10000, 2), ("step_3000_n4", 3000, 4), ("step_10500_n4", 10500, 4), ("step_10500_n100", 10500, 100)])
+def test_step_from_c_host(host, oracle, cases, tmp_path, name, prev, n):
+    c = cases[name]
+    out = str(tmp_path / "row.bin")
+    lines = subprocess.check_output([host, "step", FX, str(n), "mocha-4", out, str(prev), c["proof"][32:96]]).decode().split("\n")
+    assert lines[0] == "header " + c["header"]
+    f = _fields(lines[1])
+    assert (f["all_ok"], f["fail_mask"], f["first_bad_sig"]) == (str(int(c["all_ok"])), str(c["fail_mask"]), str(c["first_bad_sig"]))
+    want, _ = _oracle_row(oracle, c)
+    got = np.fromfile(out, dtype=np.uint64)
+    assert got.size == c["elem_count"] and np.array_equal(got, want)
+
+
+def test_hint_section_as_u32_from_c_host(host, oracle, cases, tmp_path, built_lib):
+    """tmx_witness_batch_opts(TMX_SEC_HINT, TMX_OUT_U32): exactly the elements SkipOffchainInputs::hint writes to its output stream
+    (VerifySkipVariable<N>, reference circuits/variables.rs:91-105), narrowed to u32"""
+    c = cases["skip_10000_10500_n32"]
+    out = str(tmp_path / "hint.bin")
+    subprocess.check_call([host, "hint32", FX, "32", "mocha-4", out, "10000", c["proof"][32:96], "10500"], stdout=subprocess.DEVNULL)
+    want, _ = _oracle_row(oracle, c)
+    hint = int(built_lib.tmx_hint_elem_count(0, 32))
+    got = np.fromfile(out, dtype=np.uint32)
+    assert hint == 1776 * 32 + 5320 and got.size == hint and np.array_equal(got.astype(np.uint64), want[:hint])
+
+
+def test_two_host_threads_two_contexts(host, oracle, cases, tmp_path):
+    """Two threads, a context each, 40 skip witnesses each at the same time: every row equals the single-threaded one and the oracle's
+    (the contexts share the device's three internal side streams; each owns its scratch, events and key cache)."""
+    c = cases["skip_10000_10500_n32"]
+    out = str(tmp_path / "row.bin")
+    r = subprocess.run([host, "threads", FX, "32", "mocha-4", out, "10000", c["proof"][32:96], "10500", "40"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    print(r.stdout.strip())          # mismatch counts, ms per call alone and with both threads running (-s shows it; DESIGN.md quotes it)
+    want, _ = _oracle_row(oracle, c)
+    assert np.array_equal(np.fromfile(out, dtype=np.uint64), want)

@@ -571,7 +571,8 @@ KNOBS = [
     {"TMX_DEDUP": "0"}, {"TMX_DEDUP": "2"}, {"TMX_KEY_CACHE": "0"}, {"TMX_KEY_CACHE": "0", "TMX_DEDUP": "2"}, {"TMX_KEY_CACHE_KEYS": "40"},
     {"TMX_WALK_PARTS": "1"}, {"TMX_WALK_PARTS": "1", "TMX_TAB_PARTS": "4"}, {"TMX_TAB_PARTS": "1"}, {"TMX_TAB_PARTS": "4", "TMX_KEY_CACHE": "0"},
     {"TMX_EXT_EVENTS": "0"}, {"TMX_LEAVES": "1"}, {"TMX_LEAVES": "0", "TMX_P1_EARLY": "1"}, {"TMX_LEAVES": "1", "TMX_SER_SPLIT": "0"},
-    {"TMX_SER_SPLIT": "0"}, {"TMX_SER_SPLIT": "0", "TMX_KEY_CACHE": "0"}]
+    {"TMX_SER_SPLIT": "0"}, {"TMX_SER_SPLIT": "0", "TMX_KEY_CACHE": "0"}, {"TMX_SCHEDULE": "warm"}, {"TMX_SCHEDULE": "cold"},
+    {"TMX_SCHEDULE": "warm", "TMX_KEY_CACHE_KEYS": "40"}, {"TMX_SCHEDULE": "warm", "TMX_DEDUP": "0"}]
 
 
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
@@ -651,3 +652,36 @@ def test_key_dedup_paths(tmx, oracle):
         # the same batch again must not see stale keys / tables from the previous launches
         _, reps2 = _check_vs_oracle(tmx, oracle, 0, n, same.proofs, same.targets, same.trusteds, b"celestia", ctx=ctx)
         assert ctx.last_dedup() == (16, True)
+
+
+def test_timed_workload_all_rows(tmx, oracle):
+    """The exact batch bench.py times -- synth.bench_workload("survey8d", 128, 256): 100 validators in the 128 lanes, four validator sets,
+    Bernoulli(0.9) signing re-drawn until > 2/3, rounds {0,0,0,3}, dummy-key lanes -- through the device entry point bench.py calls: all
+    256 rows bit-exact vs the oracle, cold (401 distinct keys: the per-key tables are built and walked) and warm (every lane's key resident
+    in the key cache: the schedule the headline is measured on), and `last_dedup` / the cache counters prove which path ran."""
+    import torch
+    from tendermintx_amd.synth import bench_workload
+    n, P = 128, 256
+    wl = bench_workload("survey8d", n, P, seed=0x544D58)
+    want, oreps = oracle.witness_batch(0, P, wl.proofs, wl.targets, wl.trusteds, n, b"celestia", 100800, n_threads=os.cpu_count() or 8)
+    dev = torch.device("cuda", 0)
+    d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) for b in (wl.proofs, wl.targets, wl.trusteds)]
+    stream = torch.cuda.current_stream(dev)
+    with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+        stride, count = ctx.elem_stride(0), ctx.elem_count(0)
+        for run in range(3):
+            out = torch.full((P, stride), -1, dtype=torch.int64, device=dev)
+            rep = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
+            ctx.witness_batch_device(0, P, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), out.data_ptr(), rep.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            got = out[:, :count].cpu().numpy().view(np.uint64)
+            assert np.array_equal(got, want), (run, np.argwhere(got != want)[:8].tolist())
+            assert int(out[:, count:].abs().sum().item()) == 0
+            reps = np.frombuffer(rep.cpu().numpy().tobytes(), dtype=np.uint32).reshape(P, 16)
+            assert all(int(r[8]) == 1 for r in reps) and all(o["all_ok"] for o in oreps)
+            st = ctx.key_cache_stats()
+            assert ctx.last_dedup() == (401, True)
+            if run == 0:
+                assert (st["last_new_keys"], st["last_built_keys"], st["last_hit_lanes"]) == (401, 401, 0)
+            else:
+                assert (st["last_new_keys"], st["last_hit_keys"], st["last_hit_lanes"]) == (0, 401, n * P)
