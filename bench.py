@@ -17,6 +17,8 @@ own N ranks (torch.distributed.run, RCCL) when it was not started by a launcher;
 Prints ONE JSON line on rank 0 (contract: task description "bench.py").  Beside the contract's fields:
   single_proof   BASELINE configs[2]: device-resident latency of one proof and its host-to-host time (SURVEY 8(d)'s metric definition)
   host_to_host   the batch through the host-buffer entry point (H2D + step + D2H), full rows and hint-only rows
+  key_cache      the timed steps run with a WARM per-key table cache (the same validator sets step after step: what a light client does);
+                 `cold` = the same step after tmx_key_cache_flush (every key new: decode, doubling chain, tables built inside the step)
   roofline       the step against HBM (algorithmic bytes / HIP-event time of the launch sequence), k_serialize alone, VALU issue
   cpu_baseline   oracle/c on this box's host cores: one thread, and a persistent pool on all cores (>= 16 proofs per thread) with its
                  scaling efficiency; OpenSSL's EVP_DigestVerify per signature as an independent datapoint
@@ -33,7 +35,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-SIMDS, CLOCK_GHZ, CYCLES_PER_VALU = 1024, 2.4, 4   # 256 CUs x 4 SIMD16; every VALU instruction of a wave64 occupies its SIMD for 4 cycles (tools/microbench)
+SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs
+# Issue cost of a wave64 VALU instruction per SIMD with the SIMD saturated, measured per opcode by tools/microbench/valu_isa.hip
+# (profiles/r03_valu_isa.txt): 4.05-4.08 cycles for everything these kernels are made of (v_mad_u64_u32 / v_mad_i64_i32, every VOP3 and DPP
+# form, v_mul_*, v_bfe_u32, carry pairs) -- only plain two-operand v_add_u32 / v_xor_b32 (and v_fma_f32) co-issue at ~2.3.  profiles/r03_isa_mix.json
+# holds each kernel's static share of that fast class; the issue roof is reported between "all of them co-issued" and "none".
+CYCLES_SLOW, CYCLES_FAST = 4.07, 2.3
 
 
 def parse_args(argv=None):
@@ -220,6 +227,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     kms = ctx.kernel_ms_mean(min(args.steps, 128))  # HIP events recorded on the launch stream inside the timed region
     n_unique, used_tables = ctx.last_dedup()
+    kc = ctx.key_cache_stats()
 
     gather_ms = None
     if gather:
@@ -261,6 +269,11 @@ def main():
             "all_proofs_ok": bool(int(ok_flag.item())),
             **({"debug_shared_gpu": "TMX_BENCH_SHARE_GPU=1: every rank ran on cuda:0 (control-flow test, timings meaningless)"} if share_gpu else {}),
             "dedup": {"lanes": lanes, "distinct_keys": n_unique, "per_key_tables": used_tables},
+            "key_cache": {"state_of_the_timed_steps": "warm" if kc["last_new_keys"] == 0 and kc["last_hit_lanes"] == lanes else "cold/mixed",
+                          "last_step": {k: kc[k] for k in ("last_new_keys", "last_hit_keys", "last_hit_lanes", "last_built_keys")},
+                          "resident_keys": kc["resident_keys"], "capacity_keys": kc["capacity_keys"], "bytes_per_key": kc["bytes_per_key"],
+                          "note": "the warm-up steps made the batch's validator sets resident; a light client re-verifies the same slowly changing set "
+                                  "from call to call (reference bin/tendermintx.rs:171).  `cold` below = the same step with an empty cache"},
         }
         if gather_ms is not None:
             result["gather_rows"] = {"ms": round(gather_ms, 4), "bytes_per_rank_out": P_total * stride * 8,
@@ -295,23 +308,39 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
         torch.cuda.synchronize(dev)
         a = time.perf_counter()
         run(c, k, bufs, n_proofs)
+        stream.synchronize()   # the call is complete when the caller's stream is (a cold single proof leaves the table build of its keys
+        b = time.perf_counter()  # running on the library's side stream: work for the NEXT call, not part of this one's latency)
         torch.cuda.synchronize(dev)
-        return 1e3 * (time.perf_counter() - a) / k
+        return 1e3 * (b - a) / k
+
+    # ---- cold: the same step with an empty key cache (every key new: decoded, its table built inside the step), 12 flush + step pairs
+    def cold_ms(bufs=None, n_proofs=None, reps=12):
+        xs = []
+        for _ in range(reps):
+            ctx.key_cache_flush()
+            xs.append(timed(ctx, 1, bufs, n_proofs))
+        return median(xs)
+    result["key_cache"]["cold"] = {"ms_per_step": round(cold_ms(), 4), "note": "tmx_key_cache_flush + one step, host clock around enqueue + synchronize, median of 12"}
+    timed(ctx, 3)
+    result["key_cache"]["warm"] = {"ms_per_step": round(timed(ctx, 30), 4), "note": "30 steps, host clock (the timed region above is the driver-facing figure)"}
 
     # ---- the other workload (best case <-> SURVEY 8(d)) through the same context
     other_name = "one_set" if args.workload == "survey8d" else "survey8d"
     wo = bench_workload(other_name, n, P, seed=0x544D58)
     bo = tuple(dev_bytes(b) for b in (wo.proofs, wo.targets, wo.trusteds))
+    ms_other_cold = cold_ms(bo)
     timed(ctx, 10, bo)
     ms_other = timed(ctx, 30, bo)
     uo, to = ctx.last_dedup()
     ok_o = int(d_rep.cpu().numpy().reshape(-1, 64)[:P, 32:36].copy().view(np.uint32).sum()) == P
     result["best_case" if other_name == "one_set" else "survey8d"] = {
-        "workload": wo.describe, "ms_per_step": round(ms_other, 4), "value": round(ms_other / P, 6), "distinct_keys": uo, "per_key_tables": to,
+        "workload": wo.describe, "ms_per_step": round(ms_other, 4), "ms_per_step_cold": round(ms_other_cold, 4), "value": round(ms_other / P, 6),
+        "distinct_keys": uo, "per_key_tables": to,
         "all_proofs_ok": ok_o, "note": "same context, 30 steps after 10 warm-up, host clock around the enqueue + synchronize"}
 
     # ---- BASELINE configs[2]: ONE proof.  Device-resident latency (host clock around one call) and host-to-host (host buffers in,
     # witness row in page-locked host memory out: SURVEY 8(d)'s metric definition)
+    lat_cold = cold_ms(None, 1, reps=20)
     run(ctx, 3, None, 1)
     lat = []
     for _ in range(30):
@@ -334,9 +363,10 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
             a = time.perf_counter()
             hint(KIND_SKIP, *p1, out=host_out)
             hh1_hint.append(1e3 * (time.perf_counter() - a))
-    result["single_proof"] = {"device_ms": round(median(lat), 4), "host_to_host_ms": round(median(hh1), 4),
+    result["single_proof"] = {"device_ms": round(median(lat), 4), "device_ms_cold": round(lat_cold, 4), "host_to_host_ms": round(median(hh1), 4),
                               "host_to_host_hint_only_ms": round(median(hh1_hint), 4) if hh1_hint else None,
-                              "row_bytes": stride * 8, "workload": "proof 0 of the batch above (BASELINE configs[2])"}
+                              "row_bytes": stride * 8, "workload": "proof 0 of the batch above (BASELINE configs[2]); device_ms / host_to_host with the "
+                              "proof's validator set resident in the key cache (warm), device_ms_cold after tmx_key_cache_flush"}
     result["latency_single_proof_ms"] = result["single_proof"]["device_ms"]
 
     # ---- the batch, host to host (PCIe-bound; never `value`)
@@ -381,24 +411,44 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
     result["dedup"]["without_key_tables"] = {"ms_per_step": round(timed(ctx0, 10), 4), "k_eddsa_ms": round(ctx0.kernel_ms_mean(10)["k_eddsa"], 4)}
     ctx0.close()
 
-    # ---- PMC figures of the committed rocprofv3 passes (profiles/pmc_latest.json), only if they were taken on this configuration
+    # ---- PMC figures of the committed rocprofv3 passes (profiles/pmc_latest.json), only if they were taken on this configuration.
+    # NOT measured by this run: replayed from the builder's profile collection, and marked as such in the line
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
         if pmc["config"] == {"n_max": n, "proofs_per_gpu": P, "workload": args.workload}:
+            src = "profiles/pmc_latest.json (rocprofv3 --pmc passes over tools/profile_step.py, collected by the builder; replayed, not measured in this run)"
             pk = {g: v for g, v in pmc["kernels"].items() if g != "setup"}   # (setup = the once-per-context table of B)
             roofline["traffic"] = int(sum(pk[g].get("fetch_kb", 0) + pk[g].get("write_kb", 0) for g in pk) * 1024)
+            roofline["traffic_source"] = src
             roofline["k_serialize"]["traffic"] = int((pk["k_serialize"]["fetch_kb"] + pk["k_serialize"]["write_kb"]) * 1024)
+            roofline["k_serialize"]["traffic_source"] = src
+            try:
+                mix = json.load(open(os.path.join(ROOT, "profiles", "r03_isa_mix.json")))["kernels"]
+            except (OSError, KeyError, ValueError):
+                mix = {}
 
-            def frac(insts, ms):  # wave-level VALU instructions x 4 cycles against the SIMD-cycles of the measured time
-                return round(insts * CYCLES_PER_VALU / (SIMDS * ms * 1e-3 * CLOCK_GHZ * 1e9), 4)
+            def cycles(group_or_kernel, insts, fast_share):
+                return insts * ((1 - fast_share) * CYCLES_SLOW + fast_share * CYCLES_FAST), insts * CYCLES_SLOW
+
+            lo = hi = 0.0
+            for kname, v in pmc.get("per_kernel", {}).items():
+                if "valu_insts" not in v or "init_base" in kname:
+                    continue
+                share = mix.get(kname.split("<")[0], {}).get("fast_class_share", 0.0)
+                a_, b_ = cycles(kname, v["valu_insts"], share)
+                lo, hi = lo + a_, hi + b_
+            step_s = (kms["k_eddsa"] + kms["k_serialize"]) * 1e-3
             step_insts = sum(pk[g].get("valu_insts", 0) for g in pk)
             roofline["valu_issue"] = {
-                "unit": "wave-level VALU instructions per batch (SQ_INSTS_VALU)", "cycles_per_instruction": CYCLES_PER_VALU,
-                "step": {"insts": int(step_insts), "frac_of_issue_slots": frac(step_insts, kms["k_eddsa"] + kms["k_serialize"])},
-                "k_eddsa": {"insts": int(pk["k_eddsa"]["valu_insts"]), "frac_of_issue_slots": frac(pk["k_eddsa"]["valu_insts"], kms["k_eddsa"])},
-                "k_proof": {"insts": int(pk["k_proof"]["valu_insts"])}, "k_serialize": {"insts": int(pk["k_serialize"]["valu_insts"])},
-                "note": "fraction of the 1024 SIMDs' issue cycles (2.4 GHz) that the VALU instructions occupy over the event-timed interval; "
-                        "the EdDSA kernels move 23 MB per batch (0.6 % of HBM peak): their roof is this one"}
+                "unit": "wave-level VALU instructions per batch (SQ_INSTS_VALU)", "insts_source": src,
+                "cycles_per_instruction": {"measured_by": "tools/microbench/valu_isa.hip (profiles/r03_valu_isa.txt), per SIMD, saturated",
+                                           "default": CYCLES_SLOW, "plain_v_add_u32_v_xor_b32_v_mov_when_co_issued": CYCLES_FAST},
+                "step": {"insts": int(step_insts),
+                         "frac_of_issue_slots": [round(lo / (SIMDS * step_s * CLOCK_GHZ * 1e9), 4), round(hi / (SIMDS * step_s * CLOCK_GHZ * 1e9), 4)]},
+                "k_eddsa": {"insts": int(pk["k_eddsa"]["valu_insts"])}, "k_proof": {"insts": int(pk["k_proof"]["valu_insts"])},
+                "k_serialize": {"insts": int(pk["k_serialize"]["valu_insts"])},
+                "note": "fraction of the 1024 SIMDs' issue cycles (2.4 GHz) the step's VALU instructions need over the event-timed interval: "
+                        "[every fast-class instruction co-issued at 2.3 cycles, none co-issued]; the EdDSA kernels move ~1 % of HBM peak: their roof is this one"}
     except (OSError, KeyError, ValueError):
         pass
 

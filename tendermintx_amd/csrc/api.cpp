@@ -240,9 +240,7 @@ struct Knobs {
   uint32_t key_cache_keys = 0;  // TMX_KEY_CACHE_KEYS: capacity of the cache in keys (0: by max_batch * n_max)
   bool ser_split = true;     // TMX_SER_SPLIT=0: one k_serialize launch at the end of the step (times the kernel on its own)
   int leaves = -1;           // TMX_LEAVES=0|1: leaf hashes as a launch of their own in front of k_proof (default: from 131072 lanes)
-  int p1_early = -1;         // TMX_P1_EARLY=0|1: D.1a behind k_proof's sections instead of behind k_ed_fin (default: from 131072 lanes)
   int walk_parts = -1;       // TMX_WALK_PARTS=0|1: the table walk follows the table build part by part (default: from 65536 lanes)
-  uint32_t tab_parts = 2;    // TMX_TAB_PARTS=1|2|4: launches the anchor chain of new keys is cut into
   bool ext_events = true;    // TMX_EXT_EVENTS=0: record packets instead of completion signals on the chain kernels
   int warm_schedule = -1;    // TMX_SCHEDULE=warm|cold: the EdDSA schedule for resident / new keys (default: by what the last launch saw)
 };
@@ -254,9 +252,7 @@ static Knobs read_knobs() {
   if ((v = std::getenv("TMX_KEY_CACHE_KEYS")) && std::atoll(v) > 0) k.key_cache_keys = (uint32_t)std::min<long long>(std::atoll(v), 1 << 20);
   k.ser_split = !((v = std::getenv("TMX_SER_SPLIT")) && v[0] == '0');
   k.leaves = (v = std::getenv("TMX_LEAVES")) ? (v[0] != '0' ? 1 : 0) : -1;
-  k.p1_early = (v = std::getenv("TMX_P1_EARLY")) ? (v[0] != '0' ? 1 : 0) : -1;
   k.walk_parts = (v = std::getenv("TMX_WALK_PARTS")) ? (v[0] == '1' ? 1 : 0) : -1;
-  if ((v = std::getenv("TMX_TAB_PARTS")) && (std::atoi(v) == 1 || std::atoi(v) == 2 || std::atoi(v) == 4)) k.tab_parts = (uint32_t)std::atoi(v);
   k.ext_events = !((v = std::getenv("TMX_EXT_EVENTS")) && v[0] == '0');
   k.warm_schedule = (v = std::getenv("TMX_SCHEDULE")) ? (v[0] == 'w' ? 1 : 0) : -1;
   return k;
@@ -444,9 +440,9 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   st0 = K.ser_split ? serialize(prog.mask_proof | (leaves_first ? 0u : prog.mask_leaves), c->side) : TMX_OK;
   if (st0) return st0;
   // D.1a (the byte fields of the per-target-lane derived values: a quarter of the row) needs k_proof and phase 1, not k_ed_fin: behind
-  // k_proof's sections on the side stream, i.e. while the table walk and the finish run.  Measured (TMX_P1_EARLY=1|0): -6.3 % step at 1024
-  // proofs x 128; +-0.5 % at 256 and 64, +1 ... +2 % at 512 proofs: on from 131072 lanes
-  const bool p1_early = leaves_first || (K.ser_split && c->ev_hash_recorded && (K.p1_early >= 0 ? K.p1_early != 0 : (uint64_t)n_proofs * n >= 131072));
+  // k_proof's sections on the side stream, i.e. while the table walk and the finish run.  Measured (round 2): -6.3 % step at 1024
+  // proofs x 128; +-0.5 % at 256 and 64, +1 ... +2 % at 512 proofs (and +7 % at 256 with a warm key cache): on from 131072 lanes
+  const bool p1_early = leaves_first || (K.ser_split && c->ev_hash_recorded && (uint64_t)n_proofs * n >= 131072);
   if (p1_early && !leaves_first) {
     HIPCK(c, hipStreamWaitEvent(c->side, c->ev_hash, 0));
     if ((st0 = serialize(prog.mask_p1, c->side, beside_chain_wgs))) return st0;
@@ -602,7 +598,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   // The anchor chain is cut into `parts` launches on side2; the cached multiples of part p are built on s (idle once phase 1 is
   // done) while side2 doubles part p+1, so that only the multiples of the last part follow the chain.
   // (small launches: one part -- nothing to overlap, and every part is one more launch on s)
-  const uint32_t parts = n_lanes <= 2048 ? 1u : K.tab_parts;
+  const uint32_t parts = n_lanes <= 2048 ? 1u : 2u;  // (4 parts: no further gain)
   for (uint32_t p = 0; p < parts; p++) {
     const bool last = p + 1 == parts;
     rc = launch_ed_tab_anchor(Q, p, parts, c->side2, xt && !last ? c->ev_part[p] : nullptr);

@@ -569,10 +569,10 @@ def test_validator_sharded_single_proof(tmx, oracle):
 
 KNOBS = [
     {"TMX_DEDUP": "0"}, {"TMX_DEDUP": "2"}, {"TMX_KEY_CACHE": "0"}, {"TMX_KEY_CACHE": "0", "TMX_DEDUP": "2"}, {"TMX_KEY_CACHE_KEYS": "40"},
-    {"TMX_WALK_PARTS": "1"}, {"TMX_WALK_PARTS": "1", "TMX_TAB_PARTS": "4"}, {"TMX_TAB_PARTS": "1"}, {"TMX_TAB_PARTS": "4", "TMX_KEY_CACHE": "0"},
-    {"TMX_EXT_EVENTS": "0"}, {"TMX_LEAVES": "1"}, {"TMX_LEAVES": "0", "TMX_P1_EARLY": "1"}, {"TMX_LEAVES": "1", "TMX_SER_SPLIT": "0"},
-    {"TMX_SER_SPLIT": "0"}, {"TMX_SER_SPLIT": "0", "TMX_KEY_CACHE": "0"}, {"TMX_SCHEDULE": "warm"}, {"TMX_SCHEDULE": "cold"},
-    {"TMX_SCHEDULE": "warm", "TMX_KEY_CACHE_KEYS": "40"}, {"TMX_SCHEDULE": "warm", "TMX_DEDUP": "0"}]
+    {"TMX_WALK_PARTS": "1"}, {"TMX_WALK_PARTS": "1", "TMX_KEY_CACHE": "0"}, {"TMX_EXT_EVENTS": "0"}, {"TMX_LEAVES": "1"},
+    {"TMX_LEAVES": "1", "TMX_SER_SPLIT": "0"}, {"TMX_SER_SPLIT": "0"}, {"TMX_SER_SPLIT": "0", "TMX_KEY_CACHE": "0"}, {"TMX_SCHEDULE": "warm"},
+    {"TMX_SCHEDULE": "cold"}, {"TMX_SCHEDULE": "warm", "TMX_KEY_CACHE_KEYS": "40"}, {"TMX_SCHEDULE": "warm", "TMX_DEDUP": "0"},
+    {"TMX_SCHEDULE": "cold", "TMX_LEAVES": "1", "TMX_WALK_PARTS": "1"}]
 
 
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))

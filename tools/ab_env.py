@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of environment knobs on the bench workload (256 proofs x 128 validators): alternates the configurations, fresh context each time.
-usage: ab_env.py REPS KEY=V1,V2,...   e.g.  ab_env.py 5 TMX_BASE_W=4,8,10"""
+usage: ab_env.py REPS KEY=V1,V2,...   e.g.  ab_env.py 5 TMX_SCHEDULE=warm,cold"""
 import os
 import statistics
 import sys

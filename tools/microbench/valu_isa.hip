@@ -108,6 +108,35 @@ DEF_KERNEL(v_permlane16_swap_b32, "v_permlane16_swap_b32 %0, %1\nv_permlane16_sw
            "v_permlane16_swap_b32 %0, %2")
 DEF_KERNEL(v_permlane32_swap_b32, "v_permlane32_swap_b32 %0, %1\nv_permlane32_swap_b32 %2, %3\nv_permlane32_swap_b32 %4, %5\nv_permlane32_swap_b32 %6, %7\nv_permlane32_swap_b32 %0, %2\nv_permlane32_swap_b32 %1, %3\nv_permlane32_swap_b32 %4, %6\nv_permlane32_swap_b32 %5, %7",
            "v_permlane32_swap_b32 %0, %2")
+#define SUB_I(k) "v_sub_u32 %" #k ", %" #k ", %16"
+DEF_KERNEL(v_sub_u32, I8(SUB_I), "v_sub_u32 %0, %0, %2")
+#define AND_I(k) "v_and_b32 %" #k ", %" #k ", %16"
+DEF_KERNEL(v_and_b32, I8(AND_I), "v_and_b32 %0, %0, %2")
+#define OR_I(k) "v_or_b32 %" #k ", %" #k ", %16"
+DEF_KERNEL(v_or_b32, I8(OR_I), "v_or_b32 %0, %0, %2")
+#define LSHL_I(k) "v_lshlrev_b32 %" #k ", 3, %" #k
+DEF_KERNEL(v_lshlrev_b32, I8(LSHL_I), "v_lshlrev_b32 %0, 3, %0")
+#define LSHR_I(k) "v_lshrrev_b32 %" #k ", 3, %" #k
+DEF_KERNEL(v_lshrrev_b32, I8(LSHR_I), "v_lshrrev_b32 %0, 3, %0")
+#define ASHR_I(k) "v_ashrrev_i32 %" #k ", 3, %" #k
+DEF_KERNEL(v_ashrrev_i32, I8(ASHR_I), "v_ashrrev_i32 %0, 3, %0")
+#define MOV_I(k) "v_mov_b32 %" #k ", %16"
+DEF_KERNEL(v_mov_b32, I8(MOV_I), "v_mov_b32 %0, %2")
+#define NOT_I(k) "v_not_b32 %" #k ", %" #k
+DEF_KERNEL(v_not_b32, I8(NOT_I), "v_not_b32 %0, %0")
+#define MINU_I(k) "v_min_u32 %" #k ", %" #k ", %16"
+DEF_KERNEL(v_min_u32, I8(MINU_I), "v_min_u32 %0, %0, %2")
+#define CND64_I(k) "v_cndmask_b32_e64 %" #k ", %" #k ", %16, s[10:11]"
+DEF_KERNEL(v_cndmask_b32_e64_sgpr, I8(CND64_I), "v_cndmask_b32_e64 %0, %0, %2, s[10:11]")
+#define CMP_I(k) "v_cmp_lt_u32 vcc, %" #k ", %16"
+DEF_KERNEL(v_cmp_lt_u32_vcc, I8(CMP_I), "v_cmp_lt_u32 vcc, %0, %2")
+#define ROR_I(k) "v_alignbit_b32 %" #k ", %" #k ", %" #k ", 7"
+DEF_KERNEL(v_alignbit_rotate, I8(ROR_I), "v_alignbit_b32 %0, %0, %0, 7")
+// the pair the compiler emits for a select: compare into VCC, v_cndmask reading VCC (two instructions per pair: reported per instruction)
+#define CMPSEL_I(k) "v_cmp_lt_u32 vcc, %" #k ", %16\nv_cndmask_b32 %" #k ", %" #k ", %17, vcc"
+DEF_KERNEL(v_cmp_vcc_cndmask_pair, CMPSEL_I(0) "\n" CMPSEL_I(1) "\n" CMPSEL_I(2) "\n" CMPSEL_I(3), "v_cmp_lt_u32 vcc, %0, %2\nv_cndmask_b32 %0, %0, %3, vcc")
+#define CMPSEL64_I(k) "v_cmp_lt_u32_e64 s[10:11], %" #k ", %16\nv_cndmask_b32_e64 %" #k ", %" #k ", %17, s[10:11]"
+DEF_KERNEL(v_cmp_sgpr_cndmask_pair, CMPSEL64_I(0) "\n" CMPSEL64_I(1) "\n" CMPSEL64_I(2) "\n" CMPSEL64_I(3), "v_cmp_lt_u32_e64 s[10:11], %0, %2\nv_cndmask_b32_e64 %0, %0, %3, s[10:11]")
 #define FMA_I(k) "v_fma_f32 %" #k ", %" #k ", %16, %17"
 DEF_KERNEL(v_fma_f32, I8(FMA_I), "v_fma_f32 %0, %0, %2, %3")
 // SHA-2 style ops
@@ -141,7 +170,9 @@ int main() {
       E(v_mul_u32_u24_dpp_row_ror, 64, 64), E(v_mad_u32_u24, 64, 64), E(v_mul_lo_u32, 64, 64), E(v_mul_hi_u32, 64, 64), E(v_mad_u64_u32, 64, 64),
       E(v_mad_i64_i32, 64, 64), E(v_lshlrev_b64, 64, 64), E(v_ashrrev_i64, 64, 64), E(v_mov_b32_dpp_quad_perm, 64, 64),
       E(v_mov_b32_dpp_row_newbcast, 64, 64), E(v_add_u32_dpp_quad_perm, 64, 64), E(v_permlane16_swap_b32, 64, 64),
-      E(v_permlane32_swap_b32, 64, 64), E(v_fma_f32, 64, 64), E(v_add_co_addc_pair, 64, 128)};
+      E(v_permlane32_swap_b32, 64, 64), E(v_sub_u32, 64, 64), E(v_and_b32, 64, 64), E(v_or_b32, 64, 64), E(v_lshlrev_b32, 64, 64),
+      E(v_lshrrev_b32, 64, 64), E(v_ashrrev_i32, 64, 64), E(v_mov_b32, 64, 64), E(v_not_b32, 64, 64), E(v_min_u32, 64, 64), E(v_cndmask_b32_e64_sgpr, 64, 64),
+      E(v_cmp_lt_u32_vcc, 64, 64), E(v_alignbit_rotate, 64, 64), E(v_cmp_vcc_cndmask_pair, 64, 128), E(v_cmp_sgpr_cndmask_pair, 64, 128), E(v_fma_f32, 64, 64), E(v_add_co_addc_pair, 64, 128)};
   std::printf("%-28s %9s %9s %9s | %s\n", "opcode", "lat W=1", "dep W=1", "half W=1",
               "throughput: cycles per wave64 instruction per SIMD at W = 1, 2, 4, 8, 16 waves per SIMD offered (kernel wall time x 2.4 GHz x SIMDs / wave-instructions)");
   hipEvent_t e0, e1;
