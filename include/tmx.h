@@ -303,6 +303,27 @@ int32_t tmx_ntt_goldilocks_device(tmx_ctx* ctx, uint32_t log_n, uint32_t n_cols,
 int32_t tmx_lde_goldilocks_device(tmx_ctx* ctx, uint32_t log_n, uint32_t log_blowup, uint32_t n_cols, const uint64_t* d_in,
                                   uint64_t* d_out, void* hip_stream);
 
+/* ---- Poseidon over Goldilocks + Merkle caps ("commit primitives": what a plonky2-style prover does with the LDE'd trace
+ * columns -- the reference reaches it through plonky2x `prove`, reference circuits/skip.rs:119-133; plonky2 0.2.0 is an un-vendored
+ * dependency, Cargo.lock:2957-2982).  Width 12 (rate 8, capacity 4), S-box x^7, 4 + 22 + 4 rounds, MDS = circulant + diagonal:
+ * new[r] = sum_i circ[i] old[(i + r) mod 12] + diag[r] old[r]; hash_no_pad = overwrite-mode sponge; leaf of a row of C columns = the row
+ * itself (zero padded) if C <= 4, else hash_no_pad(row); two_to_one(l, r) = permute(l | r | 0000)[0..4).
+ * PARITY UNPINNED: plonky2's 360 round constants are not in the reference tree and cannot be recalled, so the default round constants are
+ * the Poseidon paper's own Grain-LFSR stream for these parameters (field 1, sbox 0, n 64, t 12, R_F 8, R_P 22) -- NOT plonky2's table; the
+ * default MDS is the circulant recalled from plonky2 (17 15 41 16 2 28 13 13 39 18 34 20, diagonal 8 0 .. 0).  tmx_poseidon_set_constants
+ * injects the real tables (any argument NULL keeps the current one; values are taken mod p).  Checked against the CPU oracle and
+ * an independent Python model; the algebraic self-checks (bijection through the inverse permutation, MDS invertible) are in tests/.
+ * tmx_poseidon_merkle_device: n_cols columns of 2^log_n u64 (column c at element c << log_n, e.g. the output of tmx_lde_goldilocks_device),
+ * device pointers, asynchronous on hip_stream.  d_levels receives tmx_poseidon_merkle_digests() digests of 4 u64: the 2^log_n leaf digests,
+ * then each level above them down to the cap (the last 2^cap_height digests). */
+int32_t tmx_poseidon_set_constants(tmx_ctx* ctx, const uint64_t* round_constants /*[360]*/, const uint64_t* mds_circ /*[12]*/,
+                                   const uint64_t* mds_diag /*[12]*/);
+uint64_t tmx_poseidon_merkle_digests(uint32_t log_n, uint32_t cap_height);
+int32_t tmx_poseidon_merkle_device(tmx_ctx* ctx, uint32_t log_n, uint32_t n_cols, const uint64_t* d_cols, uint32_t cap_height, uint64_t* d_levels,
+                                   void* hip_stream);
+/* n permutations of caller-provided states (host buffers, 12 u64 each, blocking): test hook and micro-benchmark */
+int32_t tmx_poseidon_permute(tmx_ctx* ctx, uint32_t n, const uint64_t* states_in, uint64_t* states_out);
+
 /* Self-test hook: k_ed_fin inverts with Bernstein-Yang division steps (inv25519.hpp); this runs that inversion and the Fermat chain
  * on n caller-provided values (eight little-endian words each, taken mod 2^255 - 19) and returns both results per value:
  * out_words[16 i .. 16 i + 7] = Fermat, out_words[16 i + 8 .. 16 i + 15] = division steps.  Host buffers, blocking. */

@@ -105,6 +105,16 @@ void tmxo_ntt_set_domain(uint64_t root_2_32, uint64_t coset_shift);
 void tmxo_ntt(uint64_t* x, uint32_t log_n, int inverse);
 void tmxo_lde(const uint64_t* in, uint64_t* out, uint32_t log_n, uint32_t log_blowup);
 
+/* ---- Poseidon over Goldilocks + Merkle caps (tmxo_poseidon.c; SURVEY 8(f) rank 2 "commit primitives"; constants injectable, the defaults
+ * are NOT plonky2's: see the file header -- parity unpinned) */
+void tmxo_poseidon_grain_constants(uint64_t* out, uint32_t count);
+void tmxo_poseidon_set_constants(const uint64_t* rc, const uint64_t* circ, const uint64_t* diag);
+void tmxo_poseidon_get_constants(uint64_t* rc, uint64_t* circ, uint64_t* diag);
+void tmxo_poseidon_permute(uint64_t state[12]);
+void tmxo_poseidon_hash_no_pad(const uint64_t* in, size_t n, uint64_t out[4]);
+void tmxo_poseidon_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]);
+int tmxo_poseidon_merkle(const uint64_t* cols, uint32_t log_n, uint32_t n_cols, uint32_t cap_height, uint64_t* levels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -251,3 +251,37 @@ def lde(values, log_blowup):
         c = np.ascontiguousarray(c)
         L.tmxo_lde(c.ctypes.data, out[i].ctypes.data, log_n, log_blowup)
     return out[0] if a.ndim == 1 else out
+
+
+# ---- Poseidon over Goldilocks + Merkle caps (oracle/c/tmxo_poseidon.c)
+def poseidon_constants():
+    rc, circ, diag = (C.c_uint64 * 360)(), (C.c_uint64 * 12)(), (C.c_uint64 * 12)()
+    lib().tmxo_poseidon_get_constants(rc, circ, diag)
+    return list(rc), list(circ), list(diag)
+
+
+def poseidon_set_constants(rc=None, circ=None, diag=None):
+    lib().tmxo_poseidon_set_constants((C.c_uint64 * 360)(*rc) if rc else None, (C.c_uint64 * 12)(*circ) if circ else None,
+                                      (C.c_uint64 * 12)(*diag) if diag else None)
+
+
+def poseidon_permute(states):
+    a = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 12).copy()
+    L = lib()
+    L.tmxo_poseidon_permute.argtypes = [C.c_void_p]
+    for i in range(a.shape[0]):
+        L.tmxo_poseidon_permute(a[i].ctypes.data)
+    return a
+
+
+def poseidon_merkle(cols, log_n, n_cols, cap_height):
+    """cols: uint64 [n_cols << log_n] column-major.  Returns the levels (leaves .. cap) as one uint64 array of 4-element digests."""
+    a = np.ascontiguousarray(cols, dtype=np.uint64)
+    total = sum(1 << (log_n - k) for k in range(log_n - cap_height + 1))
+    out = np.zeros(4 * total, dtype=np.uint64)
+    L = lib()
+    L.tmxo_poseidon_merkle.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    rc = L.tmxo_poseidon_merkle(a.ctypes.data, log_n, n_cols, cap_height, out.ctypes.data)
+    if rc:
+        raise RuntimeError(f"tmxo_poseidon_merkle rc={rc}")
+    return out.reshape(-1, 4)

@@ -148,6 +148,11 @@ def lib():
     L.tmx_ntt_set_domain.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
     L.tmx_ntt_goldilocks_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.tmx_lde_goldilocks_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tmx_poseidon_set_constants.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tmx_poseidon_merkle_digests.restype = C.c_uint64
+    L.tmx_poseidon_merkle_digests.argtypes = [C.c_uint32, C.c_uint32]
+    L.tmx_poseidon_merkle_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.tmx_poseidon_permute.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.tmx_selftest_fe_invert.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.tmx_selftest_f16.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.tmx_eddsa_lanes_device.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]

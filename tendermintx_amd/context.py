@@ -174,6 +174,23 @@ class Context:
     def lde_device(self, log_n, log_blowup, n_cols, d_in, d_out, stream=None):
         check(self._L.tmx_lde_goldilocks_device(self._h, log_n, log_blowup, n_cols, d_in, d_out, self._stream(stream)), self._h)
 
+    # ---- Poseidon over Goldilocks + Merkle caps (tmx_poseidon_*)
+    def poseidon_set_constants(self, round_constants=None, mds_circ=None, mds_diag=None):
+        arr = lambda v, n: (C.c_uint64 * n)(*[int(x) for x in v]) if v is not None else None
+        check(self._L.tmx_poseidon_set_constants(self._h, arr(round_constants, 360), arr(mds_circ, 12), arr(mds_diag, 12)), self._h)
+
+    def poseidon_permute(self, states):
+        a = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 12)
+        out = np.zeros_like(a)
+        check(self._L.tmx_poseidon_permute(self._h, a.shape[0], a.ctypes.data, out.ctypes.data), self._h)
+        return out
+
+    def poseidon_merkle_digests(self, log_n, cap_height):
+        return int(self._L.tmx_poseidon_merkle_digests(log_n, cap_height))
+
+    def poseidon_merkle_device(self, log_n, n_cols, d_cols, cap_height, d_levels, stream=None):
+        check(self._L.tmx_poseidon_merkle_device(self._h, log_n, n_cols, d_cols, cap_height, d_levels, self._stream(stream)), self._h)
+
     def eddsa_lanes_device(self, n_lanes, d_lanes, d_ed_out, stream=None):
         check(self._L.tmx_eddsa_lanes_device(self._h, n_lanes, d_lanes, d_ed_out, self._stream(stream)), self._h)
 

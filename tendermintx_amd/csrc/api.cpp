@@ -15,6 +15,7 @@
 
 #include "kernels.h"
 #include "ntt.h"
+#include "poseidon.h"
 #include "trace.h"
 #include "tmx.h"
 
@@ -322,6 +323,10 @@ struct tmx_ctx {
   // NTT domain: primitive 2^32-th root of unity and coset shift.  Default: the constants recalled from plonky2's GoldilocksField
   // (POWER_OF_TWO_GENERATOR, MULTIPLICATIVE_GROUP_GENERATOR; self-consistent: the first is the second to the (p-1)/2^32).
   uint64_t ntt_root = 7277203076849721926ull, ntt_shift = 14293326489335486720ull;
+  // Poseidon: round constants | MDS circulant | MDS diagonal, host copy and device copy (uploaded on first use / on change)
+  std::vector<uint64_t> pos_consts;
+  void* d_pos_consts = nullptr;
+  bool pos_dirty = true, pos_mds_small = true;
 };
 
 static int32_t fail(tmx_ctx* c, int32_t st, const std::string& msg) {
@@ -779,6 +784,7 @@ void tmx_ctx_destroy(tmx_ctx* c) {
     for (void* m : dir)
       if (m) (void)hipFree(m);
   if (c->d_ntt_tmp) (void)hipFree(c->d_ntt_tmp);
+  if (c->d_pos_consts) (void)hipFree(c->d_pos_consts);
   for (auto& set : c->ev)
     for (auto& e : set)
       if (e) (void)hipEventDestroy(e);
@@ -1454,6 +1460,119 @@ int32_t tmx_selftest_fe_invert(tmx_ctx* c, uint32_t n, const uint32_t* in_words,
   if (d_in) (void)hipFree(d_in);
   if (d_out) (void)hipFree(d_out);
   if (e != hipSuccess) return fail(c, TMX_ERR_HIP, std::string("tmx_selftest_fe_invert: ") + hipGetErrorString(e));
+  return TMX_OK;
+}
+
+}  // extern "C"
+
+// ---- Poseidon over Goldilocks + Merkle caps --------------------------------------------------------------------------------------
+// default round constants: the Poseidon paper's Grain LFSR (80 bits: field 1 | sbox 0 | n 64 | t 12 | R_F 8 | R_P 22 | thirty ones; 160 bits
+// discarded; bits taken in pairs, the second kept when the first is 1; 64-bit big-endian integers, rejected when >= p) -- a third
+// implementation beside the two of the test oracle (tests compare the streams)
+static void poseidon_default_constants(std::vector<uint64_t>& k) {
+  k.assign(POS_CONST_WORDS, 0);
+  uint8_t st[80];
+  int n = 0;
+  const uint32_t fields[6][2] = {{1, 2}, {0, 4}, {64, 12}, {POS_T, 12}, {POS_RF, 10}, {POS_RP, 10}};
+  for (auto& f : fields)
+    for (int i = (int)f[1] - 1; i >= 0; i--) st[n++] = (uint8_t)((f[0] >> i) & 1u);
+  while (n < 80) st[n++] = 1;
+  int head = 0;
+  auto next = [&]() {
+    const uint8_t b = st[(head + 62) % 80] ^ st[(head + 51) % 80] ^ st[(head + 38) % 80] ^ st[(head + 23) % 80] ^ st[(head + 13) % 80] ^ st[head];
+    st[head] = b;
+    head = (head + 1) % 80;
+    return b;
+  };
+  for (int i = 0; i < 160; i++) (void)next();
+  uint32_t got = 0;
+  while (got < POS_ROUNDS * POS_T) {
+    uint64_t v = 0;
+    for (int bits = 0; bits < 64;) {
+      const uint8_t a = next(), b = next();
+      if (a) { v = (v << 1) | b; bits++; }
+    }
+    if (v < 0xffffffff00000001ull) k[got++] = v;
+  }
+  static const uint64_t circ[POS_T] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  for (uint32_t i = 0; i < POS_T; i++) { k[POS_ROUNDS * POS_T + i] = circ[i]; k[POS_ROUNDS * POS_T + POS_T + i] = i == 0 ? 8 : 0; }
+}
+static int32_t poseidon_ready(tmx_ctx* c, hipStream_t s) {
+  if (c->pos_consts.empty()) poseidon_default_constants(c->pos_consts);
+  if (!c->d_pos_consts) {
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipMalloc(&c->d_pos_consts, POS_CONST_WORDS * 8));
+    c->pos_dirty = true;
+  }
+  if (c->pos_dirty) {
+    HIPCK(c, hipMemcpyAsync(c->d_pos_consts, c->pos_consts.data(), POS_CONST_WORDS * 8, hipMemcpyHostToDevice, s));
+    HIPCK(c, hipStreamSynchronize(s));  // once per change of the tables: later calls may come on another stream
+    c->pos_dirty = false;
+    c->pos_mds_small = true;
+    for (uint32_t i = POS_ROUNDS * POS_T; i < POS_CONST_WORDS; i++)
+      if (c->pos_consts[i] >> 16) c->pos_mds_small = false;
+  }
+  return TMX_OK;
+}
+
+extern "C" {
+
+int32_t tmx_poseidon_set_constants(tmx_ctx* c, const uint64_t* rc, const uint64_t* circ, const uint64_t* diag) {
+  if (!c) return TMX_ERR_BAD_ARG;
+  if (c->pos_consts.empty()) poseidon_default_constants(c->pos_consts);
+  const uint64_t P = 0xffffffff00000001ull;
+  if (rc) for (uint32_t i = 0; i < POS_ROUNDS * POS_T; i++) c->pos_consts[i] = rc[i] % P;
+  if (circ) for (uint32_t i = 0; i < POS_T; i++) c->pos_consts[POS_ROUNDS * POS_T + i] = circ[i] % P;
+  if (diag) for (uint32_t i = 0; i < POS_T; i++) c->pos_consts[POS_ROUNDS * POS_T + POS_T + i] = diag[i] % P;
+  if (c->d_pos_consts) {  // kernels in flight may still read the old tables
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipDeviceSynchronize());
+  }
+  c->pos_dirty = true;
+  return TMX_OK;
+}
+
+uint64_t tmx_poseidon_merkle_digests(uint32_t log_n, uint32_t cap_height) {
+  if (log_n > 30 || cap_height > log_n) return 0;
+  uint64_t total = 0;
+  for (uint32_t k = 0; k + cap_height <= log_n; k++) total += 1ull << (log_n - k);
+  return total;
+}
+
+int32_t tmx_poseidon_merkle_device(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const uint64_t* d_cols, uint32_t cap_height, uint64_t* d_levels,
+                                   void* hip_stream) {
+  if (!c || !d_cols || !d_levels || n_cols == 0) return TMX_ERR_BAD_ARG;
+  if (log_n > 30 || cap_height > log_n) return fail(c, TMX_ERR_BAD_ARG, "cap_height must not exceed log_n (<= 30)");
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  int32_t st = poseidon_ready(c, s);
+  if (st) return st;
+  int rc = launch_poseidon_leaves(c->d_pos_consts, c->pos_mds_small, log_n, n_cols, d_cols, d_levels, s);
+  uint64_t* cur = d_levels;
+  for (uint32_t k = 0; !rc && k + cap_height < log_n; k++) {
+    const uint64_t cnt = 1ull << (log_n - k);
+    rc = launch_poseidon_level(c->d_pos_consts, c->pos_mds_small, cnt / 2, cur, cur + 4 * cnt, s);
+    cur += 4 * cnt;
+  }
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_poseidon launch: ") + hipGetErrorString((hipError_t)rc));
+  return TMX_OK;
+}
+
+int32_t tmx_poseidon_permute(tmx_ctx* c, uint32_t n, const uint64_t* in, uint64_t* out) {
+  if (!c || !in || !out) return TMX_ERR_BAD_ARG;
+  if (n == 0) return TMX_OK;
+  HIPCK(c, hipSetDevice(c->cfg.device));
+  int32_t st = poseidon_ready(c, c->side2);
+  if (st) return st;
+  void *d_in = nullptr, *d_out = nullptr;
+  hipError_t e = hipMalloc(&d_in, (size_t)n * 96);
+  if (e == hipSuccess) e = hipMalloc(&d_out, (size_t)n * 96);
+  if (e == hipSuccess) e = hipMemcpy(d_in, in, (size_t)n * 96, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = (hipError_t)launch_poseidon_permute(c->d_pos_consts, c->pos_mds_small, n, d_in, d_out, c->side2);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->side2);
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * 96, hipMemcpyDeviceToHost);
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(c, TMX_ERR_HIP, std::string("tmx_poseidon_permute: ") + hipGetErrorString(e));
   return TMX_OK;
 }
 

@@ -17,67 +17,10 @@
 
 #include <cstdint>
 
+#include "goldilocks.hpp"
 #include "ntt.h"
 
 namespace tmx {
-
-constexpr uint64_t GL_P = 0xffffffff00000001ull, GL_EPS = 0xffffffffull;
-
-__device__ __forceinline__ uint64_t gl_canon(uint64_t x) { return x >= GL_P ? x - GL_P : x; }
-__device__ __forceinline__ uint64_t gl_add(uint64_t a, uint64_t b) {  // a, b < p
-  unsigned long long s;
-  const bool carry = __builtin_uaddll_overflow(a, b, &s);
-  s += carry ? GL_EPS : 0ull;  // 2^64 = 2^32 - 1 (mod p); cannot wrap again and stays below p
-  return gl_canon(s);
-}
-__device__ __forceinline__ uint64_t gl_sub(uint64_t a, uint64_t b) {
-  unsigned long long d;
-  const bool borrow = __builtin_usubll_overflow(a, b, &d);
-  d += borrow ? GL_P : 0ull;
-  return d;
-}
-__device__ __forceinline__ uint64_t gl_neg(uint64_t a) { return a ? GL_P - a : 0; }
-// "Lazy" forms for the transform kernels: values are any 64-bit representative of their class; only the second operand of a butterfly is
-// made canonical (both corrections below rely on b < p), and the final store canonicalizes.  (Saves the closing compare-and-subtract of
-// every product, shift and load: 9 % of the kernel's instructions.)
-__device__ __forceinline__ uint64_t gl_add_lazy(uint64_t a, uint64_t b) {  // any a, b < p -> any
-  unsigned long long s;
-  const bool carry = __builtin_uaddll_overflow(a, b, &s);
-  return s + (carry ? GL_EPS : 0ull);  // after a carry s <= p - 2: cannot wrap again
-}
-__device__ __forceinline__ uint64_t gl_sub_lazy(uint64_t a, uint64_t b) {  // any a, b < p -> any
-  unsigned long long d;
-  const bool borrow = __builtin_usubll_overflow(a, b, &d);
-  return d - (borrow ? GL_EPS : 0ull);  // after a borrow d >= 2^64 - (p - 1) > EPS: cannot wrap again
-}
-__device__ __forceinline__ uint64_t gl_mul_lazy(uint64_t a, uint64_t b) {  // any a, b -> any
-  // 128-bit product from four 32 x 32 -> 64 multiply-adds (v_mad_u64_u32), no addend can overflow:
-  //   p00 = a0 b0;  p01 = a0 b1 + hi(p00);  p10 = a1 b0 + lo(p01);  p11 = a1 b1 + hi(p01) + hi(p10)
-  const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
-  const uint64_t p00 = (uint64_t)a0 * b0;
-  const uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);
-  const uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
-  const uint64_t hi = (uint64_t)a1 * b1 + ((p01 >> 32) + (p10 >> 32));
-  const uint64_t lo = (p10 << 32) | (uint32_t)p00;
-  const uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;  // x = lo + 2^64 hi_lo + 2^96 hi_hi = lo + (2^32 - 1) hi_lo - hi_hi
-  unsigned long long t0, r;
-  const bool borrow = __builtin_usubll_overflow(lo, hi_hi, &t0);
-  t0 -= borrow ? GL_EPS : 0ull;  // the wrap added 2^64 = p + EPS
-  const uint64_t t1 = (hi_lo << 32) - hi_lo;
-  const bool carry = __builtin_uaddll_overflow(t0, t1, &r);
-  r += carry ? GL_EPS : 0ull;
-  return r;
-}
-__device__ __forceinline__ uint64_t gl_mul(uint64_t a, uint64_t b) { return gl_canon(gl_mul_lazy(a, b)); }
-__device__ __forceinline__ uint64_t gl_pow(uint64_t b, uint64_t e) {
-  uint64_t r = 1;
-  while (e) {
-    if (e & 1) r = gl_mul(r, b);
-    b = gl_mul(b, b);
-    e >>= 1;
-  }
-  return r;
-}
 
 // W[i] = omega_N^i, i < N/2 (at least one entry)
 __global__ __launch_bounds__(256) void k_ntt_table(uint64_t* __restrict__ W, uint32_t log_n, uint64_t root_2_32) {

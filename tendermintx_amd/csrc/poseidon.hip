@@ -1,0 +1,184 @@
+// Poseidon over Goldilocks and the Merkle-cap commitment of LDE'd columns ("commit primitives": what a
+// plonky2-style prover does with the trace columns after the LDE -- the reference reaches it through plonky2x `prove`, reference
+// circuits/skip.rs:119-133; plonky2 itself is absent from the reference tree, Cargo.lock:2957-2982).
+// Definition (include/tmx.h; restated on the CPU by the test oracle): width 12, x^7, 4 + 22 + 4 rounds, circulant-plus-diagonal MDS, overwrite-mode sponge of rate 8,
+// two_to_one, hash_or_noop leaves.  Round constants and MDS rows are DATA (injected through tmx_poseidon_set_constants; the defaults are
+// the Poseidon paper's Grain-LFSR stream, not plonky2's table: parity unpinned), read with scalar loads -- wave-uniform addresses.
+//
+// One permutation per thread, the twelve state elements in 24 VGPRs as arbitrary 64-bit representatives of their classes ("lazy": only the
+// stored digests are canonical).  This is pure 64-bit integer VALU work -- no MFMA (nothing is a dense contraction: the MDS layer is a
+// 12 x 12 product by 6-bit constants), HBM traffic is 8 B in / 0.5 B out per hashed element -- so its roof is VALU issue:
+//   S-box x^7 = 4 field products (4 v_mad_u64_u32 + ~14 for the reduction each), 118 S-boxes per permutation;
+//   MDS layer with small entries: the sums  sum c_i lo(s_i)  and  sum c_i hi(s_i)  over the 32-bit halves fit 64 bits, so a row is
+//   24 v_mad_u64_u32 and ONE reduction (2^32 (h_lo + 2^32 h_hi) = 2^32 h_lo + (2^32 - 1) h_hi) instead of 12 field products.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "goldilocks.hpp"
+#include "poseidon.h"
+
+namespace tmx {
+
+struct PosConsts {
+  const uint64_t* rc;    // [POS_ROUNDS][12]
+  const uint64_t* circ;  // [12]
+  const uint64_t* diag;  // [12]
+};
+__device__ __forceinline__ PosConsts pos_consts(const uint64_t* c) { return PosConsts{c, c + POS_ROUNDS * POS_T, c + POS_ROUNDS * POS_T + POS_T}; }
+
+__device__ __forceinline__ uint64_t pos_sbox(uint64_t x) {
+  const uint64_t x2 = gl_mul_lazy(x, x), x3 = gl_mul_lazy(x2, x), x4 = gl_mul_lazy(x2, x2);
+  return gl_mul_lazy(x3, x4);
+}
+// lo + 2^32 hi for lo, hi < 2^63: any representative
+__device__ __forceinline__ uint64_t pos_fold(uint64_t lo, uint64_t hi) {
+  const uint64_t h_lo = hi & GL_EPS, h_hi = hi >> 32;
+  const uint64_t t = gl_add_lazy(lo, gl_canon(h_lo << 32));     // (h_lo << 32 may be >= p by at most 2^32 - 1... canonical second operand)
+  return gl_add_lazy(t, (h_hi << 32) - h_hi);                    // h_hi < 2^31: (2^32 - 1) h_hi < p
+}
+template <bool SMALL>
+__device__ __forceinline__ void pos_mds(uint64_t (&s)[12], const PosConsts& K) {
+  uint64_t o[12];
+  if (SMALL) {
+    uint32_t lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) { lo[i] = (uint32_t)s[i]; hi[i] = (uint32_t)(s[i] >> 32); }
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+      const uint32_t d = (uint32_t)K.diag[r];
+      uint64_t al = (uint64_t)d * lo[r], ah = (uint64_t)d * hi[r];
+#pragma unroll
+      for (int i = 0; i < 12; i++) {
+        const uint32_t c = (uint32_t)K.circ[i];  // < 2^16: twelve products of 48 bits + one more fit 64 bits with room
+        al += (uint64_t)c * lo[(i + r) % 12];
+        ah += (uint64_t)c * hi[(i + r) % 12];
+      }
+      o[r] = pos_fold(al, ah);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+      uint64_t acc = gl_mul(s[r], K.diag[r]);
+#pragma unroll
+      for (int i = 0; i < 12; i++) acc = gl_add(acc, gl_mul(s[(i + r) % 12], K.circ[i]));
+      o[r] = acc;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = o[i];
+}
+template <bool SMALL>
+__device__ __forceinline__ void pos_permute(uint64_t (&s)[12], const PosConsts& K) {
+#pragma unroll 1
+  for (int r = 0; r < (int)POS_ROUNDS; r++) {
+    const uint64_t* rc = K.rc + r * 12;
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add_lazy(s[i], rc[i]);
+    if (r < (int)POS_RF / 2 || r >= (int)(POS_RF / 2 + POS_RP)) {  // (uniform: a scalar branch)
+#pragma unroll
+      for (int i = 0; i < 12; i++) s[i] = pos_sbox(s[i]);
+    } else {
+      s[0] = pos_sbox(s[0]);
+    }
+    pos_mds<SMALL>(s, K);
+  }
+}
+
+template <bool SMALL>
+__global__ __launch_bounds__(256) void k_poseidon_permute(const uint64_t* __restrict__ consts, uint32_t n, const uint64_t* __restrict__ in,
+                                                          uint64_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const PosConsts K = pos_consts(consts);
+  uint64_t s[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) s[k] = in[(size_t)i * 12 + k];
+  pos_permute<SMALL>(s, K);
+#pragma unroll
+  for (int k = 0; k < 12; k++) out[(size_t)i * 12 + k] = gl_canon(s[k]);
+}
+
+// leaf digest of row r: the row's n_cols values (column c at cols[(c << log_n) + r]: consecutive threads read consecutive addresses of
+// every column), absorbed eight at a time in overwrite mode; rows of at most four values are their own digest (hash_or_noop)
+template <bool SMALL>
+__global__ __launch_bounds__(256) void k_poseidon_leaves(const uint64_t* __restrict__ consts, uint32_t log_n, uint32_t n_cols,
+                                                         const uint64_t* __restrict__ cols, uint64_t* __restrict__ digests) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >> log_n) return;
+  const PosConsts K = pos_consts(consts);
+  uint64_t s[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) s[k] = 0;
+  if (n_cols <= 4) {
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) s[c] = c < n_cols ? gl_canon(cols[((uint64_t)c << log_n) + r]) : 0;  // (inputs are taken mod p: any u64 < 2 p)
+  } else {
+    for (uint32_t c0 = 0; c0 < n_cols; c0 += 8) {
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++)
+        if (c0 + k < n_cols) s[k] = cols[((uint64_t)(c0 + k) << log_n) + r];
+      pos_permute<SMALL>(s, K);
+    }
+  }
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  u64x2 a, b;
+  a.x = gl_canon(s[0]); a.y = gl_canon(s[1]); b.x = gl_canon(s[2]); b.y = gl_canon(s[3]);
+  u64x2* o = reinterpret_cast<u64x2*>(digests + 4 * r);
+  o[0] = a; o[1] = b;
+}
+
+template <bool SMALL>
+__global__ __launch_bounds__(256) void k_poseidon_level(const uint64_t* __restrict__ consts, uint64_t n_out, const uint64_t* __restrict__ in,
+                                                        uint64_t* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const PosConsts K = pos_consts(consts);
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2* p = reinterpret_cast<const u64x2*>(in + 8 * i);
+  const u64x2 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+  uint64_t s[12] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y, 0, 0, 0, 0};
+  pos_permute<SMALL>(s, K);
+  u64x2 a, b;
+  a.x = gl_canon(s[0]); a.y = gl_canon(s[1]); b.x = gl_canon(s[2]); b.y = gl_canon(s[3]);
+  u64x2* o = reinterpret_cast<u64x2*>(out + 4 * i);
+  o[0] = a; o[1] = b;
+}
+
+static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+int launch_poseidon_permute(const void* d_consts, bool mds_small, uint32_t n, const void* d_in, void* d_out, void* stream) {
+  if (n == 0) return 0;
+  const dim3 grid((n + 255) / 256);
+  if (mds_small)
+    hipLaunchKernelGGL(k_poseidon_permute<true>, grid, dim3(256), 0, S_(stream), reinterpret_cast<const uint64_t*>(d_consts), n,
+                       reinterpret_cast<const uint64_t*>(d_in), reinterpret_cast<uint64_t*>(d_out));
+  else
+    hipLaunchKernelGGL(k_poseidon_permute<false>, grid, dim3(256), 0, S_(stream), reinterpret_cast<const uint64_t*>(d_consts), n,
+                       reinterpret_cast<const uint64_t*>(d_in), reinterpret_cast<uint64_t*>(d_out));
+  return (int)hipGetLastError();
+}
+int launch_poseidon_leaves(const void* d_consts, bool mds_small, uint32_t log_n, uint32_t n_cols, const void* d_cols, void* d_digests, void* stream) {
+  const uint64_t n = 1ull << log_n;
+  const dim3 grid((uint32_t)((n + 255) / 256));
+  if (mds_small)
+    hipLaunchKernelGGL(k_poseidon_leaves<true>, grid, dim3(256), 0, S_(stream), reinterpret_cast<const uint64_t*>(d_consts), log_n, n_cols,
+                       reinterpret_cast<const uint64_t*>(d_cols), reinterpret_cast<uint64_t*>(d_digests));
+  else
+    hipLaunchKernelGGL(k_poseidon_leaves<false>, grid, dim3(256), 0, S_(stream), reinterpret_cast<const uint64_t*>(d_consts), log_n, n_cols,
+                       reinterpret_cast<const uint64_t*>(d_cols), reinterpret_cast<uint64_t*>(d_digests));
+  return (int)hipGetLastError();
+}
+int launch_poseidon_level(const void* d_consts, bool mds_small, uint64_t n_out, const void* d_in, void* d_out, void* stream) {
+  if (n_out == 0) return 0;
+  const dim3 grid((uint32_t)((n_out + 255) / 256));
+  if (mds_small)
+    hipLaunchKernelGGL(k_poseidon_level<true>, grid, dim3(256), 0, S_(stream), reinterpret_cast<const uint64_t*>(d_consts), n_out,
+                       reinterpret_cast<const uint64_t*>(d_in), reinterpret_cast<uint64_t*>(d_out));
+  else
+    hipLaunchKernelGGL(k_poseidon_level<false>, grid, dim3(256), 0, S_(stream), reinterpret_cast<const uint64_t*>(d_consts), n_out,
+                       reinterpret_cast<const uint64_t*>(d_in), reinterpret_cast<uint64_t*>(d_out));
+  return (int)hipGetLastError();
+}
+
+}  // namespace tmx
