@@ -458,13 +458,23 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // (a small batch is pure latency: its tail stays on s, two cross-stream hops cost more than the overlap gains)
   const bool tail_aside = K.ser_split && (uint64_t)n_proofs * n >= 4096;
   if (K.ser_split && !tail_aside) {
+    // D.1a (needs the leaves and the hash role, both long done) goes with k_proof's sections on the side stream; what follows the join of
+    // k_proof and the EdDSA finish on s is ONE launch: verdict + the sections that carry it + the seam spans (k_verdict_tail)
+    if (!p1_early) {
+      if (!c->ev_hash_recorded) HIPCK(c, hipEventRecord(c->ev_hash, s));  // (a producer without a phase-1 event: everything it enqueued)
+      HIPCK(c, hipStreamWaitEvent(c->side, c->ev_hash, 0));
+      if ((st0 = serialize(prog.mask_p1, c->side))) return st0;
+    }
+    HIPCK(c, hipEventRecord(c->ev_join, c->side));  // (re-recorded behind the launch just added)
     HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
     const bool xv = K.ext_events && n_proofs != 0;  // the verdict's two timing events ride on its dispatch
     if (!xv) HIPCK(c, hipEventRecord(evs[2], s));
-    rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, row, s, xv ? evs[2] : nullptr, xv ? evs[3] : nullptr);
-    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
+    const bool with_rows = d_out_elems != nullptr;
+    uint32_t tail_mask = (mask_final | prog.mask_tail) & (((c->sections & TMX_SEC_HINT) ? prog.mask_hint : 0u) | ((c->sections & TMX_SEC_DERIVED) ? prog.mask_derived : 0u) | (1u << 31));
+    rc = launch_verdict_tail((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, row, prog.sp, src, c->d_lut[kind], c->d_seams[kind],
+                             (uint32_t)prog.seam_waves.size(), with_rows ? d_out_elems : nullptr, tail_mask, s, xv ? evs[2] : nullptr, xv ? evs[3] : nullptr);
+    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict_tail launch: ") + hipGetErrorString((hipError_t)rc));
     if (!xv) HIPCK(c, hipEventRecord(evs[3], s));
-    if ((st0 = serialize(mask_final | (p1_early ? 0u : prog.mask_p1) | prog.mask_tail, s))) return st0;
     HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
   } else if (K.ser_split) {
     // tail: the per-lane derived section (a quarter of the row) only needs k_ed_fin + k_proof, so it is written on s while the

@@ -80,6 +80,10 @@ int launch_valid_skip(uint32_t n_cand, uint32_t n_max, const void* d_start, uint
 // (row.rows != null: d_ed is the ED part of the unified lane records, and the ten k_proof-derived D.1b elements of every lane are written)
 int launch_verdict(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_ed, uint32_t ed_stride, void* d_pf, void* d_reports, const RowOut& row,
                    void* stream, void* started = nullptr, void* done = nullptr);
+// a few proofs: k_verdict, the serialization of the sections in sec_mask (bit 31: the seam spans) element by element and the seams in ONE launch
+int launch_verdict_tail(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_ed, uint32_t ed_stride, void* d_pf, void* d_reports, const RowOut& row,
+                        const SerializeProgram& S, const SerializeSources& src, const void* d_lut, const void* d_seam_waves, uint32_t n_seams, void* d_out,
+                        uint32_t sec_mask, void* stream, void* started = nullptr, void* done = nullptr);
 // sec_mask: bit s = section s, bit 31 = waves straddling a section boundary / the row end
 int launch_serialize(const SerializeProgram& S, const SerializeSources& src, const void* d_lut, const void* d_wave_sec, const void* d_seam_waves,
                      uint32_t n_seams, uint32_t n_proofs, void* d_out, uint32_t sec_mask, void* stream, uint32_t max_wgs = 0, uint32_t proof0 = 0);
