@@ -387,37 +387,41 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   if (c->last_stream_valid && c->last_stream != s) HIPCK(c, hipStreamWaitEvent(s, c->ev_done, 0));
   HIPCK(c, hipEventRecord(ev[0], s));
   HIPCK(c, hipStreamWaitEvent(c->side, ev[0], 0));
-  HIPCK(c, hipStreamWaitEvent(c->side3, ev[0], 0));
   int32_t st0 = TMX_OK;
-  // side3: the sections that are a pure expansion of the input records (42 % of a skip row) -- HBM is idle while EdDSA runs.
-  // Launches that run beside the EdDSA latency chain are walked by a fixed number of workgroups (k_serialize_few): a memory-bound grid of
-  // half a million short waves keeps every wave slot of the chip taken, and the chain's workgroups then wait for a slot whatever their
-  // priority (a pure store stream beside the EdDSA stage: k_ed_keys 50 -> 103 us, the stage 0.42 -> 0.72 ms).  Four workgroups per CU
-  // still write at the rate these sections need: step -3 % at 256 proofs x 128 (1024 workgroups; 512: the EdDSA stage -48 us but the
-  // sections end after it), -4.5 % at 512, -3 % at 1024 (1536), -1 % at 64, +-0 at 32.
+  int rc = 0;
   const uint32_t beside_chain_wgs = (uint64_t)n_proofs * n >= 131072 ? 1536u : 1024u;
-  if (K.ser_split && (st0 = serialize(prog.mask_inputs, c->side3, beside_chain_wgs))) return st0;
-  HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
   // Leaves first (TMX_LEAVES=1|0, default by size): marshalled validators + leaf hashes as a 10-us launch of their own in front of k_proof,
   // so that the byte fields of the two per-lane derived sections (D.2a: the leaves; D.1a: the leaves + phase 1 -- 42 % of a skip row) are
   // written by the low-priority stream behind the input sections instead of behind k_proof (which ends at ~300 us inside a step) / k_ed_fin.
   // Measured at N = 128: -5 % step at 1024 proofs (on top of the -6 % of D.1a behind k_proof's sections), but +1.5 % at 256, +4.5 % at 512,
   // +8 % at 64: below ~1000 proofs every extra concurrent launch stretches the EdDSA chain by more than the tail it removes.
   const bool leaves_first = K.ser_split && d_out_elems && (K.leaves >= 0 ? K.leaves != 0 : (uint64_t)n_proofs * n >= 131072);
-  // side: k_proof, then the sections that only need its results
-  HIPCK(c, hipEventRecord(evs[0], c->side));
-  int rc = 0;
+  // side: k_proof first -- for a single proof it IS the critical path, and every API call in front of its launch is latency --, its two
+  // timing events on the dispatch itself; then the sections that only need its results
+  const bool xp = K.ext_events && !leaves_first;
+  if (!xp) HIPCK(c, hipEventRecord(evs[0], c->side));
   if (leaves_first) {
     rc = launch_leaves((uint32_t)kind, n, n_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->side, K.ext_events ? c->ev_leaves : nullptr);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_leaves launch: ") + hipGetErrorString((hipError_t)rc));
     if (!K.ext_events) HIPCK(c, hipEventRecord(c->ev_leaves, c->side));
+  }
+  rc = launch_proof(proof_params(c, kind, leaves_first), n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf, c->d_nodes_t,
+                    c->d_nodes_r, reports, c->side, xp ? evs[0] : nullptr, xp ? evs[1] : nullptr);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_proof launch: ") + hipGetErrorString((hipError_t)rc));
+  if (!xp) HIPCK(c, hipEventRecord(evs[1], c->side));
+  // side3: the sections that are a pure expansion of the input records (42 % of a skip row) -- HBM is idle while EdDSA runs.
+  // Launches that run beside the EdDSA latency chain are walked by a fixed number of workgroups (k_serialize_few): a memory-bound grid of
+  // half a million short waves keeps every wave slot of the chip taken, and the chain's workgroups then wait for a slot whatever their
+  // priority (a pure store stream beside the EdDSA stage: k_ed_keys 50 -> 103 us, the stage 0.42 -> 0.72 ms).  Four workgroups per CU
+  // still write at the rate these sections need: step -3 % at 256 proofs x 128 (1024 workgroups; 512: the EdDSA stage -48 us but the
+  // sections end after it), -4.5 % at 512, -3 % at 1024 (1536), -1 % at 64, +-0 at 32.
+  HIPCK(c, hipStreamWaitEvent(c->side3, ev[0], 0));
+  if (K.ser_split && (st0 = serialize(prog.mask_inputs, c->side3, beside_chain_wgs))) return st0;
+  if (leaves_first) {
     HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_leaves, 0));
     if ((st0 = serialize(prog.mask_leaves, c->side3, beside_chain_wgs))) return st0;
   }
-  rc = launch_proof(proof_params(c, kind, leaves_first), n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf, c->d_nodes_t,
-                        c->d_nodes_r, reports, c->side);
-  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_proof launch: ") + hipGetErrorString((hipError_t)rc));
-  HIPCK(c, hipEventRecord(evs[1], c->side));
+  HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
 
   // ev[1] rides on the k_ed_fin dispatch itself (TMX_EXT_EVENTS=0: a record packet behind it)
   c->fin_done = K.ext_events ? ev[1] : nullptr;
@@ -442,30 +446,29 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     if ((st0 = serialize(prog.mask_p1, c->side3, beside_chain_wgs))) return st0;
     HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
   }
-  st0 = K.ser_split ? serialize(prog.mask_proof | (leaves_first ? 0u : prog.mask_leaves), c->side) : TMX_OK;
+  // (a small batch is pure latency: its tail stays on s, two cross-stream hops cost more than the overlap gains)
+  const bool tail_aside = K.ser_split && (uint64_t)n_proofs * n >= 4096;
+  const bool small_tail = K.ser_split && !tail_aside;  // D.1a goes into the SAME launch as k_proof's sections (one launch, behind the hash event)
+  if (small_tail && !leaves_first) {
+    if (!c->ev_hash_recorded) HIPCK(c, hipEventRecord(c->ev_hash, s));  // (a producer without a phase-1 event: everything it enqueued)
+    HIPCK(c, hipStreamWaitEvent(c->side, c->ev_hash, 0));
+  }
+  st0 = K.ser_split ? serialize(prog.mask_proof | (leaves_first ? 0u : prog.mask_leaves) | (small_tail && !leaves_first ? prog.mask_p1 : 0u), c->side) : TMX_OK;
   if (st0) return st0;
   // D.1a (the byte fields of the per-target-lane derived values: a quarter of the row) needs k_proof and phase 1, not k_ed_fin: behind
   // k_proof's sections on the side stream, i.e. while the table walk and the finish run.  Measured (round 2): -6.3 % step at 1024
   // proofs x 128; +-0.5 % at 256 and 64, +1 ... +2 % at 512 proofs (and +7 % at 256 with a warm key cache): on from 131072 lanes
-  const bool p1_early = leaves_first || (K.ser_split && c->ev_hash_recorded && (uint64_t)n_proofs * n >= 131072);
-  if (p1_early && !leaves_first) {
+  const bool p1_early = leaves_first || small_tail || (K.ser_split && c->ev_hash_recorded && (uint64_t)n_proofs * n >= 131072);
+  if (p1_early && !leaves_first && !small_tail) {
     HIPCK(c, hipStreamWaitEvent(c->side, c->ev_hash, 0));
     if ((st0 = serialize(prog.mask_p1, c->side, beside_chain_wgs))) return st0;
   }
   HIPCK(c, hipStreamWaitEvent(c->side, c->ev_join3, 0));  // ev_join = both low-priority streams done
   HIPCK(c, hipEventRecord(c->ev_join, c->side));
   if (!c->fin_done_attached) HIPCK(c, hipEventRecord(ev[1], s));
-  // (a small batch is pure latency: its tail stays on s, two cross-stream hops cost more than the overlap gains)
-  const bool tail_aside = K.ser_split && (uint64_t)n_proofs * n >= 4096;
-  if (K.ser_split && !tail_aside) {
+  if (small_tail) {
     // D.1a (needs the leaves and the hash role, both long done) goes with k_proof's sections on the side stream; what follows the join of
     // k_proof and the EdDSA finish on s is ONE launch: verdict + the sections that carry it + the seam spans (k_verdict_tail)
-    if (!p1_early) {
-      if (!c->ev_hash_recorded) HIPCK(c, hipEventRecord(c->ev_hash, s));  // (a producer without a phase-1 event: everything it enqueued)
-      HIPCK(c, hipStreamWaitEvent(c->side, c->ev_hash, 0));
-      if ((st0 = serialize(prog.mask_p1, c->side))) return st0;
-    }
-    HIPCK(c, hipEventRecord(c->ev_join, c->side));  // (re-recorded behind the launch just added)
     HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
     const bool xv = K.ext_events && n_proofs != 0;  // the verdict's two timing events ride on its dispatch
     if (!xv) HIPCK(c, hipEventRecord(evs[2], s));
@@ -564,7 +567,8 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   // the end of side2's part of a launch: the launch's hash table cleared for the next one, the cache committed
   auto side2_tail = [&]() -> int {
     hipError_t e2;
-    if ((e2 = hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, c->side2)) != hipSuccess) return (int)e2;
+    if ((size_t)c->hash_mask + 1 > KC_EPILOGUE_CLEARS_UP_TO &&  // (small tables: the epilogue clears them itself)
+        (e2 = hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, c->side2)) != hipSuccess) return (int)e2;
     // (with parts > 1 the multiples of the earlier parts run on s: the epilogue only needs the counters k_ed_keys left, not the tables)
     int r2 = launch_kc_epilogue(Q, c->side2);
     if (r2) return r2;
