@@ -202,13 +202,13 @@ int32_t tmx_sync(tmx_ctx* ctx);
  * never / automatic / whenever a table fits).  Blocks. */
 int32_t tmx_last_dedup(tmx_ctx* ctx, uint32_t* n_unique, uint32_t* used_tables);
 
-/* ---- persistent per-key table cache.  h*A of a lane is 43 additions from a 215-KB window table of its public key instead of 252
+/* ---- persistent per-key table cache.  h*A of a lane is 32 additions from a 655-KB window table of its public key instead of 252
  * doublings + 64 additions; the context keeps those tables in a content-addressed cache in HBM (key = the 32 public-key bytes, all 32
  * compared on a hit), so that a validator set that was seen by an earlier call -- a light client re-verifies the same, slowly changing set
  * for days (reference bin/tendermintx.rs:171) -- skips the decode -> doubling chain -> table build entirely.  New keys are inserted by the
  * call that first sees them (a single-proof call builds their tables off its critical path, for the next call); when the cache runs full
  * the least recently used keys are evicted.  Exact group arithmetic on every path: the witness is bit-identical with the cache on, off,
- * cold or warm.  Default capacity: 1024 .. 16384 keys by max_batch * n_max (TMX_KEY_CACHE_KEYS overrides; TMX_KEY_CACHE=0 disables).
+ * cold or warm.  Default capacity: 1024 .. 8192 keys by max_batch * n_max (TMX_KEY_CACHE_KEYS overrides; TMX_KEY_CACHE=0 disables).
  * All three calls block until the context's work in flight is done. */
 typedef struct {
   uint32_t capacity_keys, resident_keys, enabled, epoch;

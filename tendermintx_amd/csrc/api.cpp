@@ -389,7 +389,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   HIPCK(c, hipStreamWaitEvent(c->side, ev[0], 0));
   int32_t st0 = TMX_OK;
   int rc = 0;
-  const uint32_t beside_chain_wgs = (uint64_t)n_proofs * n >= 131072 ? 1536u : 1024u;
+  const uint32_t beside_chain_wgs = (uint64_t)n_proofs * n >= 131072 ? 1536u : 1024u;  // (warm key cache, 256 proofs: 2048 / 4096 / uncapped +10 / +4 / +2 %)
   // Leaves first (TMX_LEAVES=1|0, default by size): marshalled validators + leaf hashes as a 10-us launch of their own in front of k_proof,
   // so that the byte fields of the two per-lane derived sections (D.2a: the leaves; D.1a: the leaves + phase 1 -- 42 % of a skip row) are
   // written by the low-priority stream behind the input sections instead of behind k_proof (which ends at ~300 us inside a step) / k_ed_fin.
@@ -902,10 +902,10 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     HIPCK(c, hipMalloc(&c->d_slot_of_uid, lanes * 4));
     HIPCK(c, hipMalloc(&c->d_owners, lanes * 4));
   }
-  // key cache: by default room for the keys of 4 x max_batch x n_max lanes at 8 lanes per key, between 1024 and 16384 keys (215 KB each:
-  // 0.2 - 3.5 GB of the 288 GB); TMX_KEY_CACHE_KEYS / tmx_key_cache_resize choose another capacity
+  // key cache: by default room for the keys of 4 x max_batch x n_max lanes at 8 lanes per key, between 1024 and 8192 keys (655 KB each:
+  // 0.7 - 5.4 GB of the 288 GB); TMX_KEY_CACHE_KEYS / tmx_key_cache_resize choose another capacity
   {
-    size_t keys = c->knobs.key_cache_keys ? c->knobs.key_cache_keys : std::min<size_t>(16384, std::max<size_t>(1024, lanes / 2));
+    size_t keys = c->knobs.key_cache_keys ? c->knobs.key_cache_keys : std::min<size_t>(8192, std::max<size_t>(1024, lanes / 2));
     int32_t st = alloc_key_cache(c, (uint32_t)keys);
     if (st) return st;
   }
