@@ -1365,7 +1365,9 @@ static int32_t ntt_run(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const void* 
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_ntt_tile launch: ") + hipGetErrorString((hipError_t)rc));
     return TMX_OK;
   }
-  const uint32_t a = (log_n + 1) / 2, b = log_n - a;  // N = N1 N2, N1 = 2^a (pass A, strided), N2 = 2^b (pass B, contiguous)
+  // N = N1 N2, N1 = 2^a (pass A, strided), N2 = 2^b (pass B, contiguous).  (Round 3 re-measured the split and the tile sizes at 2^16 / 2^20 /
+  // 2^22: a = ceil(log_n / 2) -1 / -2 / +1 and tiles of 2^12 / 2^13 / 2^14 elements everywhere -- the balanced split with the tile rule below wins each.)
+  const uint32_t a = (log_n + 1) / 2, b = log_n - a;
   const uint64_t N = (uint64_t)1 << log_n, N1 = (uint64_t)1 << a, N2 = (uint64_t)1 << b;
   // tiles of the two strided passes: T >= 8 sub-transforms side by side (runs of >= 64 B along the unit-stride dimension; with T = 4 at
   // N1 = 2^10, FETCH_SIZE was 4x the data), in the smallest tile that allows it (2^12 .. 2^14 elements: three, two or one workgroup per
