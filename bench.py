@@ -459,8 +459,13 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
         d_tr = torch.empty(P * te, dtype=torch.int64, device=dev)
         bi = tuple(dev_bytes(b) for b in (wl.proofs, wl.targets, wl.trusteds))
         run(ctx, 1, bi)                                       # the Level-1 lane records the trace kernels read
+        tn, sz = 0, n
+        while sz > 1:
+            sz = (sz + 1) // 2
+            tn += sz
         sec_elems = {"ladders": (_lib.TRACE_LADDERS, n * 2 * 256 * 65), "sha512": (_lib.TRACE_SHA512, n * 2880), "sha256": (_lib.TRACE_SHA256, n * 1152),
-                     "match": (_lib.TRACE_MATCH, n * n), "all": (_lib.TRACE_ALL, te)}
+                     "match": (_lib.TRACE_MATCH, n * n), "tree": (_lib.TRACE_TREE, 2 * tn * 1152), "header": (_lib.TRACE_HEADER, 20 * 1152),
+                     "all": (_lib.TRACE_ALL, te)}
         l2 = {}
         for name, (mask, elems) in sec_elems.items():
             ctx.trace_rows_device(KIND_SKIP, P, bi[1].data_ptr(), bi[2].data_ptr(), d_tr.data_ptr(), mask, stream.cuda_stream)
@@ -473,7 +478,8 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
             l2[name] = {"ms": round(ms, 4), "bytes": P * elems * 8, "gbs": round(gbs(P * elems * 8, ms), 1)}
         result["level2_trace_rows"] = {
             "what": "row-level trace of both scalar multiplications (256 rows x 65 elements each), SHA-512 / leaf SHA-256 round states, N x N match "
-                    "bits of every lane of the batch: this build's own row specification, DESIGN.md 'Level-2 trace rows'",
+                    "bits of every lane of the batch, SHA-256 round states of the inner nodes of both validator trees and of the header proofs: "
+                    "this build's own row specification, DESIGN.md 'Level-2 trace rows'",
             "sections": l2, "ms_per_batch": l2["all"]["ms"], "ms_per_proof": round(l2["all"]["ms"] / P, 5),
             "roofline": {"kernel": "k_trace_ladder_pass1 + _pass2", "bound": "hbm", "achieved": l2["ladders"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(l2["ladders"]["gbs"] / HBM_PEAK_GBS, 4), "algorithmic_bytes": l2["ladders"]["bytes"], "traffic": None,
@@ -514,7 +520,7 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
                       "speedup_vs_1_thread": round(per_proof_1 / per_proof_n, 1), "scaling_efficiency": round(per_proof_1 / per_proof_n / cores, 3)}}
     if tr0 is not None:  # constraint checker (oracle/c/tmxo_trace.c) on the rows of proof 0
         a = time.perf_counter()
-        code = oc.trace_check(KIND_SKIP, wl.targets[:n * 256], wl.trusteds[:n * 48], n, tr0)
+        code = oc.trace_check(KIND_SKIP, wl.proofs[:2336], wl.targets[:n * 256], wl.trusteds[:n * 48], n, tr0)
         result["level2_trace_rows"]["constraint_check"] = {"proof": 0, "violations": code, "checker_ms": round(1e3 * (time.perf_counter() - a), 1)}
     ossl = openssl_verify_us(wl, n)
     if ossl is not None:

@@ -230,13 +230,19 @@ int32_t tmx_key_cache_config(tmx_ctx* ctx, uint32_t enabled, uint32_t max_keys);
  *   SHA-512   lane i, block b < 2, 80 rounds x 18: W_t and a..h after the round (64-bit words as lo, hi)
  *   SHA-256   validator leaf hashes of the target (and, for skip, trusted) set: 64 rounds x 9
  *   N x N     skip: signed[i] & (target pubkey i == trusted pubkey j)
+ *   tree      set s, node slot of the fixed-shape validator tree (Level-1 order): 2 blocks x 64 rounds x 9 of SHA-256(01 | L | R) over the
+ *             slot's two children as Level-1 holds them (every pair is hashed, then selected: validator.rs:248-251); promoted slots are zero
+ *   header    the header proofs in Level-1 order (chain id, height, validators hash, X, Y), each the leaf hash and the four path-node
+ *             hashes: 2 blocks x 64 x 9 each (verify.rs:189-209, shared.rs:183-203)
  * tmx_trace_rows_device reads the Level-1 lane records the context holds: call it after tmx_witness_batch_device of the SAME batch, on the
  * same stream.  d_trace_out: n_proofs * tmx_trace_elem_count() u64.  38 MB per proof at N = 128: this launch is HBM-write work. */
 #define TMX_TRACE_LADDERS 1u
 #define TMX_TRACE_SHA512 2u
 #define TMX_TRACE_SHA256 4u
 #define TMX_TRACE_MATCH 8u
-#define TMX_TRACE_ALL 15u
+#define TMX_TRACE_TREE 16u
+#define TMX_TRACE_HEADER 32u
+#define TMX_TRACE_ALL 63u
 uint64_t tmx_trace_elem_count(int32_t kind, uint32_t n_max);
 int32_t tmx_trace_rows_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const void* d_targets, const void* d_trusteds, void* d_trace_out,
                               uint32_t sections, void* hip_stream);

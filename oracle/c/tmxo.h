@@ -87,8 +87,9 @@ double tmxo_witness_pool_seconds(int kind, uint32_t n_proofs, const uint8_t* pro
 /* ---- Level-2 trace rows (tmxo_trace.c, DESIGN.md "Level-2 trace rows"): generator with independent affine arithmetic, and the
  * constraint checker (0 = every row satisfies its recurrence and connects to the inputs / Level-1 values; else an error code) */
 size_t tmxo_trace_elem_count(int kind, size_t n);
-int tmxo_trace(int kind, const uint8_t* target_recs, const uint8_t* trusted_recs, uint32_t n, uint64_t* out);
-long long tmxo_trace_check(int kind, const uint8_t* target_recs, const uint8_t* trusted_recs, uint32_t n, const uint64_t* trace);
+int tmxo_trace(int kind, const uint8_t* proof_rec, const uint8_t* target_recs, const uint8_t* trusted_recs, uint32_t n, uint64_t* out);
+long long tmxo_trace_check(int kind, const uint8_t* proof_rec, const uint8_t* target_recs, const uint8_t* trusted_recs, uint32_t n, const uint64_t* trace);
+int tmxo_header_proof_messages(int kind, const uint8_t* proof_rec, uint8_t msgs[5][5][96], uint32_t lens[5][5], uint8_t digests[5][5][32]);
 void tmxo_trace_ladder(const uint8_t k[32], const uint8_t px[32], const uint8_t py[32], uint64_t* rows);
 int tmxo_trace_ladder_check(const uint64_t* rows, const uint8_t k[32], const uint8_t px[32], const uint8_t py[32], const uint8_t rx[32],
                             const uint8_t ry[32]);
@@ -97,6 +98,8 @@ void tmxo_trace_sha512(const uint8_t* msg, size_t len, uint64_t* rows);
 int tmxo_trace_sha512_check(const uint64_t* rows, const uint8_t* msg, size_t len, const uint8_t digest[64]);
 void tmxo_trace_sha256_1(const uint8_t* msg, size_t len, uint64_t* rows);
 int tmxo_trace_sha256_1_check(const uint64_t* rows, const uint8_t* msg, size_t len, const uint8_t digest[32]);
+void tmxo_trace_sha256_2(const uint8_t* msg, size_t len, uint64_t* rows);
+int tmxo_trace_sha256_2_check(const uint64_t* rows, const uint8_t* msg, size_t len, const uint8_t digest[32]);
 
 /* ---- Goldilocks NTT / coset LDE (tmxo_ntt.c; parity unpinned against plonky2, see the file header) */
 uint64_t tmxo_gl_pow(uint64_t b, uint64_t e);

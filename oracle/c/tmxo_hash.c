@@ -250,3 +250,67 @@ int tmxo_trace_sha256_1_check(const uint64_t* rows, const uint8_t* msg, size_t l
   }
   return 0;
 }
+
+/* SHA-256 of a message of at most 119 bytes (two blocks): 2 x 64 rows of 9 elements [W_t, a .. h after round t]; the second block starts
+ * from the chaining value IV + (a .. h of row 63); the rows of an unused second block are zero.  Inner tree nodes (01 | L | R: 65 bytes,
+ * always two blocks) and the header-proof leaves and path nodes. */
+static size_t pad256(const uint8_t* msg, size_t len, uint8_t buf[128]) {
+  const size_t nb = (len + 9 > 64) ? 2 : 1;
+  memset(buf, 0, 128); memcpy(buf, msg, len); buf[len] = 0x80;
+  const uint64_t bits = (uint64_t)len * 8;
+  for (int i = 0; i < 8; i++) buf[64 * nb - 1 - i] = (uint8_t)(bits >> (8 * i));
+  return nb;
+}
+void tmxo_trace_sha256_2(const uint8_t* msg, size_t len, uint64_t* rows) {
+  uint8_t buf[128];
+  const size_t nb = pad256(msg, len, buf);
+  memset(rows, 0, sizeof(uint64_t) * 2 * 64 * 9);
+  uint32_t st[8];
+  memcpy(st, IV256, sizeof st);
+  for (size_t b = 0; b < nb; b++) {
+    uint32_t w[64], v[8];
+    for (int i = 0; i < 16; i++) { const uint8_t* q = buf + 64 * b + 4 * i; w[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3]; }
+    for (int i = 16; i < 64; i++)
+      w[i] = w[i - 16] + (ror32(w[i - 15], 7) ^ ror32(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] + (ror32(w[i - 2], 17) ^ ror32(w[i - 2], 19) ^ (w[i - 2] >> 10));
+    memcpy(v, st, sizeof v);
+    for (int t = 0; t < 64; t++) {
+      const uint32_t t1 = v[7] + (ror32(v[4], 6) ^ ror32(v[4], 11) ^ ror32(v[4], 25)) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + K256[t] + w[t];
+      const uint32_t t2 = (ror32(v[0], 2) ^ ror32(v[0], 13) ^ ror32(v[0], 22)) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
+      v[7] = v[6]; v[6] = v[5]; v[5] = v[4]; v[4] = v[3] + t1; v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = t1 + t2;
+      uint64_t* row = rows + (b * 64 + t) * 9;
+      row[0] = w[t];
+      for (int k = 0; k < 8; k++) row[1 + k] = v[k];
+    }
+    for (int k = 0; k < 8; k++) st[k] += v[k];
+  }
+}
+/* 0 = holds; else 100 * (block * 64 + round + 1) + constraint number; 4 = the digest */
+int tmxo_trace_sha256_2_check(const uint64_t* rows, const uint8_t* msg, size_t len, const uint8_t digest[32]) {
+  uint8_t buf[128];
+  const size_t nb = pad256(msg, len, buf);
+  uint32_t st[8], prev[8], w[64];
+  memcpy(st, IV256, sizeof st);
+  for (size_t b = 0; b < 2; b++) {
+    if (b >= nb) { for (int i = 0; i < 64 * 9; i++) if (rows[b * 64 * 9 + i]) return 100 * (int)(b * 64 + 1) + 9; continue; }
+    memcpy(prev, st, sizeof prev);
+    for (int t = 0; t < 64; t++) {
+      const uint64_t* row = rows + (b * 64 + t) * 9;
+      const int e = 100 * (int)(b * 64 + t + 1);
+      for (int k = 0; k < 9; k++) if (row[k] >> 32) return e + 1;
+      w[t] = (uint32_t)row[0];
+      uint32_t want;
+      if (t < 16) { const uint8_t* q = buf + 64 * b + 4 * t; want = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3]; }
+      else want = w[t - 16] + (ror32(w[t - 15], 7) ^ ror32(w[t - 15], 18) ^ (w[t - 15] >> 3)) + w[t - 7] + (ror32(w[t - 2], 17) ^ ror32(w[t - 2], 19) ^ (w[t - 2] >> 10));
+      if (w[t] != want) return e + 2;
+      const uint32_t t1 = prev[7] + (ror32(prev[4], 6) ^ ror32(prev[4], 11) ^ ror32(prev[4], 25)) + ((prev[4] & prev[5]) ^ (~prev[4] & prev[6])) + K256[t] + w[t];
+      const uint32_t t2 = (ror32(prev[0], 2) ^ ror32(prev[0], 13) ^ ror32(prev[0], 22)) + ((prev[0] & prev[1]) ^ (prev[0] & prev[2]) ^ (prev[1] & prev[2]));
+      const uint32_t v[8] = {t1 + t2, prev[0], prev[1], prev[2], prev[3] + t1, prev[4], prev[5], prev[6]};
+      for (int k = 0; k < 8; k++) if ((uint32_t)row[1 + k] != v[k]) return e + 3;
+      memcpy(prev, v, sizeof prev);
+    }
+    for (int k = 0; k < 8; k++) st[k] += prev[k];
+  }
+  for (int i = 0; i < 8; i++)
+    if (digest[4 * i] != (uint8_t)(st[i] >> 24) || digest[4 * i + 1] != (uint8_t)(st[i] >> 16) || digest[4 * i + 2] != (uint8_t)(st[i] >> 8) || digest[4 * i + 3] != (uint8_t)st[i]) return 4;
+  return 0;
+}

@@ -370,6 +370,40 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
   return E.n == tmxo_elem_count(kind, n) ? 0 : -2;
 }
 
+/* The SHA-256 messages behind the header proofs of one proof record, in the order Level-1 emits the proofs (chain id, height, validators
+ * hash, X = trusted next-validators hash (skip) / last block id (step), Y = next validators hash (step)): per proof the leaf message
+ * (00 | leaf as the proof struct carries it, cut at 1 + enc_len) and the four path-node messages (01 | left | right, path bits LSB-first),
+ * exactly the values tmxo_witness hashes above.  Level-2 section T.6 traces them.  Returns the number of proofs (4 / 5). */
+int tmxo_header_proof_messages(int kind, const uint8_t* prec, uint8_t msgs[5][5][96], uint32_t lens[5][5], uint8_t digests[5][5][32]) {
+  hdr ha, hb;
+  hdr_load(&ha, prec + 64); hdr_load(&hb, prec + 64 + TMXO_REC_HEADER);
+  const uint64_t height_a = height_from_leaf(ha.leaf[2], ha.len[2]);
+  const int nq = kind == TMXO_KIND_SKIP ? 4 : 5;
+  const int index[5] = {1, 2, 7, kind == TMXO_KIND_SKIP ? 7 : 4, 8};
+  const hdr* from[5] = {&ha, &ha, &ha, kind == TMXO_KIND_SKIP ? &hb : &ha, &hb};
+  memset(msgs, 0, 5 * 5 * 96); memset(lens, 0, sizeof(uint32_t) * 25); memset(digests, 0, 5 * 5 * 32);
+  for (int q = 0; q < nq; q++) {
+    uint8_t* m = msgs[q][0];
+    const hdr* h = from[q];
+    const int f = index[q];
+    if (q == 0) { memcpy(m + 1, h->leaf[1], h->len[1] < 52 ? h->len[1] : 52); lens[q][0] = (uint32_t)(h->len[1] > 79 ? 79 : h->len[1]) + 1; }
+    else if (q == 1) { m[1] = 0x08; tmxo_varint9(height_a, m + 2); lens[q][0] = (uint32_t)(h->len[2] > 79 ? 79 : h->len[2]) + 1; }
+    else { const size_t w = (kind == TMXO_KIND_STEP && q == 3) ? 72 : 34; memcpy(m + 1, h->leaf[f], h->len[f] < w ? h->len[f] : w); lens[q][0] = (uint32_t)w + 1; }
+    tmxo_sha256(m, lens[q][0], digests[q][0]);
+    uint8_t aunts[4][32];
+    rfc6962_aunts(&h->lh[0][0], 14, (size_t)f, aunts);
+    for (int k = 0; k < 4; k++) {
+      uint8_t* nm = msgs[q][1 + k];
+      nm[0] = 0x01;
+      if ((f >> k) & 1) { memcpy(nm + 1, aunts[k], 32); memcpy(nm + 33, digests[q][k], 32); }
+      else { memcpy(nm + 1, digests[q][k], 32); memcpy(nm + 33, aunts[k], 32); }
+      lens[q][1 + k] = 65;
+      tmxo_sha256(nm, 65, digests[q][1 + k]);
+    }
+  }
+  return nq;
+}
+
 /* is_valid_skip (reference circuits/input/tendermint_utils.rs:444-482), loop for loop, on 32-byte address records
  * (address[20], has_address, pad[3], voting_power).  Returns the predicate; *shared / *total as the reference accumulates them
  * (including its early exit, so *shared may be a partial sum when the result is true). */

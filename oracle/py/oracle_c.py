@@ -183,23 +183,24 @@ def trace_elem_count(kind, n):
     return int(L.tmxo_trace_elem_count(kind, n))
 
 
-def trace(kind, target_recs, trusted_recs, n):
+def trace(kind, proof_rec, target_recs, trusted_recs, n):
     """Level-2 trace block of one proof, generated with per-operation affine arithmetic (slow: ~20 ms per lane)."""
     out = np.zeros(trace_elem_count(kind, n), dtype=np.uint64)
-    rc = lib().tmxo_trace(kind, bytes(target_recs), bytes(trusted_recs) if trusted_recs else None, C.c_uint32(n), out.ctypes.data_as(C.POINTER(C.c_uint64)))
+    rc = lib().tmxo_trace(kind, bytes(proof_rec), bytes(target_recs), bytes(trusted_recs) if trusted_recs else None, C.c_uint32(n),
+                          out.ctypes.data_as(C.POINTER(C.c_uint64)))
     if rc:
         raise RuntimeError(f"tmxo_trace rc={rc}")
     return out
 
 
-def trace_check(kind, target_recs, trusted_recs, n, trace_rows):
+def trace_check(kind, proof_rec, target_recs, trusted_recs, n, trace_rows):
     """Constraint checker: 0 if every row satisfies its recurrence and connects to the inputs / Level-1 values, else an error code
     (section * 10^9 + lane * 10^6 + detail)."""
     L = lib()
     L.tmxo_trace_check.restype = C.c_longlong
     a = np.ascontiguousarray(trace_rows, dtype=np.uint64)
     assert a.size == trace_elem_count(kind, n)
-    return int(L.tmxo_trace_check(kind, bytes(target_recs), bytes(trusted_recs) if trusted_recs else None, C.c_uint32(n),
+    return int(L.tmxo_trace_check(kind, bytes(proof_rec), bytes(target_recs), bytes(trusted_recs) if trusted_recs else None, C.c_uint32(n),
                                   a.ctypes.data_as(C.POINTER(C.c_uint64))))
 
 

@@ -15,7 +15,7 @@ N_KERNELS = 4
 KERNEL_NAMES = ("k_eddsa", "k_proof", "k_verdict", "k_serialize")
 ED_STRIDE = 448
 SEC_HINT, SEC_DERIVED, SEC_ALL = 1, 2, 3   # TMX_SEC_*
-TRACE_LADDERS, TRACE_SHA512, TRACE_SHA256, TRACE_MATCH, TRACE_ALL = 1, 2, 4, 8, 15   # TMX_TRACE_*
+TRACE_LADDERS, TRACE_SHA512, TRACE_SHA256, TRACE_MATCH, TRACE_TREE, TRACE_HEADER, TRACE_ALL = 1, 2, 4, 8, 16, 32, 63   # TMX_TRACE_*
 
 
 class ValidatorRec(C.Structure):

@@ -1084,7 +1084,10 @@ int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const
       HIPCK(c, hipEventRecord(c->ev_trace[4], c->side));
     }
   }
-  if (!rc && (sections & ~(uint32_t)TMX_TRACE_LADDERS)) rc = launch_trace_rest((uint32_t)kind, n, n_proofs, d_targets, d_trusteds, d_trace_out, sections, s);
+  if (!rc && (sections & ~(uint32_t)TMX_TRACE_LADDERS)) {
+    const TraceLevel1 L1 = {reinterpret_cast<const uint8_t*>(c->d_tl) + TL_OFF_LT, c->d_lr, c->d_nodes_t, c->d_nodes_r, c->d_pf, TL_STRIDE};
+    rc = launch_trace_rest((uint32_t)kind, n, n_proofs, d_targets, d_trusteds, L1, d_trace_out, sections, s);
+  }
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_trace launch: ") + hipGetErrorString((hipError_t)rc));
   if ((sections & TMX_TRACE_LADDERS) && c->ev_trace[4]) HIPCK(c, hipStreamWaitEvent(s, c->ev_trace[4], 0));  // the call ends on the caller's stream
   return TMX_OK;

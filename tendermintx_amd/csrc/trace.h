@@ -16,7 +16,14 @@ int launch_trace_ladder_pass1(uint32_t n, uint32_t n_proofs, const void* d_targe
                               uint32_t row1, void* stream);
 int launch_trace_ladder_pass2(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_ed, uint32_t ed_stride, const void* d_tmp,
                               void* d_out, uint32_t row0, uint32_t row1, void* stream);
-// sections: bit 1 SHA-512 rounds, 2 leaf SHA-256 rounds, 3 N x N match bits
-int launch_trace_rest(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_trusted, void* d_out, uint32_t sections, void* stream);
+// Level-1 values of the SAME batch the tree / header sections hash over (the context's scratch): per-lane derived records of the target set
+// (d_lt: LT part inside TL, lt_stride) and of the trusted set (d_lr), the tree nodes of both sets, the per-proof derived records
+struct TraceLevel1 {
+  const void *d_lt, *d_lr, *d_nodes_t, *d_nodes_r, *d_pf;
+  uint32_t lt_stride;
+};
+// sections: bit 1 SHA-512 rounds, 2 leaf SHA-256 rounds, 3 N x N match bits, 4 inner tree nodes, 5 header-proof hashes
+int launch_trace_rest(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_trusted, const TraceLevel1& L1, void* d_out,
+                      uint32_t sections, void* stream);
 
 }  // namespace tmx

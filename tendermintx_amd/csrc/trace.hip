@@ -9,6 +9,7 @@
 //                    limbs and stores with one thread per (ladder, eight rows): see the comment at the kernels
 //   k_trace_sha512   one thread per lane, four rounds per flush        k_trace_sha256   one thread per (set, lane)
 //   k_trace_match    one thread per (i, j)
+//   k_trace_sha256x2 one thread per two-block SHA-256: the inner nodes of the validator trees and the header-proof hashes
 #include "trace.h"
 
 #include <hip/hip_runtime.h>
@@ -389,6 +390,128 @@ __global__ __launch_bounds__(64) void k_trace_sha256(uint32_t kind, uint32_t n_l
   }
 }
 
+// T.5 / T.6: SHA-256 of a message of at most two blocks, one thread per hash, over values Level-1 holds in the context's scratch
+//   T.5  item (set, node slot): 01 | L | R over the two children of the slot in the fixed-shape validator tree -- leaf hashes below the
+//        first level, Level-1 nodes above -- hashed for every pair whether or not both are enabled (the circuit selects afterwards,
+//        reference validator.rs:248-251); a promoted slot has zero rows
+//   T.6  item (proof q, hash h): h = 0 the leaf hash 00 | leaf (as the proof struct carries it), h = 1..4 the path nodes 01 | left | right
+//        (verify.rs:189-209, shared.rs:183-203, tendermint_utils.rs:214-224)
+// Items of a proof are contiguous in the output: T.5 (sets x tree_nodes), then T.6 (4 or 5 proofs x 5), 1152 elements each.
+constexpr uint32_t TR_SHA256_2 = 2u * 64u * TR_SHA256_ROW;
+__global__ __launch_bounds__(64) void k_trace_sha256x2(uint32_t kind, uint32_t n_proofs, uint32_t n, uint32_t tn, uint32_t sections,
+                                                       const uint8_t* __restrict__ lt, uint32_t lt_stride, const uint8_t* __restrict__ lr,
+                                                       const uint8_t* __restrict__ nodes_t, const uint8_t* __restrict__ nodes_r,
+                                                       const uint8_t* __restrict__ pf, uint64_t* __restrict__ out, uint64_t proof_stride, uint64_t sec_off) {
+  constexpr int RPF = 8, NV = RPF * TR_SHA256_ROW;
+  __shared__ uint32_t stage[64][NV + 1];
+  __shared__ uint32_t msg[64][33];
+  __shared__ uint64_t s_base[64];
+  __shared__ uint8_t s_live[64];
+  const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t, sets = kind == 0 ? 2u : 1u, nq = kind == 0 ? 4u : 5u;
+  const uint32_t per_proof = sets * tn + nq * 5u;
+  const uint32_t p = id / per_proof, it = id - p * per_proof;
+  const bool tree_item = it < sets * tn;
+  const bool live = p < n_proofs && (sections & (tree_item ? 16u : 32u));
+  s_base[t] = (uint64_t)p * proof_stride + sec_off + (uint64_t)it * TR_SHA256_2;
+  s_live[t] = live ? 1 : 0;
+  uint8_t* mb = reinterpret_cast<uint8_t*>(msg[t]);
+#pragma unroll 1
+  for (int q = 0; q < 32; q++) msg[t][q] = 0u;
+  uint32_t len = 0;  // 0: zero rows
+  if (live && tree_item) {
+    const uint32_t set = it >= tn ? 1u : 0u;
+    uint32_t rem = it - set * tn, sz = n, level = 0, first = 0, prev_first = 0;  // first: slot of the level's first node
+    for (;;) {
+      const uint32_t nx = (sz + 1u) / 2u;
+      if (rem < nx) break;
+      rem -= nx; prev_first = first; first += nx; sz = nx; level++;
+    }
+    if (2u * rem + 1u < sz) {
+      const uint8_t* l;
+      uint32_t step;
+      if (level == 0) {
+        step = set ? LANE_STRIDE : lt_stride;
+        l = (set ? lr : lt) + (size_t)(p * n + 2u * rem) * step + LN_OFF_LEAF;
+      } else {
+        step = 32u;
+        l = (set ? nodes_r : nodes_t) + ((size_t)p * tn + prev_first + 2u * rem) * 32u;
+      }
+      mb[0] = 0x01;
+      for (uint32_t b = 0; b < 32u; b++) { mb[1u + b] = l[b]; mb[33u + b] = l[step + b]; }
+      len = 65u;
+    }
+  } else if (live) {
+    const uint32_t j = it - sets * tn, q = j / 5u, h = j - q * 5u;
+    const uint8_t* r = pf + (size_t)p * PF_STRIDE;
+    if (h == 0) {
+      if (q == 0) {
+        for (uint32_t b = 0; b < 52u; b++) mb[1u + b] = r[PF_OFF_CID52 + b];
+        len = min(ld32(r + PF_OFF_CIDLEN), 79u) + 1u;
+      } else if (q == 1) {
+        for (uint32_t b = 0; b < 11u; b++) mb[b] = r[PF_OFF_HLEAF + b];
+        len = min(ld32(r + PF_OFF_HLEN), 79u) + 1u;
+      } else {
+        const uint32_t off = q == 2 ? PF_OFF_LEAFV : (q == 3 ? PF_OFF_LEAFX : PF_OFF_LEAFY), w = (kind == 1 && q == 3) ? 72u : 34u;
+        for (uint32_t b = 0; b < w; b++) mb[1u + b] = r[off + b];
+        len = w + 1u;
+      }
+    } else {
+      const uint32_t k = h - 1u, index = q == 0 ? 1u : (q == 1 ? 2u : (q == 2 ? 7u : (q == 3 ? (kind == 0 ? 7u : 4u) : 8u)));
+      const uint8_t* cur = r + PF_OFF_PROOFD + q * 160u + k * 32u;
+      const uint8_t* aunt = r + PF_OFF_AUNTS + q * 128u + k * 32u;
+      const bool right = (index >> k) & 1u;  // the running hash is the right child
+      mb[0] = 0x01;
+      for (uint32_t b = 0; b < 32u; b++) { mb[1u + b] = right ? aunt[b] : cur[b]; mb[33u + b] = right ? cur[b] : aunt[b]; }
+      len = 65u;
+    }
+  }
+  const uint32_t n_blocks = len == 0 ? 0u : (len + 9u > 64u ? 2u : 1u);
+  if (len) {
+    mb[len] = 0x80;
+    msg[t][16u * n_blocks - 1u] = __builtin_bswap32(len * 8u);
+  }
+  uint32_t st[8];
+  sha256_init(st);
+#pragma unroll 1
+  for (uint32_t blk = 0; blk < 2u; blk++) {
+    const bool used = blk < n_blocks;
+    uint32_t w[16], v[8];
+#pragma unroll
+    for (int q = 0; q < 16; q++) w[q] = __builtin_bswap32(msg[t][16u * blk + q]);
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = st[q];
+#pragma unroll 1
+    for (int g = 0; g < 64 / RPF; g++) {
+#pragma unroll
+      for (int u = 0; u < RPF; u++) {
+        const int i = g * RPF + u;
+        uint32_t w16 = w[0], w15 = w[0], w7 = w[0], w2 = w[0];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          w16 = ((i) & 15) == q ? w[q] : w16; w15 = ((i + 1) & 15) == q ? w[q] : w15;
+          w7 = ((i + 9) & 15) == q ? w[q] : w7; w2 = ((i + 14) & 15) == q ? w[q] : w2;
+        }
+        uint32_t wt = w16;
+        if (i >= 16) {
+          wt = w16 + (rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3)) + w7 + (rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10));
+#pragma unroll
+          for (int q = 0; q < 16; q++) w[q] = (i & 15) == q ? wt : w[q];
+        }
+        const uint32_t t1 = v[7] + (rotr32(v[4], 6) ^ rotr32(v[4], 11) ^ rotr32(v[4], 25)) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + K_SHA256[i] + wt;
+        const uint32_t t2 = (rotr32(v[0], 2) ^ rotr32(v[0], 13) ^ rotr32(v[0], 22)) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
+        v[7] = v[6]; v[6] = v[5]; v[5] = v[4]; v[4] = v[3] + t1; v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = t1 + t2;
+        uint32_t* o = stage[t] + u * TR_SHA256_ROW;
+        o[0] = used ? wt : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; q++) o[1 + q] = used ? v[q] : 0u;
+      }
+      coop_flush<NV>(stage, s_base, s_live, (uint64_t)(blk * 64u + g * RPF) * TR_SHA256_ROW, out);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) st[q] += v[q];
+  }
+}
+
 // skip: m[i][j] = signed[i] and target pubkey i == trusted pubkey j (verify.rs:398-418, every pair)
 __global__ __launch_bounds__(256) void k_trace_match(uint32_t n_proofs, uint32_t n, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ in_trusted,
                                                      uint64_t* __restrict__ out, uint64_t proof_stride, uint64_t sec_off) {
@@ -407,9 +530,17 @@ __global__ __launch_bounds__(256) void k_trace_match(uint32_t n_proofs, uint32_t
 
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-uint64_t trace_elems(uint32_t kind, uint32_t n) {
+static uint32_t tree_slots(uint32_t n) {  // nodes of the fixed-shape tree, every level (promoted odd nodes included)
+  uint32_t c = 0;
+  while (n > 1) { n = (n + 1) / 2; c += n; }
+  return c;
+}
+static uint64_t trace_off_tree(uint32_t kind, uint32_t n) {
   const uint64_t sets = kind == 0 ? 2 : 1;
   return (uint64_t)n * (2ull * TR_LADDER_ROWS * TR_LADDER_ROW + 2ull * 80 * TR_SHA512_ROW + sets * 64 * TR_SHA256_ROW) + (kind == 0 ? (uint64_t)n * n : 0);
+}
+uint64_t trace_elems(uint32_t kind, uint32_t n) {
+  return trace_off_tree(kind, n) + ((kind == 0 ? 2ull : 1ull) * tree_slots(n) + (kind == 0 ? 4ull : 5ull) * 5) * TR_SHA256_2;
 }
 
 size_t trace_tmp_bytes(uint32_t n, uint32_t n_proofs) { return (size_t)((2ull * n_proofs * n + 63) / 64) * 64 * TR_LADDER_ROWS * TR_PT_WORDS * 4; }
@@ -444,7 +575,8 @@ int launch_trace_ladder_pass2(uint32_t kind, uint32_t n, uint32_t n_proofs, cons
 }
 
 // the other sections (bits 1, 2, 3 of `sections`)
-int launch_trace_rest(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_trusted, void* d_out, uint32_t sections, void* stream) {
+int launch_trace_rest(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_trusted, const TraceLevel1& L1, void* d_out,
+                      uint32_t sections, void* stream) {
   if (n_proofs == 0) return 0;
   const uint32_t lanes = n_proofs * n;
   const uint64_t stride = trace_elems(kind, n);
@@ -457,6 +589,13 @@ int launch_trace_rest(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* 
   if ((sections & 8u) && kind == 0) {
     const uint64_t off = (uint64_t)n * (2ull * TR_LADDER_ROWS * TR_LADDER_ROW + 2ull * 80 * TR_SHA512_ROW + 2ull * 64 * TR_SHA256_ROW);
     hipLaunchKernelGGL(k_trace_match, dim3((n * n + 255) / 256, n_proofs), dim3(256), 0, S_(stream), n_proofs, n, tg, tr, out, stride, off);
+  }
+  if (sections & (16u | 32u)) {
+    const uint32_t tn = tree_slots(n), items = n_proofs * ((kind == 0 ? 2u : 1u) * tn + (kind == 0 ? 4u : 5u) * 5u);
+    hipLaunchKernelGGL(k_trace_sha256x2, dim3((items + 63) / 64), dim3(64), 0, S_(stream), kind, n_proofs, n, tn, sections,
+                       reinterpret_cast<const uint8_t*>(L1.d_lt), L1.lt_stride, reinterpret_cast<const uint8_t*>(L1.d_lr),
+                       reinterpret_cast<const uint8_t*>(L1.d_nodes_t), reinterpret_cast<const uint8_t*>(L1.d_nodes_r), reinterpret_cast<const uint8_t*>(L1.d_pf), out,
+                       stride, trace_off_tree(kind, n));
   }
   return (int)hipGetLastError();
 }

@@ -135,8 +135,9 @@ def test_fuzz_trace_rows(tmx, oracle, seed):
     for p in range(P):
         t = targets[p * n * 256:(p + 1) * n * 256]
         r = trusteds[p * n * 48:(p + 1) * n * 48] if kind == 0 else None
-        assert np.array_equal(got[p], oracle.trace(kind, t, r, n)), (s, p)
-        assert oracle.trace_check(kind, t, r, n, got[p]) == 0, (s, p)
+        pr = proofs[p * 2336:(p + 1) * 2336]
+        assert np.array_equal(got[p], oracle.trace(kind, pr, t, r, n)), (s, p)
+        assert oracle.trace_check(kind, pr, t, r, n, got[p]) == 0, (s, p)
 
 
 def test_one_context_many_different_calls(tmx, oracle):

@@ -14,18 +14,61 @@ def _case(cases, name):
 
 @pytest.mark.parametrize("name", ["skip_10000_10500_n4", "step_10500_n4", "skip_3000_3100_n4"])
 def test_generated_rows_satisfy_every_constraint(oracle, cases, built_lib, name):
-    kind, n, _, targets, trusteds = _case(cases, name)
-    tr = oracle.trace(kind, targets, trusteds, n)
+    kind, n, proof, targets, trusteds = _case(cases, name)
+    tr = oracle.trace(kind, proof, targets, trusteds, n)
     assert tr.size == oracle.trace_elem_count(kind, n) == built_lib.tmx_trace_elem_count(kind, n)
     assert int(tr.max()) < 2**32
-    assert oracle.trace_check(kind, targets, trusteds, n, tr) == 0
+    assert oracle.trace_check(kind, proof, targets, trusteds, n, tr) == 0
     # the last row of every ladder is the Level-1 point: s*B / h*A of the lane (checked inside trace_check against tmxo_eddsa_trace_lane)
     rng = np.random.default_rng(3)
     for _ in range(300):   # any single-bit change of any element breaks a constraint
         i = int(rng.integers(0, tr.size))
         m = tr.copy()
         m[i] ^= np.uint64(1 << int(rng.integers(0, 33)))
-        assert oracle.trace_check(kind, targets, trusteds, n, m) != 0, i
+        assert oracle.trace_check(kind, proof, targets, trusteds, n, m) != 0, i
+
+
+@pytest.mark.parametrize("name", ["skip_10000_10500_n32", "step_10500_n4", "step_10500_n100"])
+def test_tree_and_header_sections(oracle, cases, name):
+    """T.5 / T.6: the traced hashes are the ones Level-1 reports -- the last path node of every proof against a real header is that
+    header's hash (mocha-4 fixtures), the last tree slot's digest is the validators hash in the header -- and a flipped bit anywhere in the
+    two sections is rejected."""
+    import ctypes as C
+    kind, n, proof, targets, trusteds = _case(cases, name)
+    msgs, lens, dgs = (C.c_uint8 * (5 * 5 * 96))(), (C.c_uint32 * 25)(), (C.c_uint8 * (5 * 5 * 32))()
+    nq = oracle.lib().tmxo_header_proof_messages(kind, proof, msgs, lens, dgs)
+    assert nq == (4 if kind == 0 else 5)
+    header = bytes.fromhex(cases[name]["header"])
+    roots = [bytes(dgs[(5 * q + 4) * 32:(5 * q + 5) * 32]) for q in range(nq)]
+    assert roots[0] == roots[1] == roots[2] == header                      # chain id, height, validators hash: proofs against the target header
+    assert roots[3] == (proof[16:48] if kind == 0 else header)              # skip: the trusted header's hash (public input); step: last block id
+    if kind == 1:
+        assert roots[4] == proof[16:48]                                     # next validators hash: a leaf of the previous header
+    assert all(lens[5 * q + h] == 65 for q in range(nq) for h in range(1, 5)) and lens[10] == 35
+    tr = oracle.trace(kind, proof, targets, trusteds, n)
+    sets = 2 if kind == 0 else 1
+    tn, slots = 0, n
+    while slots > 1:
+        slots = (slots + 1) // 2
+        tn += slots
+    o5 = n * (2 * 256 * 65 + 2880 + sets * 576) + (n * n if kind == 0 else 0)
+    assert tr.size == o5 + (sets * tn + nq * 5) * 1152
+    # the digest of the target tree's last slot (its root when every lane is enabled) = IV + the last row of block 1
+    iv = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+    def digest(rows):
+        mid = [(iv[k] + int(rows[63 * 9 + 1 + k])) & 0xffffffff for k in range(8)]
+        return b"".join(struct.pack(">I", (mid[k] + int(rows[127 * 9 + 1 + k])) & 0xffffffff) for k in range(8))
+    nb = struct.unpack_from("<I", proof, 56)[0]
+    if nb >= n:
+        assert digest(tr[o5 + (tn - 1) * 1152:o5 + tn * 1152]) == bytes(msgs[(5 * 2) * 96 + 3:(5 * 2) * 96 + 35])   # = the validators hash leaf value
+    assert digest(tr[o5 + (sets * tn + 4) * 1152:][:1152]) == header
+    rng = np.random.default_rng(9)
+    for _ in range(200):
+        i = int(rng.integers(o5, tr.size))
+        m = tr.copy()
+        m[i] ^= np.uint64(1 << int(rng.integers(0, 33)))
+        rc = oracle.trace_check(kind, proof, targets, trusteds, n, m)
+        assert rc >= 5_000_000_000, (i, rc)
 
 
 def test_ladder_checker_rejects_a_consistent_trace_of_another_scalar(oracle):
@@ -45,7 +88,7 @@ def test_ladder_checker_rejects_a_consistent_trace_of_another_scalar(oracle):
     assert L.tmxo_trace_ladder_check(rows.ctypes.data_as(C.POINTER(C.c_uint64)), k1, bytes(bx), bytes(by), ry, rx) == 257008
 
 
-def _gpu_trace(tmx, kind, n, proofs, targets, trusteds, sections=15):
+def _gpu_trace(tmx, kind, n, proofs, targets, trusteds, sections=63):
     import torch
     P = len(proofs) // 2336
     dev = torch.device("cuda", 0)
@@ -68,8 +111,8 @@ def test_hip_rows_equal_the_generator_and_pass_the_checker(built_lib, oracle, ca
     for name in ("skip_10000_10500_n4", "step_10500_n4"):
         kind, n, proof, targets, trusteds = _case(cases, name)
         got = _gpu_trace(tmx, kind, n, proof, targets, trusteds)
-        assert np.array_equal(got[0], oracle.trace(kind, targets, trusteds, n)), name
-        assert oracle.trace_check(kind, targets, trusteds, n, got[0]) == 0
+        assert np.array_equal(got[0], oracle.trace(kind, proof, targets, trusteds, n)), name
+        assert oracle.trace_check(kind, proof, targets, trusteds, n, got[0]) == 0
     for kind, n, P, nb in ((0, 7, 5, 6), (1, 16, 3, 16), (0, 33, 2, 30)):
         wl = Workload(kind, n, P, nb, chain_id=b"celestia", seed=77 + n, signed_permille=800, rounds=(0, 2))
         targets = bytearray(wl.targets)
@@ -80,8 +123,9 @@ def test_hip_rows_equal_the_generator_and_pass_the_checker(built_lib, oracle, ca
         for p in range(P):
             t = bytes(targets[p * n * 256:(p + 1) * n * 256])
             r = wl.trusteds[p * n * 48:(p + 1) * n * 48] if kind == 0 else None
-            assert np.array_equal(got[p], oracle.trace(kind, t, r, n)), (kind, n, p)
-            assert oracle.trace_check(kind, t, r, n, got[p]) == 0
+            pr = wl.proofs[p * 2336:(p + 1) * 2336]
+            assert np.array_equal(got[p], oracle.trace(kind, pr, t, r, n)), (kind, n, p)
+            assert oracle.trace_check(kind, pr, t, r, n, got[p]) == 0
 
 
 @pytest.mark.gpu
@@ -95,8 +139,9 @@ def test_hip_rows_at_n128(built_lib, oracle):
     got = _gpu_trace(tmx, 0, n, wl.proofs, wl.targets, wl.trusteds)
     for p in range(P):
         t, r = wl.targets[p * n * 256:(p + 1) * n * 256], wl.trusteds[p * n * 48:(p + 1) * n * 48]
-        assert oracle.trace_check(0, t, r, n, got[p]) == 0
-        assert np.array_equal(got[p], oracle.trace(0, t, r, n))
+        pr = wl.proofs[p * 2336:(p + 1) * 2336]
+        assert oracle.trace_check(0, pr, t, r, n, got[p]) == 0
+        assert np.array_equal(got[p], oracle.trace(0, pr, t, r, n))
     only = _gpu_trace(tmx, 0, n, wl.proofs, wl.targets, wl.trusteds, sections=2 | 8)
     lad = n * 2 * 256 * 65
     assert (only[:, :lad] == np.uint64(2**64 - 1)).all() and np.array_equal(only[:, lad:lad + n * 2880], got[:, lad:lad + n * 2880])

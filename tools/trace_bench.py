@@ -23,7 +23,12 @@ tr = torch.empty(P * te, dtype=torch.int64, device=dev)
 s = torch.cuda.Stream(dev)
 ctx.witness_batch_device(KIND_SKIP, P, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), out.data_ptr(), rep.data_ptr(), s.cuda_stream)
 torch.cuda.synchronize()
-secs = {"ladders": (1, n * 2 * 256 * 65), "sha512": (2, n * 2880), "sha256": (4, n * 2 * 576), "match": (8, n * n), "all": (15, te)}
+tn, sz = 0, n
+while sz > 1:
+    sz = (sz + 1) // 2
+    tn += sz
+secs = {"ladders": (1, n * 2 * 256 * 65), "sha512": (2, n * 2880), "sha256": (4, n * 2 * 576), "match": (8, n * n), "tree": (16, 2 * tn * 1152),
+        "header": (32, 20 * 1152), "all": (63, te)}
 for name, (mask, elems) in secs.items():
     for _ in range(2):
         ctx.trace_rows_device(KIND_SKIP, P, d[1].data_ptr(), d[2].data_ptr(), tr.data_ptr(), mask, s.cuda_stream)
