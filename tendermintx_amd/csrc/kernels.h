@@ -9,7 +9,7 @@ namespace tmx {
 
 // persistent per-key table cache of a context (DESIGN.md "Key cache"): device pointers + geometry, passed to the kernels by value
 struct KeyCache {
-  uint32_t cap;        // slots: decoded key record + 215-KB window table each
+  uint32_t cap;        // slots: decoded key record + window table (655 KB at the default 8-bit windows) each
   uint32_t hash_mask;  // open-addressing table of (hash_mask + 1) slot ids, >= 4 * cap
   uint32_t new_cap;    // tables one launch builds at most (anchor scratch)
   uint32_t persist;    // 1: keys stay resident across launches; 0: every launch starts from an empty cache (same code path)

@@ -72,8 +72,8 @@ for seed in range(int(sys.argv[2])):
         assert L.tmxo_witness(kind, pr, tg, tr, C.c_uint32(n), chain, C.c_uint32(len(chain)), C.c_uint64(skip_max), out.ctypes.data_as(C.c_void_p), rep) == 0
         if n <= 4 and p < 2:
             t = np.zeros(L.tmxo_trace_elem_count(kind, n), dtype=np.uint64)
-            assert L.tmxo_trace(kind, tg, tr, C.c_uint32(n), t.ctypes.data_as(C.c_void_p)) == 0
-            assert L.tmxo_trace_check(kind, tg, tr, C.c_uint32(n), t.ctypes.data_as(C.c_void_p)) == 0
+            assert L.tmxo_trace(kind, pr, tg, tr, C.c_uint32(n), t.ctypes.data_as(C.c_void_p)) == 0
+            assert L.tmxo_trace_check(kind, pr, tg, tr, C.c_uint32(n), t.ctypes.data_as(C.c_void_p)) == 0
 print("asan fuzz ok")
 '''
     env = dict(os.environ, LD_PRELOAD=asan_rt, ASAN_OPTIONS="detect_leaks=0")

@@ -267,9 +267,9 @@ rep = (C.c_uint8 * 64)()
 assert L.tmxo_witness(0, p, t, r, C.c_uint32(4), b"mocha-4", C.c_uint32(7), C.c_uint64(100800), out.ctypes.data_as(C.c_void_p), rep) == 0
 L.tmxo_trace_elem_count.restype = C.c_size_t; L.tmxo_trace_elem_count.argtypes = [C.c_int, C.c_size_t]
 tr = np.zeros(L.tmxo_trace_elem_count(0, 4), dtype=np.uint64)
-assert L.tmxo_trace(0, t, r, C.c_uint32(4), tr.ctypes.data_as(C.c_void_p)) == 0
+assert L.tmxo_trace(0, p, t, r, C.c_uint32(4), tr.ctypes.data_as(C.c_void_p)) == 0
 L.tmxo_trace_check.restype = C.c_longlong
-assert L.tmxo_trace_check(0, t, r, C.c_uint32(4), tr.ctypes.data_as(C.c_void_p)) == 0
+assert L.tmxo_trace_check(0, p, t, r, C.c_uint32(4), tr.ctypes.data_as(C.c_void_p)) == 0
 print("asan ok")
 '''
     golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cases.json")
