@@ -71,6 +71,107 @@ def test_tree_and_header_sections(oracle, cases, name):
         assert rc >= 5_000_000_000, (i, rc)
 
 
+def _sha256_rows_digest(rows):
+    """the digest a two-block SHA-256 row group ends in: IV + working variables after round 63 of block 0 (+ those of block 1, if used)"""
+    iv = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+    st = [(iv[k] + int(rows[63 * 9 + 1 + k])) & 0xffffffff for k in range(8)]
+    if rows[64 * 9:].any():
+        st = [(st[k] + int(rows[127 * 9 + 1 + k])) & 0xffffffff for k in range(8)]
+    return b"".join(struct.pack(">I", w) for w in st)
+
+
+@pytest.mark.parametrize("entry_id", ["skip_baseline", "skip_nb3_of_4", "step_valhash_proof_root", "skip_chain_id_root"])
+def test_tree_and_header_rows_against_hashlib(oracle, entry_id):
+    """T.5 / T.6 against an INDEPENDENT restatement (tests/ASSERTS.md "Level-2"): the ledger's scenarios are built with hashlib + OpenSSL
+    only; here every traced digest is recomputed with hashlib from the packed records -- the leaf bytes by the reference's marshalling
+    rule (validator.rs:185-207, shared.rs:67-156), every PAIR of the fixed-shape tree hashed whether or not both children are enabled
+    (validator.rs:248-251 selects afterwards), the proof paths from the header leaves (verify.rs:189-209, shared.rs:183-203) -- and
+    compared with what the traced rows end in.  nb < N, a 35-byte validators-hash field and a 51-character chain id are among them."""
+    import hashlib
+    import ledger
+    e = next(x for x in ledger.ENTRIES if x[0] == entry_id)
+    sc = ledger.build(e[2], **e[3])
+    kind, n, proof, targets, trusteds = sc["kind"], sc["n"], sc["proof"], sc["targets"], sc["trusteds"]
+    tr = oracle.trace(kind, proof, targets, trusteds, n)
+    assert oracle.trace_check(kind, proof, targets, trusteds, n, tr) == 0
+    sha = lambda b: hashlib.sha256(b).digest()
+
+    def varint9(v):
+        s = [(v >> (7 * i)) & 0x7f for i in range(9)]
+        last = max([i for i in range(9) if s[i]] or [0])
+        return bytes(b | (0x80 if i < last else 0) for i, b in enumerate(s))
+
+    def leaf(pk, power, vlen):
+        return sha(b"\x00" + (b"\x0a\x22\x0a\x20" + pk + b"\x10" + varint9(power))[:min(vlen, 46)])
+
+    sets = [[leaf(targets[256 * i:256 * i + 32], struct.unpack_from("<Q", targets, 256 * i + 224)[0], targets[256 * i + 222]) for i in range(n)]]
+    nbs = [struct.unpack_from("<I", proof, 56)[0]]
+    if kind == 0:
+        sets.append([leaf(trusteds[48 * j:48 * j + 32], struct.unpack_from("<Q", trusteds, 48 * j + 32)[0], trusteds[48 * j + 40]) for j in range(n)])
+        nbs.append(struct.unpack_from("<I", proof, 60)[0])
+    tn, sz = 0, n
+    while sz > 1:
+        sz = (sz + 1) // 2
+        tn += sz
+    o5 = n * (2 * 256 * 65 + 2880 + len(sets) * 576) + (n * n if kind == 0 else 0)
+    for s, (cur, nb) in enumerate(zip(sets, nbs)):
+        en, slot = [i < nb for i in range(n)], 0
+        while len(cur) > 1:
+            nxt, nen = [], []
+            for i in range((len(cur) + 1) // 2):
+                rows = tr[o5 + (s * tn + slot) * 1152:o5 + (s * tn + slot + 1) * 1152]
+                if 2 * i + 1 < len(cur):
+                    h = sha(b"\x01" + cur[2 * i] + cur[2 * i + 1])
+                    assert _sha256_rows_digest(rows) == h, (entry_id, s, slot)              # hashed whether enabled or not
+                    nxt.append(h if en[2 * i] and en[2 * i + 1] else cur[2 * i])
+                else:
+                    assert not rows.any()                                                   # a promoted node: no hash, zero rows
+                    nxt.append(cur[2 * i])
+                nen.append(en[2 * i]); slot += 1
+            cur, en = nxt, nen
+    # T.6: chain id (leaf 1), height (2), validators hash (7) of the target header; X, Y as the kind says
+    hdr = lambda off: [proof[off + 16 + 80 * i:off + 16 + 80 * i + min(proof[off + i], 79)] for i in range(14)]
+    ha, hb = hdr(64), hdr(64 + 1136)
+
+    def rfc_root(leaves):
+        if len(leaves) == 1:
+            return leaves[0]
+        k = 1
+        while 2 * k < len(leaves):
+            k *= 2
+        return sha(b"\x01" + rfc_root(leaves[:k]) + rfc_root(leaves[k:]))
+
+    def aunts(leaves, idx):
+        if len(leaves) == 1:
+            return []
+        k = 1
+        while 2 * k < len(leaves):
+            k *= 2
+        return aunts(leaves[:k], idx) + [rfc_root(leaves[k:])] if idx < k else aunts(leaves[k:], idx - k) + [rfc_root(leaves[:k])]
+
+    o6 = o5 + len(sets) * tn * 1152
+    plan = [(ha, 1, 52), (ha, 2, None), (ha, 7, 34)] + ([(hb, 7, 34)] if kind == 0 else [(ha, 4, 72), (hb, 8, 34)])
+    for q, (h, idx, fixed) in enumerate(plan):
+        lh = [sha(b"\x00" + f) for f in h]
+        field = h[idx]
+        if idx == 2:    # the re-encoded height: 00 08 varint9(height), cut at 1 + the field's length (shared.rs:158-194)
+            v, sft = 0, 0
+            for b in field[1:11]:
+                v |= (b & 0x7f) << sft; sft += 7
+            msg = (b"\x00\x08" + varint9(v) + bytes(80))[:1 + len(field)]
+        elif idx == 1:  # chain id resized to 52 bytes, hashed over 1 + the field's length (verify.rs:189-202)
+            msg = (b"\x00" + field[:52].ljust(52, b"\0") + bytes(40))[:1 + len(field)]
+        else:           # the leaf as the proof struct carries it: resized to 34 / 72 bytes
+            msg = b"\x00" + field[:fixed].ljust(fixed, b"\0")
+        cur = sha(msg)
+        assert _sha256_rows_digest(tr[o6 + (5 * q) * 1152:][:1152]) == cur, (entry_id, q, "leaf")
+        for k, aunt in enumerate(aunts(lh, idx)):
+            cur = sha(b"\x01" + (aunt + cur if (idx >> k) & 1 else cur + aunt))
+            assert _sha256_rows_digest(tr[o6 + (5 * q + 1 + k) * 1152:][:1152]) == cur, (entry_id, q, k)
+        if msg == b"\x00" + field:
+            assert cur == rfc_root(lh)      # a leaf that is the header's own: the proof ends in the header hash
+
+
 def test_ladder_checker_rejects_a_consistent_trace_of_another_scalar(oracle):
     """Rows that satisfy every curve relation but belong to scalar k' != k fail the bit-composition constraint."""
     import ctypes as C
