@@ -483,8 +483,10 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
             "sections": l2, "ms_per_batch": l2["all"]["ms"], "ms_per_proof": round(l2["all"]["ms"] / P, 5),
             "roofline": {"kernel": "k_trace_ladder_pass1 + _pass2", "bound": "hbm", "achieved": l2["ladders"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(l2["ladders"]["gbs"] / HBM_PEAK_GBS, 4), "algorithmic_bytes": l2["ladders"]["bytes"], "traffic": None,
-                         "note": "pass 1 (the double-and-add chain, one thread per ladder) is latency-bound, pass 2 (inversions, canonical limbs, "
-                                 "stores; one thread per eight rows) issue-bound at ~44 % of the slots: not yet HBM-bound (DESIGN.md section 3)"}}
+                         "note": "pass 1 (the double-and-add chain, one thread per ladder) is one latency-bound wave per SIMD, pass 2 (inversions, "
+                                 "canonical limbs, stores) waits for its loads at two waves per SIMD; 5.6 k instructions per row put the issue-bound "
+                                 "ceiling at 0.45 of HBM, and the 21 GB the two passes move (4 GB of projective points written and read back) at "
+                                 "~4.8 ms: DESIGN.md 'The writer, measured'"}}
         tr0 = d_tr[:te].cpu().numpy().view(np.uint64)
         del d_tr
     except Exception as e:  # the trace rows are a widening row: never let them take the headline line down
