@@ -235,7 +235,7 @@ int32_t tmx_key_cache_config(tmx_ctx* ctx, uint32_t enabled, uint32_t max_keys);
  *   header    the header proofs in Level-1 order (chain id, height, validators hash, X, Y), each the leaf hash and the four path-node
  *             hashes: 2 blocks x 64 x 9 each (verify.rs:189-209, shared.rs:183-203)
  * tmx_trace_rows_device reads the Level-1 lane records the context holds: call it after tmx_witness_batch_device of the SAME batch, on the
- * same stream.  d_trace_out: n_proofs * tmx_trace_elem_count() u64.  38 MB per proof at N = 128: this launch is HBM-write work. */
+ * same stream.  d_trace_out: n_proofs * tmx_trace_elem_count() u64.  41 MB per proof at N = 128: this launch is HBM-write work. */
 #define TMX_TRACE_LADDERS 1u
 #define TMX_TRACE_SHA512 2u
 #define TMX_TRACE_SHA256 4u
