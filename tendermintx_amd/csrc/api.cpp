@@ -750,32 +750,52 @@ void release_streams(int device) {
 }  // namespace
 
 // (re)allocate the key cache for `keys` slots and empty it.  The caller has made sure nothing of this context is in flight.
+// Transactional: the new buffers are allocated and reset first; the old cache is freed only when all of that succeeded, so a failed
+// (e.g. oversized) request leaves the context exactly as it was.  A request whose tables cannot fit in the device's free memory is
+// refused up front with TMX_ERR_CAPACITY.
 static int32_t alloc_key_cache(tmx_ctx* c, uint32_t keys) {
-  void** bufs[] = {(void**)&c->kc.d_hash, (void**)&c->kc.d_pk, (void**)&c->kc.d_used, (void**)&c->kc.d_free, (void**)&c->kc.d_state, &c->d_keyrec,
-                   &c->d_anchors, &c->d_keytab};
-  for (void** b : bufs)
-    if (*b) { (void)hipFree(*b); *b = nullptr; }
   const size_t lanes = (size_t)c->cfg.max_batch * c->cfg.n_max;
   if (keys > (1u << 20)) keys = 1u << 20;
   if (keys == 0) keys = 1;
   uint64_t hsz = 1;
   while (hsz < 4 * (uint64_t)keys) hsz <<= 1;
-  c->kc.cap = keys;
-  c->kc.hash_mask = (uint32_t)(hsz - 1);
-  c->kc.new_cap = (uint32_t)std::min<size_t>(std::min<size_t>(keys, 4096), lanes);  // tables one launch builds at most: the anchor scratch
-  c->kc.persist = c->knobs.key_cache ? 1u : 0u;
-  c->kc.hint = const_cast<uint32_t*>(c->h_hint);
+  KeyCache kc = c->kc;
+  kc.cap = keys;
+  kc.hash_mask = (uint32_t)(hsz - 1);
+  kc.new_cap = (uint32_t)std::min<size_t>(std::min<size_t>(keys, 4096), lanes);  // tables one launch builds at most: the anchor scratch
+  kc.persist = c->knobs.key_cache ? 1u : 0u;
+  kc.hint = const_cast<uint32_t*>(c->h_hint);
+  kc.d_hash = kc.d_pk = kc.d_used = kc.d_free = kc.d_state = nullptr;
+  const size_t sizes[8] = {(size_t)hsz * 4, (size_t)keys * 32, (size_t)keys * 4, (size_t)keys * 4, (size_t)KC_STATE_WORDS * 4,
+                           ((size_t)keys + lanes) * key_bytes_per_key(), (size_t)kc.new_cap * anchor_bytes_per_key(), (size_t)keys * keytab_bytes_per_key()};
+  {
+    size_t want = 0, free_b = 0, total_b = 0;
+    for (size_t b : sizes) want += b;
+    // (the new cache is allocated before the old one is released, so it has to fit beside it)
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b)
+      return fail(c, TMX_ERR_CAPACITY, "key cache of " + std::to_string(keys) + " keys needs " + std::to_string(want >> 20) + " MiB, " +
+                                           std::to_string(free_b >> 20) + " MiB free on the device");
+  }
+  void* nb[8] = {};
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipMalloc(&nb[i], sizes[i]);
+  if (e == hipSuccess) {
+    kc.d_hash = (uint32_t*)nb[0]; kc.d_pk = (uint32_t*)nb[1]; kc.d_used = (uint32_t*)nb[2]; kc.d_free = (uint32_t*)nb[3]; kc.d_state = (uint32_t*)nb[4];
+    e = (hipError_t)launch_kc_reset(kc, c->side2);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->side2);
+  }
+  if (e != hipSuccess) {  // the old cache stays in place and usable
+    (void)hipGetLastError();
+    for (void* b : nb)
+      if (b) (void)hipFree(b);
+    return fail(c, e == hipErrorOutOfMemory ? TMX_ERR_CAPACITY : TMX_ERR_HIP, std::string("key cache allocation: ") + hipGetErrorString(e));
+  }
+  void* old[] = {c->kc.d_hash, c->kc.d_pk, c->kc.d_used, c->kc.d_free, c->kc.d_state, c->d_keyrec, c->d_anchors, c->d_keytab};
+  for (void* b : old)
+    if (b) (void)hipFree(b);
+  c->kc = kc;
+  c->d_keyrec = nb[5]; c->d_anchors = nb[6]; c->d_keytab = nb[7];
   c->h_hint[0] = 0; c->h_hint[1] = 0;
-  HIPCK(c, hipMalloc((void**)&c->kc.d_hash, hsz * 4));
-  HIPCK(c, hipMalloc((void**)&c->kc.d_pk, (size_t)keys * 32));
-  HIPCK(c, hipMalloc((void**)&c->kc.d_used, (size_t)keys * 4));
-  HIPCK(c, hipMalloc((void**)&c->kc.d_free, (size_t)keys * 4));
-  HIPCK(c, hipMalloc((void**)&c->kc.d_state, KC_STATE_WORDS * 4));
-  HIPCK(c, hipMalloc(&c->d_keyrec, ((size_t)keys + lanes) * key_bytes_per_key()));
-  HIPCK(c, hipMalloc(&c->d_anchors, (size_t)c->kc.new_cap * anchor_bytes_per_key()));
-  HIPCK(c, hipMalloc(&c->d_keytab, (size_t)keys * keytab_bytes_per_key()));
-  int rc = launch_kc_reset(c->kc, c->side2);
-  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_kc_reset launch: ") + hipGetErrorString((hipError_t)rc));
   return TMX_OK;
 }
 
@@ -906,6 +926,8 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   // 0.7 - 5.4 GB of the 288 GB); TMX_KEY_CACHE_KEYS / tmx_key_cache_resize choose another capacity
   {
     size_t keys = c->knobs.key_cache_keys ? c->knobs.key_cache_keys : std::min<size_t>(8192, std::max<size_t>(1024, lanes / 2));
+    // TMX_KEY_CACHE=0: a table lives for one launch only, so the slots one launch can build (<= 4096, <= lanes) are all it ever uses
+    if (!c->knobs.key_cache && !c->knobs.key_cache_keys) keys = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(4096, lanes), keys));
     int32_t st = alloc_key_cache(c, (uint32_t)keys);
     if (st) return st;
   }
@@ -979,6 +1001,7 @@ int32_t tmx_key_cache_flush(tmx_ctx* c) {
   int rc = launch_kc_reset(c->kc, c->side2);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_kc_reset launch: ") + hipGetErrorString((hipError_t)rc));
   HIPCK(c, hipStreamSynchronize(c->side2));
+  c->h_hint[0] = 0; c->h_hint[1] = 0;  // an empty cache: the next enqueue takes the cold schedule, as the first call of a context does
   return TMX_OK;
 }
 
@@ -986,11 +1009,18 @@ int32_t tmx_key_cache_config(tmx_ctx* c, uint32_t enabled, uint32_t max_keys) {
   if (!c) return TMX_ERR_BAD_ARG;
   int32_t q = quiesce(c);
   if (q) return q;
+  const bool was = c->knobs.key_cache;
   c->knobs.key_cache = enabled != 0;
   if (max_keys != 0 && max_keys != c->kc.cap) {
-    int32_t st = alloc_key_cache(c, max_keys);
-    if (st) return st;
+    int32_t st = alloc_key_cache(c, max_keys);  // (on failure the old cache, and the old setting, stay)
+    if (st) { c->knobs.key_cache = was; return st; }
+  } else if (was && !enabled) {
+    // persistence switched off: every launch starts from an empty cache, so the resident keys go now (a full cache would otherwise
+    // leave the launches without free slots, i.e. without per-launch tables)
+    int rc = launch_kc_reset(c->kc, c->side2);
+    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_kc_reset launch: ") + hipGetErrorString((hipError_t)rc));
     HIPCK(c, hipStreamSynchronize(c->side2));
+    c->h_hint[0] = 0; c->h_hint[1] = 0;
   }
   c->kc.persist = enabled ? 1u : 0u;
   return TMX_OK;

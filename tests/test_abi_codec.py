@@ -135,3 +135,62 @@ def test_product_never_touches_the_oracle():
     import subprocess
     syms = subprocess.check_output(["nm", "-D", os.path.join(ROOT, "tendermintx_amd", "libtmx.so")]).decode()
     assert "tmxo_" not in syms
+
+
+def _paged_fixture(tmp_path, height, first_page, extra):
+    """A copy of fixture `height` whose validator set is served in two pages: the first `first_page` real validators, then the others plus
+    `extra` synthetic ones (absent votes, CommitSig::BlockIdFlagAbsent) -- the shape a /validators?page=2 answer has at > 100 validators."""
+    import hashlib
+    import json
+    import shutil
+    src = os.path.join(FX, str(height))
+    dst = os.path.join(str(tmp_path), str(height))
+    os.makedirs(dst)
+    shutil.copy(os.path.join(src, "commit.json"), os.path.join(dst, "commit.json"))
+    with open(os.path.join(src, "validators_1.json")) as f:
+        page = json.load(f)
+    vals = page["result"]["validators"]
+    import base64
+    synth = []
+    for i in range(extra):
+        seed = hashlib.sha256(b"tmx-page2" + bytes([i])).digest()
+        synth.append({"address": hashlib.sha256(seed).hexdigest()[:40].upper(), "pub_key": {"type": "tendermint/PubKeyEd25519", "value": base64.b64encode(seed).decode()},
+                      "voting_power": str(1000 + 7 * i), "proposer_priority": "0"})
+    allv = vals + synth
+    total = str(len(allv))
+    for k, part in enumerate((allv[:first_page], allv[first_page:]), start=1):
+        doc = {"jsonrpc": "2.0", "id": -1, "result": {"block_height": str(height), "validators": part, "count": str(len(part)), "total": total}}
+        with open(os.path.join(dst, f"validators_{k}.json"), "w") as f:
+            json.dump(doc, f)
+    if extra:
+        with open(os.path.join(dst, "commit.json")) as f:
+            c = json.load(f)
+        c["result"]["signed_header"]["commit"]["signatures"] += [
+            {"block_id_flag": 1, "validator_address": "", "timestamp": "0001-01-01T00:00:00Z", "signature": None} for _ in range(extra)]
+        with open(os.path.join(dst, "commit.json"), "w") as f:
+            json.dump(c, f)
+    return str(tmp_path)
+
+
+def test_codec_two_validator_pages(built_lib, tmp_path):
+    """reference circuits/input/mod.rs:219-241: the /validators RPC pages 100 per request, so a Celestia-size set (N = 128) arrives as
+    page 1 (100) + page 2 (28).  tmx_skip_inputs_from_json takes the pages back to back: the records must equal the Python codec's on the
+    same two files, and -- with no synthetic validators -- the one-page fixture's."""
+    from tendermintx_amd.circuits import InputDataFetcher
+    # (a) the real 100-validator set of 157001 split 60 + 40 == the committed one-page records
+    fx_a = _paged_fixture(tmp_path / "a", 157001, 60, 0)
+    one = InputDataFetcher(FX).get_skip_inputs(128, 157001, bytes(32), 157001)
+    two = InputDataFetcher(fx_a).get_skip_inputs(128, 157001, bytes(32), 157001)
+    assert one == two
+    # (b) 128 validators = 100 + 28 through both codecs
+    fx_b = _paged_fixture(tmp_path / "b", 157001, 100, 28)
+    pr, tg, tr = m.skip_inputs_from_fixtures(m.FixtureFetcher(fx_b), 157001, 157001, 128)
+    p2, t2, r2 = InputDataFetcher(fx_b).get_skip_inputs(128, 157001, m.unpack_proof(pr)["hash"], 157001)
+    assert p2 == pr and t2 == b"".join(tg) and r2 == b"".join(tr)
+    assert m.unpack_proof(pr)["nb_a"] == 128 and m.unpack_proof(pr)["nb_b"] == 128
+    lanes = [t2[256 * i:256 * (i + 1)] for i in range(128)]
+    assert all(l[223] & 2 for l in lanes) and not any(l[223] & 1 for l in lanes[100:])   # present, not signed
+    # 129 validators do not fit N = 128 (mod.rs:439-444)
+    fx_c = _paged_fixture(tmp_path / "c", 157001, 100, 29)
+    with pytest.raises(AssertionError, match="larger than the VALIDATOR_SET_SIZE_MAX"):
+        InputDataFetcher(fx_c).get_skip_inputs(128, 157001, bytes(32), 157001)
