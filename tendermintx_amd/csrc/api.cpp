@@ -244,6 +244,7 @@ struct Knobs {
   int walk_parts = -1;       // TMX_WALK_PARTS=0|1: the table walk follows the table build part by part (default: from 65536 lanes)
   bool ext_events = true;    // TMX_EXT_EVENTS=0: record packets instead of completion signals on the chain kernels
   int warm_schedule = -1;    // TMX_SCHEDULE=warm|cold: the EdDSA schedule for resident / new keys (default: by what the last launch saw)
+  int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
 static Knobs read_knobs() {
   Knobs k;
@@ -256,6 +257,7 @@ static Knobs read_knobs() {
   k.walk_parts = (v = std::getenv("TMX_WALK_PARTS")) ? (v[0] == '1' ? 1 : 0) : -1;
   k.ext_events = !((v = std::getenv("TMX_EXT_EVENTS")) && v[0] == '0');
   k.warm_schedule = (v = std::getenv("TMX_SCHEDULE")) ? (v[0] == 'w' ? 1 : 0) : -1;
+  k.tiny = (v = std::getenv("TMX_TINY")) ? (v[0] != '0' ? 1 : 0) : -1;
   return k;
 }
 
@@ -304,6 +306,9 @@ struct tmx_ctx {
   hipStream_t side3 = nullptr;  // early serialization of the input-only sections
   hipEvent_t ev_join3 = nullptr;
   uint32_t parity = 0;  // which of the two counter sets this launch uses
+  void* d_tiny = nullptr;      // counters of the small-launch path (kernels.h: tiny_counter_words), zero between launches
+  void* d_shadow = nullptr;    // key bytes + flags of the lanes of a small launch (TINY_MAX_LANES records): what its key pipeline reads
+  bool slot_tiny[EV_RING_DECL] = {};  // which event sets of the ring belong to small launches (their four events mark other points)
   uint64_t last_lanes = 0;
   // scratch sized for cfg.max_batch proofs
   void *d_ed = nullptr, *d_tl = nullptr, *d_lr = nullptr, *d_pf = nullptr, *d_nodes_t = nullptr, *d_nodes_r = nullptr, *d_reports = nullptr;
@@ -507,6 +512,119 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     if ((st0 = serialize(prog.mask_inputs | prog.mask_proof | prog.mask_leaves | mask_final | prog.mask_p1 | prog.mask_tail, s))) return st0;
   }
   HIPCK(c, hipEventRecord(ev[3], s));
+  c->slot_tiny[slot] = false;
+  c->last_stream = s; c->last_stream_valid = true;
+  c->ev_done = ev[3];
+  c->last_kind = kind; c->last_n_proofs = n_proofs;
+  c->n_calls++;
+  return TMX_OK;
+}
+
+// ---- the small-launch path (kernels.h TinyLaunch, tiny.hpp): <= TINY_MAX_LANES validator lanes.
+// Two launches on the caller's stream, no cross-stream hand-off in front of any of them: k_tiny (every role that needs only the input
+// records) and k_tiny_tail (checks, verdict, the sections that needed k_tiny).  A lane whose key is not resident is computed table-free
+// inside its workgroup.  The key cache is only READ by k_tiny; its bookkeeping is the classic key pipeline, unchanged, enqueued on the
+// high-priority side stream BEHIND k_tiny over the context's shadow copy of the lanes' keys (k_ed_dedup -> k_ed_keys -> tables of the new
+// keys -> k_kc_epilogue): hit / miss counters, LRU stamps, insertion, eviction and the schedule hint are exactly what a classic launch
+// leaves, and nothing reads the caller's buffers once the caller's stream is done.  TMX_TINY=0 never takes this path.
+static bool use_tiny(const tmx_ctx* c, uint64_t n_lanes) {
+  const Knobs& K = c->knobs;
+  if (K.tiny == 0 || n_lanes == 0 || n_lanes > TINY_MAX_LANES || !c->d_tiny || !c->d_shadow) return false;
+  if (c->kc.cap == 0 || K.dedup_mode == 0) return false;  // (TMX_DEDUP=0: no per-key tables at all -- the classic table-free kernels)
+  if (K.warm_schedule >= 0 && K.tiny < 0) return false;   // a forced schedule names one of the classic graphs
+  return true;
+}
+static void tiny_common(tmx_ctx* c, TinyLaunch& T, uint32_t n_lanes, const void* d_lanes, void* d_ed, uint32_t ed_stride) {
+  std::memset(&T, 0, sizeof T);
+  T.n_lanes = n_lanes; T.d_target = d_lanes; T.d_ed = d_ed; T.ed_stride = ed_stride;
+  T.d_qtable = c->d_qtable; T.d_keytab = c->d_keytab; T.d_keyrec = c->d_keyrec; T.kc = c->kc; T.d_tiny = c->d_tiny; T.d_shadow = c->d_shadow;
+  c->last_lanes = n_lanes;
+}
+// the ordering a small launch needs in front of it: the previous batch if it ran on another stream, and the tail of the key pipeline
+// the previous launch left on the side stream (it may still be inserting keys into the cache this launch probes)
+static int32_t tiny_order(tmx_ctx* c, hipStream_t s) {
+  if (c->last_stream_valid && c->last_stream != s) HIPCK(c, hipStreamWaitEvent(s, c->ev_done, 0));
+  HIPCK(c, hipStreamWaitEvent(s, c->ev_hash_clean, 0));
+  return TMX_OK;
+}
+// the cache bookkeeping of a small launch: the classic key pipeline on side2, behind k_tiny (event `after`), over the shadow records
+static int32_t tiny_key_pipeline(tmx_ctx* c, uint32_t n_lanes, hipEvent_t after) {
+  const Knobs& K = c->knobs;
+  EdQuad Q;
+  std::memset(&Q, 0, sizeof Q);
+  Q.n_lanes = n_lanes; Q.d_target = c->d_shadow; Q.d_qtable = c->d_qtable; Q.d_pre = c->d_pre; Q.d_mulout = c->d_mulout;
+  Q.d_hash = c->d_hash; Q.hash_mask = c->hash_mask; Q.d_owner_of = c->d_owner_of; Q.d_slot_of_owner = c->d_slot_of_owner;
+  Q.d_slot_of_uid = c->d_slot_of_uid; Q.d_owners = c->d_owners; Q.d_keyrec = c->d_keyrec; Q.d_anchors = c->d_anchors; Q.d_keytab = c->d_keytab;
+  Q.kc = c->kc; Q.mode = K.dedup_mode;
+  Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * c->parity;
+  Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1);
+  c->parity ^= 1;
+  Q.use_new = 0;  // nobody waits for the tables of this launch: they are for the next call
+  Q.warm = (c->kc.persist && c->h_hint && c->h_hint[0] != 0 && c->h_hint[1] == 0) ? 1u : 0u;  // (grid sizes of the new-key kernels only)
+  HIPCK(c, hipStreamWaitEvent(c->side2, after, 0));
+  int rc = launch_ed_dedup(Q, c->side2);
+  if (!rc) rc = launch_ed_keys(Q, c->side2);
+  if (!rc) rc = launch_ed_tab_anchor(Q, 0, 1, c->side2);
+  if (!rc) rc = launch_ed_tab_mult(Q, 0, 1, c->side2);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("key pipeline launch: ") + hipGetErrorString((hipError_t)rc));
+  if ((size_t)c->hash_mask + 1 > KC_EPILOGUE_CLEARS_UP_TO) HIPCK(c, hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, c->side2));
+  rc = launch_kc_epilogue(Q, c->side2);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_kc_epilogue launch: ") + hipGetErrorString((hipError_t)rc));
+  HIPCK(c, hipEventRecord(c->ev_hash_clean, c->side2));
+  return TMX_OK;
+}
+static int32_t run_tiny_lanes(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_ed, uint32_t ed_stride, hipStream_t s) {
+  int32_t st = tiny_order(c, s);
+  if (st) return st;
+  TinyLaunch T;
+  tiny_common(c, T, n_lanes, d_lanes, d_ed, ed_stride);
+  const bool x = c->knobs.ext_events;
+  int rc = launch_tiny(T, s, nullptr, x ? c->ev_fork2 : nullptr);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_tiny launch: ") + hipGetErrorString((hipError_t)rc));
+  if (!x) HIPCK(c, hipEventRecord(c->ev_fork2, s));
+  return tiny_key_pipeline(c, n_lanes, c->ev_fork2);
+}
+static int32_t run_tiny(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets, const void* d_trusteds,
+                        void* d_out_elems, void* d_reports, hipStream_t s) {
+  const uint32_t n = c->cfg.n_max;
+  const Knobs& K = c->knobs;
+  int32_t st = tiny_order(c, s);
+  if (st) return st;
+  uint8_t* tl = reinterpret_cast<uint8_t*>(c->d_tl);
+  const uint64_t slot = c->n_calls % tmx_ctx::EV_RING;
+  hipEvent_t* ev = c->ev[slot];
+  const Program& prog = c->prog[kind];
+  SerializeSources src;
+  std::memset(&src, 0, sizeof src);
+  src.base[SRC_TARGET] = (const uint8_t*)d_targets; src.base[SRC_TRUSTED] = (const uint8_t*)d_trusteds;
+  src.base[SRC_TL] = tl; src.base[SRC_LR] = (const uint8_t*)c->d_lr; src.base[SRC_PF] = (const uint8_t*)c->d_pf;
+  src.nodes_t = (const uint8_t*)c->d_nodes_t; src.nodes_r = (const uint8_t*)c->d_nodes_r;
+  TinyLaunch T;
+  tiny_common(c, T, n_proofs * n, d_targets, tl + TL_OFF_ED, TL_STRIDE);
+  T.n_proofs = n_proofs; T.P = proof_params(c, kind, false); T.d_proofs = d_proofs; T.d_trusted = d_trusteds;
+  T.d_lt = tl + TL_OFF_LT; T.lt_stride = TL_STRIDE; T.d_lr = c->d_lr; T.d_pf = c->d_pf; T.d_nodes_t = c->d_nodes_t; T.d_nodes_r = c->d_nodes_r;
+  T.d_reports = d_reports ? d_reports : c->d_reports;
+  T.S = &prog.sp; T.src = &src; T.d_lut = c->d_lut[kind]; T.d_wave_sec = c->d_wave_sec[kind]; T.d_seams = c->d_seams[kind];
+  T.n_seams = (uint32_t)prog.seam_waves.size(); T.d_out = d_out_elems;
+  // sections the caller asked for (the seam spans are few and always written); D.1b goes straight from the finish into the rows
+  const uint32_t want = ((c->sections & TMX_SEC_HINT) ? prog.mask_hint : 0u) | ((c->sections & TMX_SEC_DERIVED) ? prog.mask_derived : 0u) | (1u << 31);
+  if (d_out_elems && (c->sections & TMX_SEC_DERIVED)) {
+    T.row.rows = reinterpret_cast<uint64_t*>(d_out_elems); T.row.elem_stride = prog.sp.elem_stride; T.row.n = n; T.row.d1b_start = prog.d1b_start;
+  }
+  T.mask_inputs = prog.mask_inputs & want;
+  T.mask_after = (prog.mask_proof | prog.mask_leaves | prog.mask_p1 | (T.row.rows ? 0u : prog.mask_final)) & want;
+  T.mask_tail = prog.mask_tail & want;
+  const bool x = K.ext_events;
+  if (!x) HIPCK(c, hipEventRecord(ev[0], s));
+  int rc = launch_tiny(T, s, x ? ev[0] : nullptr, x ? ev[1] : nullptr);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_tiny launch: ") + hipGetErrorString((hipError_t)rc));
+  if (!x) { HIPCK(c, hipEventRecord(ev[1], s)); HIPCK(c, hipEventRecord(ev[2], s)); }
+  rc = launch_tiny_tail(T, s, x ? ev[2] : nullptr, x ? ev[3] : nullptr);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_tiny_tail launch: ") + hipGetErrorString((hipError_t)rc));
+  if (!x) HIPCK(c, hipEventRecord(ev[3], s));
+  // (enqueued after both launches of the caller's stream: the key pipeline is nobody's critical path)
+  if ((st = tiny_key_pipeline(c, n_proofs * n, ev[1]))) return st;
+  c->slot_tiny[slot] = true;
   c->last_stream = s; c->last_stream_valid = true;
   c->ev_done = ev[3];
   c->last_kind = kind; c->last_n_proofs = n_proofs;
@@ -809,7 +927,7 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   }
   void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_owner_of, c->d_slot_of_owner, c->d_slot_of_uid, c->d_owners, c->d_keyrec,
                   c->d_anchors, c->d_keytab, c->kc.d_hash, c->kc.d_pk, c->kc.d_used, c->kc.d_free, c->kc.d_state, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
-                  c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out, c->d_pack, c->d_trace_tmp};
+                  c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out, c->d_pack, c->d_trace_tmp, c->d_tiny, c->d_shadow};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (void* w : c->d_ntt_w)
@@ -902,6 +1020,10 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   HIPCK(c, hipMalloc(&c->d_nodes_t, B * (tn + 1) * 32));
   HIPCK(c, hipMalloc(&c->d_nodes_r, B * (tn + 1) * 32));
   HIPCK(c, hipMalloc(&c->d_reports, B * sizeof(tmx_report)));
+  HIPCK(c, hipMalloc(&c->d_tiny, tiny_counter_words(cfg->max_batch) * 4));
+  HIPCK(c, hipMemsetAsync(c->d_tiny, 0, tiny_counter_words(cfg->max_batch) * 4, c->side2));
+  HIPCK(c, hipMalloc(&c->d_shadow, (size_t)TINY_MAX_LANES * VR_STRIDE));
+  HIPCK(c, hipMemsetAsync(c->d_shadow, 0, (size_t)TINY_MAX_LANES * VR_STRIDE, c->side2));
   // fixed-base table of B (13-bit signed windows: kernels.hip BASE_W), affine form, then the quad layout the kernels read
   HIPCK(c, hipMalloc(&c->d_table, base_table_bytes()));
   int rc = launch_init_base(c->d_table, c->side2);
@@ -1038,6 +1160,7 @@ int32_t tmx_witness_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, co
   if (st) return st;
   if (n_proofs == 0) return TMX_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = the HIP default stream, exactly as passed
+  if (use_tiny(c, (uint64_t)n_proofs * c->cfg.n_max)) return run_tiny(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out_elems, d_reports, s);
   return run_batch(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out_elems, d_reports, s, true, [&](hipStream_t ss) -> int32_t {
     int rc = run_eddsa(c, n_proofs * c->cfg.n_max, d_targets, reinterpret_cast<uint8_t*>(c->d_tl) + TL_OFF_ED, TL_STRIDE, ss);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("EdDSA kernel launch: ") + hipGetErrorString((hipError_t)rc));
@@ -1050,6 +1173,7 @@ int32_t tmx_eddsa_lanes_device(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes
   if (n_lanes == 0) return TMX_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
   if ((uint64_t)n_lanes > (uint64_t)c->cfg.max_batch * c->cfg.n_max) return fail(c, TMX_ERR_CAPACITY, "n_lanes exceeds max_batch * n_max");
+  if (use_tiny(c, n_lanes)) return run_tiny_lanes(c, n_lanes, d_lanes, d_ed_out, ED_STRIDE, s);
   int rc = run_eddsa(c, n_lanes, d_lanes, d_ed_out, ED_STRIDE, s);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("EdDSA kernel launch: ") + hipGetErrorString((hipError_t)rc));
   return TMX_OK;
@@ -1132,6 +1256,14 @@ int32_t tmx_kernel_ms_mean(tmx_ctx* c, uint32_t last_k, float ms[TMX_N_KERNELS])
   for (uint32_t j = 0; j < last_k; j++) {
     hipEvent_t* ev = c->ev[(c->n_calls - 1 - j) % tmx_ctx::EV_RING];
     HIPCK(c, hipEventSynchronize(ev[3]));
+    if (c->slot_tiny[(c->n_calls - 1 - j) % tmx_ctx::EV_RING]) {
+      // a small launch: ev[0] .. ev[1] = k_tiny (the EdDSA lanes and the proof roles side by side), ev[2] .. ev[3] = k_tiny_tail
+      float t = 0;
+      HIPCK(c, hipEventElapsedTime(&t, ev[0], ev[1])); acc[TMX_K_EDDSA] += t; acc[TMX_K_PROOF] += t;
+      HIPCK(c, hipEventElapsedTime(&t, ev[2], ev[3])); acc[TMX_K_VERDICT] += t;
+      HIPCK(c, hipEventElapsedTime(&t, ev[1], ev[3])); acc[TMX_K_SERIALIZE] += t;
+      continue;
+    }
     hipEvent_t* evs = c->ev_side[(c->n_calls - 1 - j) % tmx_ctx::EV_RING];
     HIPCK(c, hipEventSynchronize(evs[1]));
     float t = 0;
@@ -1259,8 +1391,13 @@ int32_t tmx_eddsa_lanes(tmx_ctx* c, uint32_t n_lanes, const tmx_validator_rec* l
   int32_t st = ensure_staging(c);
   if (st) return st;
   HIPCK(c, hipMemcpyAsync(c->d_in_targets, lanes, (size_t)n_lanes * sizeof(tmx_validator_rec), hipMemcpyHostToDevice, c->stream));
-  int rc = run_eddsa(c, n_lanes, c->d_in_targets, c->d_ed, ED_STRIDE, c->stream);
-  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_eddsa launch: ") + hipGetErrorString((hipError_t)rc));
+  if (use_tiny(c, n_lanes)) {
+    st = run_tiny_lanes(c, n_lanes, c->d_in_targets, c->d_ed, ED_STRIDE, c->stream);
+    if (st) return st;
+  } else {
+    int rc = run_eddsa(c, n_lanes, c->d_in_targets, c->d_ed, ED_STRIDE, c->stream);
+    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_eddsa launch: ") + hipGetErrorString((hipError_t)rc));
+  }
   HIPCK(c, hipMemcpyAsync(out, c->d_ed, (size_t)n_lanes * ED_STRIDE, hipMemcpyDeviceToHost, c->stream));
   HIPCK(c, hipStreamSynchronize(c->stream));
   return TMX_OK;

@@ -94,4 +94,39 @@ int launch_serialize(const SerializeProgram& S, const SerializeSources& src, con
 int launch_pack_rows(const void* d_rows, void* d_out, uint32_t elem_stride, uint32_t first, uint32_t row_elems, uint32_t n_proofs, bool as_u32,
                      void* stream);
 
+
+// ---- the small-launch path (tiny.hpp): a whole batch of <= TINY_MAX_LANES validator lanes as TWO launches on the caller's stream
+constexpr uint32_t TINY_MAX_LANES = 1024;
+struct TinyLaunch {
+  // EdDSA lanes
+  uint32_t n_lanes;
+  const void* d_target;
+  void* d_ed;
+  uint32_t ed_stride;
+  const void *d_qtable, *d_keytab, *d_keyrec;
+  KeyCache kc;
+  RowOut row;
+  void* d_tiny;    // tiny_counter_words(max_batch) zeroed words owned by the context
+  void* d_shadow;  // TINY_MAX_LANES x 256 B: the lanes' key bytes + flags for the key pipeline that runs behind the launch
+  // proofs (n_proofs = 0: the lanes only -- tmx_eddsa_lanes_device)
+  uint32_t n_proofs;
+  ProofParams P;
+  const void *d_proofs, *d_trusted;
+  void* d_lt;
+  uint32_t lt_stride;
+  void *d_lr, *d_pf, *d_nodes_t, *d_nodes_r, *d_reports;
+  // witness rows (d_out = null: reports only)
+  const SerializeProgram* S;
+  const SerializeSources* src;
+  const void *d_lut, *d_wave_sec, *d_seams;
+  uint32_t n_seams;
+  void* d_out;
+  uint32_t mask_inputs;  // sections k_tiny's input role writes
+  uint32_t mask_after;   // sections k_tiny_tail's span roles write
+  uint32_t mask_tail;    // sections (and bit 31: the seam spans) the per-proof final role of k_tiny_tail writes
+};
+size_t tiny_counter_words(uint32_t max_proofs);
+int launch_tiny(const TinyLaunch& T, void* stream, void* started = nullptr, void* done = nullptr);
+int launch_tiny_tail(const TinyLaunch& T, void* stream, void* started = nullptr, void* done = nullptr);
+
 }  // namespace tmx

@@ -632,14 +632,14 @@ def test_key_dedup_paths(tmx, oracle):
     def cat(wls):
         return b"".join(w.proofs for w in wls), b"".join(w.targets for w in wls), b"".join(w.trusteds for w in wls)
 
-    same = Workload(0, n, 40, 16, chain_id=b"celestia", seed=1, signed_permille=1000)  # 640 lanes (launches of <= 512 lanes never wait for fresh tables)
+    same = Workload(0, n, 80, 16, chain_id=b"celestia", seed=1, signed_permille=1000)  # 1280 lanes (launches of <= 1024 lanes take the small path, which never waits for fresh tables)
     distinct = [Workload(0, n, 1, 16, chain_id=b"celestia", seed=100 + i, signed_permille=1000) for i in range(24)]
     mixed = [Workload(0, n, 12, 16, chain_id=b"celestia", seed=7, signed_permille=900)] + distinct[:6]
-    with tmx.Context(n, b"celestia", max_batch=40) as ctx:
+    with tmx.Context(n, b"celestia", max_batch=80) as ctx:
         _, reps = _check_vs_oracle(tmx, oracle, 0, n, same.proofs, same.targets, same.trusteds, b"celestia", ctx=ctx)
         assert all(r["all_ok"] for r in reps)
         uniq, tables = ctx.last_dedup()
-        assert uniq == 16 and tables                      # 640 lanes, 16 keys
+        assert uniq == 16 and tables                      # 1280 lanes, 16 keys
         p, t, r = cat(distinct)
         _, reps = _check_vs_oracle(tmx, oracle, 0, n, p, t, r, b"celestia", ctx=ctx)
         assert all(x["all_ok"] for x in reps)
