@@ -76,6 +76,7 @@ struct Program {
   uint32_t hint_elems;
   uint32_t d1b_start = 0;  // first element of D.1b in a row (the EdDSA finish writes that section directly: RowOut)
   uint32_t mask_hint = 0, mask_derived = 0;  // sections of H / of D (tmx_witness_batch_opts: a caller may ask for one of them only)
+  uint32_t tail_dep_elem = 0;  // first element of a row whose value is written by the final checks (verdicts, check words, all_ok): the small-launch tail
 };
 
 Program build_program(int kind, uint32_t n) {
@@ -193,6 +194,7 @@ Program build_program(int kind, uint32_t n) {
   emit_proof_d(L, 3);
   if (!skip) emit_proof_d(L, 4);
   for (int k = 0; k < 4; k++) L.u64(PF_OFF_TALLY_T + 8 * k);
+  P.tail_dep_elem = elem + ((uint32_t)L.v.size() - mark);
   L.u32(PF_OFF_VERDICTS);
   if (skip) {
     for (int k = 0; k < 4; k++) L.u64(PF_OFF_TALLY_R + 8 * k);
@@ -614,6 +616,7 @@ static int32_t run_tiny(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void*
   T.mask_inputs = prog.mask_inputs & want;
   T.mask_after = (prog.mask_proof | prog.mask_leaves | prog.mask_p1 | (T.row.rows ? 0u : prog.mask_final)) & want;
   T.mask_tail = prog.mask_tail & want;
+  T.tail_dep_elem = prog.tail_dep_elem;
   const bool x = K.ext_events;
   if (!x) HIPCK(c, hipEventRecord(ev[0], s));
   int rc = launch_tiny(T, s, x ? ev[0] : nullptr, x ? ev[1] : nullptr);

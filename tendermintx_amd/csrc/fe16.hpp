@@ -145,25 +145,54 @@ __device__ __forceinline__ uint32_t const_sqrtm1(uint32_t k) {
   constexpr uint16_t t[16] = {0xa0b0, 0x4a0e, 0x1b27, 0xc4ee, 0xe478, 0xad2f, 0x1806, 0x2f43, 0xd7a7, 0x3dfb, 0x0099, 0x2b4d, 0xdf0b, 0x4fc1, 0x2480, 0x2b83};
   return t[k];
 }
+// ---- ONE element held in all four rows (e.g. the product of the Z's a finish inverts): the four rows share the sixteen partial products
+// of a limb -- row r takes a[k - s] b[s] for s = 4r .. 4r + 3 -- and the row sums are added across the rows; the result is again in all
+// four rows.  ~38 instructions instead of 61: a 254-squaring inversion chain is a third shorter.  Inputs carried (<= F16_C).
+__device__ __forceinline__ uint32_t mul1(uint32_t a, uint32_t b, const Ctx& c) {
+  // a_r[k] = a[k - 4r] (times 38 where that index wraps), b_r[k] = b[k + 4r]: DPP row rotations applied to one row each (row_mask)
+  int ar = (int)a, br = (int)b;
+  ar = __builtin_amdgcn_update_dpp(ar, (int)a, 0x120 + 4, 0x2, 0xf, false);
+  ar = __builtin_amdgcn_update_dpp(ar, (int)a, 0x120 + 8, 0x4, 0xf, false);
+  ar = __builtin_amdgcn_update_dpp(ar, (int)a, 0x120 + 12, 0x8, 0xf, false);
+  br = __builtin_amdgcn_update_dpp(br, (int)b, 0x120 + 12, 0x2, 0xf, false);
+  br = __builtin_amdgcn_update_dpp(br, (int)b, 0x120 + 8, 0x4, 0xf, false);
+  br = __builtin_amdgcn_update_dpp(br, (int)b, 0x120 + 4, 0x8, 0xf, false);
+  const uint32_t a4 = __umul24((uint32_t)ar, c.k < 4 * c.row ? 38u : 1u), b4 = (uint32_t)br;
+  // (a wrapped index is wrapped by exactly one of the two rotations, so the factors 38 never meet: a4 fac[j] < 2^24 as in mul())
+  uint64_t acc = (uint64_t)a4 * bcast<0>(b4);
+  mul_step<1>(acc, a4, b4, c); mul_step<2>(acc, a4, b4, c); mul_step<3>(acc, a4, b4, c);
+  const uint32_t r = carry_wide(acc, c);  // this row's share, carried
+  const auto p = __builtin_amdgcn_permlane16_swap(r, r, false, false);  // (r0 r0 r2 r2), (r1 r1 r3 r3)
+  const uint32_t s2 = p[0] + p[1];
+  const auto e = __builtin_amdgcn_permlane32_swap(s2, s2, false, false);  // (r0 + r1) x 4, (r2 + r3) x 4
+  return carry(e[0] + e[1], c);
+}
+template <bool ONE>
+__device__ __forceinline__ uint32_t mulx(uint32_t a, uint32_t b, const Ctx& c) {
+  if constexpr (ONE) return mul1(a, b, c);
+  else return mul(a, b, c);
+}
+template <bool ONE = false>
 __device__ __forceinline__ uint32_t sqn(uint32_t a, int n, const Ctx& c) {
 #pragma unroll 1
-  for (int i = 0; i < n; i++) a = mul(a, a, c);
+  for (int i = 0; i < n; i++) a = mulx<ONE>(a, a, c);
   return a;
 }
 // z^((p-5)/8) = z^(2^252 - 3): ref10's fe_pow22523 addition chain (252 squarings, 11 multiplications)
+template <bool ONE = false>
 __device__ __forceinline__ uint32_t pow_p58(uint32_t z, const Ctx& c) {
-  uint32_t t0 = mul(z, z, c);                  // 2
-  uint32_t t1 = mul(z, sqn(t0, 2, c), c);      // 9
-  t0 = mul(t0, t1, c);                         // 11
-  t0 = mul(t1, mul(t0, t0, c), c);             // 31 = 2^5 - 1
-  t0 = mul(sqn(t0, 5, c), t0, c);              // 2^10 - 1
-  t1 = mul(sqn(t0, 10, c), t0, c);             // 2^20 - 1
-  t1 = mul(sqn(t1, 20, c), t1, c);             // 2^40 - 1
-  t0 = mul(sqn(t1, 10, c), t0, c);             // 2^50 - 1
-  t1 = mul(sqn(t0, 50, c), t0, c);             // 2^100 - 1
-  t1 = mul(sqn(t1, 100, c), t1, c);            // 2^200 - 1
-  t0 = mul(sqn(t1, 50, c), t0, c);             // 2^250 - 1
-  return mul(sqn(t0, 2, c), z, c);             // 2^252 - 3
+  uint32_t t0 = mulx<ONE>(z, z, c);                  // 2
+  uint32_t t1 = mulx<ONE>(z, sqn<ONE>(t0, 2, c), c);      // 9
+  t0 = mulx<ONE>(t0, t1, c);                         // 11
+  t0 = mulx<ONE>(t1, mulx<ONE>(t0, t0, c), c);             // 31 = 2^5 - 1
+  t0 = mulx<ONE>(sqn<ONE>(t0, 5, c), t0, c);              // 2^10 - 1
+  t1 = mulx<ONE>(sqn<ONE>(t0, 10, c), t0, c);             // 2^20 - 1
+  t1 = mulx<ONE>(sqn<ONE>(t1, 20, c), t1, c);             // 2^40 - 1
+  t0 = mulx<ONE>(sqn<ONE>(t1, 10, c), t0, c);             // 2^50 - 1
+  t1 = mulx<ONE>(sqn<ONE>(t0, 50, c), t0, c);             // 2^100 - 1
+  t1 = mulx<ONE>(sqn<ONE>(t1, 100, c), t1, c);            // 2^200 - 1
+  t0 = mulx<ONE>(sqn<ONE>(t1, 50, c), t0, c);             // 2^250 - 1
+  return mulx<ONE>(sqn<ONE>(t0, 2, c), z, c);             // 2^252 - 3
 }
 
 __device__ __forceinline__ uint32_t const_2d(uint32_t k) {
@@ -200,19 +229,20 @@ __device__ __forceinline__ uint32_t with_xy(uint32_t Q, const Ctx& c) {
 }
 
 // z^(p-2) = z^(2^255 - 21): ref10's fe_invert chain (254 squarings, 11 multiplications)
+template <bool ONE = false>
 __device__ __forceinline__ uint32_t invert(uint32_t z, const Ctx& c) {
-  uint32_t t0 = mul(z, z, c);                  // 2
-  uint32_t t1 = mul(z, sqn(t0, 2, c), c);      // 9
-  t0 = mul(t0, t1, c);                         // 11
-  t1 = mul(t1, mul(t0, t0, c), c);             // 31 = 2^5 - 1
-  t1 = mul(sqn(t1, 5, c), t1, c);              // 2^10 - 1
-  uint32_t t2 = mul(sqn(t1, 10, c), t1, c);    // 2^20 - 1
-  t2 = mul(sqn(t2, 20, c), t2, c);             // 2^40 - 1
-  t1 = mul(sqn(t2, 10, c), t1, c);             // 2^50 - 1
-  t2 = mul(sqn(t1, 50, c), t1, c);             // 2^100 - 1
-  t2 = mul(sqn(t2, 100, c), t2, c);            // 2^200 - 1
-  t1 = mul(sqn(t2, 50, c), t1, c);             // 2^250 - 1
-  return mul(sqn(t1, 5, c), t0, c);            // 2^255 - 32 + 11
+  uint32_t t0 = mulx<ONE>(z, z, c);                  // 2
+  uint32_t t1 = mulx<ONE>(z, sqn<ONE>(t0, 2, c), c);      // 9
+  t0 = mulx<ONE>(t0, t1, c);                         // 11
+  t1 = mulx<ONE>(t1, mulx<ONE>(t0, t0, c), c);             // 31 = 2^5 - 1
+  t1 = mulx<ONE>(sqn<ONE>(t1, 5, c), t1, c);              // 2^10 - 1
+  uint32_t t2 = mulx<ONE>(sqn<ONE>(t1, 10, c), t1, c);    // 2^20 - 1
+  t2 = mulx<ONE>(sqn<ONE>(t2, 20, c), t2, c);             // 2^40 - 1
+  t1 = mulx<ONE>(sqn<ONE>(t2, 10, c), t1, c);             // 2^50 - 1
+  t2 = mulx<ONE>(sqn<ONE>(t1, 50, c), t1, c);             // 2^100 - 1
+  t2 = mulx<ONE>(sqn<ONE>(t2, 100, c), t2, c);            // 2^200 - 1
+  t1 = mulx<ONE>(sqn<ONE>(t2, 50, c), t1, c);             // 2^250 - 1
+  return mulx<ONE>(sqn<ONE>(t1, 5, c), t0, c);            // 2^255 - 32 + 11
 }
 
 }  // namespace f16

@@ -123,7 +123,8 @@ struct TinyLaunch {
   void* d_out;
   uint32_t mask_inputs;  // sections k_tiny's input role writes
   uint32_t mask_after;   // sections k_tiny_tail's span roles write
-  uint32_t mask_tail;    // sections (and bit 31: the seam spans) the per-proof final role of k_tiny_tail writes
+  uint32_t mask_tail;    // sections that carry the verdict (k_tiny_tail: span roles up to tail_dep_elem, the per-proof final role from there)
+  uint32_t tail_dep_elem;  // first element of a row that depends on the final checks
 };
 size_t tiny_counter_words(uint32_t max_proofs);
 int launch_tiny(const TinyLaunch& T, void* stream, void* started = nullptr, void* done = nullptr);

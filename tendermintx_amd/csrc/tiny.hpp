@@ -26,6 +26,14 @@
 #pragma once
 
 constexpr uint32_t TINY_THREADS = 128;
+// Profiling build only (-DTMX_TINY_PROF, tools/build_variant.sh): TMX_TINY_DBG is a bit mask that switches roles / stages off so that the
+// others can be timed by the kernel's events -- the outputs of such a run are wrong by construction.
+#ifdef TMX_TINY_PROF
+#define TINY_DBG(bit) (g_tiny_dbg & (bit))
+__device__ uint32_t g_tiny_dbg;
+#else
+#define TINY_DBG(bit) false
+#endif
 // context-owned counters (zero between launches: the final role of k_tiny_tail resets what it reads)
 enum : uint32_t { TN_WORDS = 8, TN_PER_PROOF = 16 };
 // per-proof words behind TN_WORDS: [0] sign-bytes failures [1] varint sign-bit failures [2] u64 overflow in a tally
@@ -50,6 +58,7 @@ struct TinyProof {
   uint8_t* lt;
   uint32_t lt_stride;
   uint8_t *lr, *pf, *nodes_t, *nodes_r, *reports;
+  RowOut row;  // the lane's ten k_proof-derived D.1b elements go straight into the rows from the roles that compute them (rows = null: none)
 };
 struct TinySer {
   SerializeProgram S;  // resolved for this batch
@@ -61,7 +70,9 @@ struct TinySer {
   uint32_t mask;         // sections this launch writes through its span roles
   uint32_t first_block;  // span block (4 spans) range [first_block, first_block + n_blocks) per proof
   uint32_t n_blocks;
-  uint32_t tail_mask;    // k_tiny_tail: the sections the per-proof final role expands element by element
+  uint32_t tail_mask;    // k_tiny_tail: the sections that carry the verdict (their spans below tail_first_span go through the span roles)
+  uint32_t tail_first_span;  // the first span of a row with an element that depends on the final checks: from here to the row end the
+                             // per-proof final role expands element by element, behind its checks
 };
 
 // the sixteen quads of a wave hold partial sums of one point: after four rounds quad 0 holds the total
@@ -149,7 +160,82 @@ struct TinyLaneLds {
   uint32_t key[64];    // key record of a lane whose key is not resident (KEY_STRIDE / 4 words)
   uint32_t slot;
   uint32_t sh[6][64];
+  uint64_t w[2][80];   // W_t + K_t of the two SHA-512 blocks
 };
+
+// SHA-512(R | A | M) mod l of one lane by lanes 0 and 1 of a wave (blk = the calling lane): each assembles the sixteen message words of
+// ITS block from aligned dword loads (the pad byte and the length by masks, no byte loop) and runs that block's message schedule -- the two
+// schedules in lockstep, i.e. for the instructions of one -- leaving W_t + K_t in LDS; lane 0 then runs the 2 x 80 compression rounds
+// alone.  Same digest / h as ed_role_hram (8.8 k instead of 11.7 k instructions on the lane's critical path).
+__device__ __forceinline__ void tiny_hram(const uint8_t* __restrict__ rec, uint8_t* __restrict__ o, TinyLaneLds& L, uint32_t blk) {
+  const bool is_signed = rec[VR_OFF_FLAGS] & 1;
+  uint32_t mlen = is_signed ? (uint32_t)rec[VR_OFF_MLEN] | ((uint32_t)rec[VR_OFF_MLEN + 1] << 8) : 32u;
+  if (mlen > 124u) mlen = 124u;
+  const uint32_t total = 64 + mlen;
+  const bool two_blocks = total + 17 > 128;
+  uint64_t w[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    uint32_t half[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {
+      const int c = 2 * k + hh;                 // dword c of this lane's block = dword 32 blk + c of the message
+      const uint32_t j = 32u * blk + (uint32_t)c;
+      uint32_t data;
+      if (c < 16) {                             // block 0: R | A from the signature / key (or the dummy pair); block 1: message dwords 16 ..
+        const uint32_t mw = 16u + (uint32_t)c;  // (block 1 only: bytes 64 .. of M)
+        const uint8_t* src = blk ? rec + VR_OFF_MSG + 4 * (mw < 31u ? mw : 0u) : (c < 8 ? rec + VR_OFF_SIG + 4 * c : rec + VR_OFF_PK + 4 * (c - 8));
+        data = ld32(src);
+        if (!is_signed) data = blk ? 0u : (c < 8 ? K_DUMMY_SIG[c] : K_DUMMY_PK[c < 8 ? 0 : c - 8]);
+        if (blk && mw >= 31u) data = 0u;
+      } else {                                  // message dword c - 16 (block 0) or c + 16 (block 1: beyond the 124 bytes)
+        const uint32_t mw = (uint32_t)c - 16u;
+        data = blk ? 0u : ld32(rec + VR_OFF_MSG + 4 * (mw < 31u ? mw : 0u));
+        if (!is_signed || (!blk && mw >= 31u)) data = 0u;
+      }
+      const int32_t rem = (int32_t)total - (int32_t)(4u * j);  // message bytes left from this dword on
+      const uint32_t keep = rem >= 4 ? 0xffffffffu : (rem <= 0 ? 0u : (1u << (8 * rem)) - 1u);
+      const uint32_t mark = (rem >= 0 && rem < 4) ? 0x80u << (8 * rem) : 0u;
+      half[hh] = __builtin_bswap32((data & keep) | mark);
+    }
+    w[k] = ((uint64_t)half[0] << 32) | half[1];
+  }
+  if (blk == (two_blocks ? 1u : 0u)) w[15] = (uint64_t)total * 8;
+#pragma unroll
+  for (int i = 0; i < 80; i++) {
+    if (i >= 16) {
+      const uint64_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+      const uint64_t s0 = rotr64(w15, 1) ^ rotr64(w15, 8) ^ (w15 >> 7);
+      const uint64_t s1 = rotr64(w2, 19) ^ rotr64(w2, 61) ^ (w2 >> 6);
+      w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
+    }
+    L.w[blk][i] = w[i & 15] + K_SHA512[i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (blk != 0) return;
+  uint64_t dg[8];
+  sha512_init(dg);
+#pragma unroll 1
+  for (uint32_t b = 0; b < (two_blocks ? 2u : 1u); b++) {
+    uint64_t a = dg[0], bb = dg[1], c = dg[2], d = dg[3], e = dg[4], f = dg[5], g = dg[6], h = dg[7];
+#pragma unroll
+    for (int i = 0; i < 80; i++) {
+      const uint64_t t1 = h + (rotr64(e, 14) ^ rotr64(e, 18) ^ rotr64(e, 41)) + ((e & f) ^ (~e & g)) + L.w[b][i];
+      const uint64_t t2 = (rotr64(a, 28) ^ rotr64(a, 34) ^ rotr64(a, 39)) + ((a & bb) ^ (a & c) ^ (bb & c));
+      h = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+    }
+    dg[0] += a; dg[1] += bb; dg[2] += c; dg[3] += d; dg[4] += e; dg[5] += f; dg[6] += g; dg[7] += h;
+  }
+  uint32_t dw[16], hs[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { dw[2 * i] = bswap32((uint32_t)(dg[i] >> 32)); dw[2 * i + 1] = bswap32((uint32_t)dg[i]); }
+  sc_reduce512(dw, hs);
+#pragma unroll
+  for (int w2 = 0; w2 < 16; w2++) st32(o + ED_OFF_DIGEST + 4 * w2, dw[w2]);
+#pragma unroll
+  for (int w2 = 0; w2 < 8; w2++) { st32(o + ED_OFF_H + 4 * w2, hs[w2]); L.h[w2] = hs[w2]; }
+}
 
 // One validator lane, one workgroup of two waves:
 //   wave 1   probe the key cache | key not resident: decode it (k_ed_keys' limb-parallel form) | s*B with sixteen quads
@@ -199,15 +285,16 @@ __device__ __forceinline__ void tiny_lane(const TinyEd& A, uint32_t lane, TinyLa
       const uint32_t v = f16::mul(yy, f16::const_d(c.k), c) + one;
       const uint32_t v3 = f16::mul(f16::mul(v, v, c), v, c);
       const uint32_t uv7 = f16::mul(f16::mul(f16::mul(v3, v3, c), v, c), uu, c);
-      const uint32_t x = f16::mul(f16::mul(f16::pow_p58(uv7, c), v3, c), uu, c);
+      const uint32_t x = f16::mul(f16::mul(f16::pow_p58<true>(uv7, c), v3, c), uu, c);  // (one key in all four rows: they share the chain)
       const uint32_t xi = f16::mul(x, f16::const_sqrtm1(c.k), c);
       L.sh[0][t1] = x; L.sh[1][t1] = xi; L.sh[2][t1] = f16::mul(f16::mul(x, x, c), v, c); L.sh[3][t1] = uu;
       L.sh[4][t1] = f16::mul(x, y, c); L.sh[5][t1] = f16::mul(xi, y, c);
     }
-  } else if (tid == 0) {
-    ed_role_hram(lane, rec, nullptr, o, L.h);
+  } else if (tid < 2) {
+    tiny_hram(rec, o, L, tid);
   }
   __syncthreads();  // B1: h, the slot, (miss) the decode's products
+  if (TINY_DBG(0x100)) return;
   const uint32_t slot = L.slot;
   const bool hit = slot != DEDUP_EMPTY;
   const uint32_t* kr = hit ? A.keyrec + (size_t)slot * (KEY_STRIDE / 4) : L.key;
@@ -280,6 +367,7 @@ __device__ __forceinline__ void tiny_lane(const TinyEd& A, uint32_t lane, TinyLa
     hA16 = acc;
   }
   __syncthreads();  // B3: s*B (and the walk's h*A) in LDS
+  if (TINY_DBG(0x200)) return;
   // ---- finish in the limb-parallel form: D = s*B - h*A, ONE inversion for the three Z's, the six affine coordinates; thread 0 then runs
   // the scalar second half (comparison with the signature's R bytes, the lane's record and its D.1b elements)
   if (tid < 64) {
@@ -288,7 +376,7 @@ __device__ __forceinline__ void tiny_lane(const TinyEd& A, uint32_t lane, TinyLa
     const uint32_t D = f16::add_cached(sB, f16::neg_cached(f16::to_cached(hA16, c), c), c);
     const uint32_t zS = f16::rows(sB).r2, zH = f16::rows(hA16).r2, zD = f16::rows(D).r2;
     const uint32_t p12 = f16::mul(zS, zH, c);
-    const uint32_t inv = f16::invert(f16::mul(p12, zD, c), c);
+    const uint32_t inv = f16::invert<true>(f16::mul1(p12, zD, c), c);  // (one element in all four rows: the rows share its products)
     const uint32_t inv12 = f16::mul(inv, zD, c);
     L.sh[0][tid] = f16::mul(sB, f16::mul(inv12, zH, c), c);
     L.sh[1][tid] = f16::mul(hA16, f16::mul(inv12, zS, c), c);
@@ -296,6 +384,7 @@ __device__ __forceinline__ void tiny_lane(const TinyEd& A, uint32_t lane, TinyLa
     L.sh[3][tid] = hA16;
   }
   __syncthreads();
+  if (TINY_DBG(0x400)) return;
   if (tid == 0) {
     ge_ext hA;
     hA.X = f16_row_to_fe(&L.sh[3][0]); hA.Y = f16_row_to_fe(&L.sh[3][16]); hA.Z = f16_row_to_fe(&L.sh[3][32]); hA.T = f16_row_to_fe(&L.sh[3][48]);
@@ -520,6 +609,10 @@ __device__ __forceinline__ void tiny_header(const TinyProof& A, uint32_t p, uint
     uint8_t* o = ltp + (size_t)i * A.lt_stride + LN_OFF_FLAGS;
     st32(o, (enabled ? 1u : 0u) | (hash_in_msg ? 1u << 8 : 0u) | (is_precommit ? 1u << 16 : 0u) | (height_ok ? 1u << 24 : 0u));
     st32(o + 4, (round_ok ? 1u : 0u) | (sigdata_ok ? 1u << 8 : 0u));
+    if (uint64_t* row = row_d1b(A.row, p * n + i)) {  // D.1b elements 89 .. 94: the six flags (k_verdict writes them on the classic path)
+      row[D1B_ED_ELEMS + 0] = enabled; row[D1B_ED_ELEMS + 1] = hash_in_msg; row[D1B_ED_ELEMS + 2] = is_precommit; row[D1B_ED_ELEMS + 3] = height_ok;
+      row[D1B_ED_ELEMS + 4] = round_ok; row[D1B_ED_ELEMS + 5] = sigdata_ok;
+    }
     if (!sigdata_ok) fails++;
   }
   if (fails) atomicAdd(&tp[0], fails);
@@ -571,9 +664,15 @@ __device__ __forceinline__ void tiny_tally(const TinyProof& A, uint32_t p, uint3
   }
   __syncthreads();
   const u96 t_total = block_prefix_sums(n, [&](uint32_t i) { return i < nb ? ld64(tg + (size_t)i * VR_STRIDE + VR_OFF_POWER) : 0ull; },
-                                        [&](uint32_t i, uint64_t v) { st64(ltp + (size_t)i * A.lt_stride + LN_OFF_TOT, v); }, L.wave_tot);
+                                        [&](uint32_t i, uint64_t v) {
+                                          st64(ltp + (size_t)i * A.lt_stride + LN_OFF_TOT, v);
+                                          if (uint64_t* row = row_d1b(A.row, p * n + i)) { row[D1B_ED_ELEMS + 6] = (uint32_t)v; row[D1B_ED_ELEMS + 7] = v >> 32; }
+                                        }, L.wave_tot);
   const u96 t_acc = block_prefix_sums(n, [&](uint32_t i) { return L.sgn[i] ? ld64(tg + (size_t)i * VR_STRIDE + VR_OFF_POWER) : 0ull; },
-                                      [&](uint32_t i, uint64_t v) { st64(ltp + (size_t)i * A.lt_stride + LN_OFF_ACC, v); }, L.wave_tot);
+                                      [&](uint32_t i, uint64_t v) {
+                                        st64(ltp + (size_t)i * A.lt_stride + LN_OFF_ACC, v);
+                                        if (uint64_t* row = row_d1b(A.row, p * n + i)) { row[D1B_ED_ELEMS + 8] = (uint32_t)v; row[D1B_ED_ELEMS + 9] = v >> 32; }
+                                      }, L.wave_tot);
   u96 r_total = {0, 0}, r_acc = {0, 0};
   if (skip) {
     r_total = block_prefix_sums(n, [&](uint32_t j) { return j < nbt ? ld64(tr + (size_t)j * HR_STRIDE + HR_OFF_POWER) : 0ull; },
@@ -595,28 +694,45 @@ __device__ __forceinline__ void tiny_tally(const TinyProof& A, uint32_t p, uint3
 }
 
 // thresholds, checks, verdict of one proof from what the roles left in the proof record, the tree nodes and the counters (proof_body
-// phase 5).  One thread.  Owns [PF_OFF_VERDICTS, PF_OFF_HEIGHT) of the record and the report.
-__device__ __forceinline__ void tiny_final_checks(const TinyProof& A, uint32_t p, uint32_t* tp) {
+// phase 5).  The whole workgroup: the 32-byte comparisons are one byte per thread (a wave does two of them, a ballot each), the chain-id
+// bytes one per thread of the next wave; thread 0 assembles.  Owns [PF_OFF_VERDICTS, PF_OFF_HEIGHT) of the record and the report.
+__device__ __forceinline__ void tiny_final_checks(const TinyProof& A, uint32_t p, uint32_t* tp, uint32_t* s_eq /*[10]*/) {
   const ProofParams& P = A.P;
   const bool skip = P.kind == 0;
-  const uint32_t n = P.n;
+  const uint32_t n = P.n, t = threadIdx.x;
   const uint8_t* pr = A.in_proof + (size_t)p * PR_STRIDE;
   uint8_t* pf = A.pf + (size_t)p * PF_STRIDE;
-  const uint64_t block_a = ld64(pr + PR_OFF_BLOCK_A), block_b = ld64(pr + PR_OFF_BLOCK_B), round_ = ld64(pr + PR_OFF_ROUND);
-  const uint32_t nb = ld32(pr + PR_OFF_NB_A), nbt = ld32(pr + PR_OFF_NB_B);
-  auto eq32 = [&](const uint8_t* a, const uint8_t* b) {
-    uint32_t d = 0;
-    for (int k = 0; k < 32; k++) d |= (uint32_t)(a[k] ^ b[k]);
-    return d == 0;
-  };
   // the computed validators hash of a set: the last node of its tree (a one-lane tree: the leaf hash itself)
   const uint8_t* root_t = P.tree_nodes ? A.nodes_t + ((size_t)p * P.tree_nodes + P.tree_nodes - 1) * 32 : A.lt + (size_t)p * n * A.lt_stride + LN_OFF_LEAF;
   const uint8_t* root_r = P.tree_nodes ? A.nodes_r + ((size_t)p * P.tree_nodes + P.tree_nodes - 1) * 32 : A.lr + (size_t)p * n * LANE_STRIDE + LN_OFF_LEAF;
   const uint8_t* hdr_hash = pf + PF_OFF_HEADER;
-  auto incl_root = [&](int q) { return pf + PF_OFF_PROOFD + 160 * q + 128; };
-  const uint64_t t_total = ld64(pf + PF_OFF_TALLY_T), t_sa = ld64(pf + PF_OFF_TALLY_T + 16), t_st = ld64(pf + PF_OFF_TALLY_T + 24);
+  auto incl_root = [&](int q) { return (const uint8_t*)(pf + PF_OFF_PROOFD + 160 * q + 128); };
+  if (t < 256) {  // comparison c = t / 32, byte t % 32
+    const uint32_t c = t >> 5, k = t & 31u;
+    const uint8_t *x, *y;
+    if (skip) {
+      x = c == 0 ? incl_root(3) : c == 1 ? root_r : c == 2 ? root_t : c == 3 ? incl_root(2) : c == 4 ? incl_root(0) : incl_root(1);
+      y = c == 0 ? pr + PR_OFF_HASH : c == 1 ? pf + PF_OFF_LEAFX + 2 : c == 2 ? pf + PF_OFF_LEAFV + 2 : hdr_hash;
+    } else {
+      x = c == 0 ? root_t : c == 1 ? incl_root(2) : c == 2 ? incl_root(0) : c == 3 ? incl_root(1) : c == 4 ? incl_root(3)
+          : c == 5 ? pf + PF_OFF_LEAFX + 2 : c == 6 ? incl_root(4) : pf + PF_OFF_LEAFV + 2;
+      y = c == 0 ? pf + PF_OFF_LEAFV + 2 : c <= 4 ? hdr_hash : c == 5 ? pr + PR_OFF_HASH : c == 6 ? pr + PR_OFF_HASH : pf + PF_OFF_LEAFY + 2;
+    }
+    const bool live = c < (skip ? 6u : 8u);
+    const uint64_t ne = __ballot(live && x[k] != y[k]);
+    if ((t & 63u) == 0) { s_eq[2 * (t >> 6)] = (uint32_t)ne == 0; s_eq[2 * (t >> 6) + 1] = (uint32_t)(ne >> 32) == 0; }
+  } else if (t < 320) {
+    const uint32_t k = t - 256;
+    const bool bad = k < P.chain_id_len && k < 50 && pf[PF_OFF_CID52 + 2 + k] != P.chain_id[k];
+    const uint64_t ne = __ballot(bad);
+    if (k == 0) s_eq[8] = (ne == 0 && P.chain_id_len <= 50) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (t != 0) return;
+  const uint64_t block_a = ld64(pr + PR_OFF_BLOCK_A), block_b = ld64(pr + PR_OFF_BLOCK_B), round_ = ld64(pr + PR_OFF_ROUND);
+  const uint32_t nb = ld32(pr + PR_OFF_NB_A), nbt = ld32(pr + PR_OFF_NB_B);
+  const uint64_t t_sa = ld64(pf + PF_OFF_TALLY_T + 16), t_st = ld64(pf + PF_OFF_TALLY_T + 24);
   const uint64_t r_sa = ld64(pf + PF_OFF_TALLY_R + 16), r_st = ld64(pf + PF_OFF_TALLY_R + 24);
-  (void)t_total;
   const bool gt_t = t_sa > t_st;
   bool gt_r = false, dist_gt = false, dist_le = false;
   if (skip) {
@@ -626,35 +742,34 @@ __device__ __forceinline__ void tiny_final_checks(const TinyProof& A, uint32_t p
   }
   for (uint32_t i = PF_OFF_VERDICTS; i < PF_OFF_HEIGHT; i += 4) st32(pf + i, 0u);
   st32(pf + PF_OFF_VERDICTS, gt_t); st32(pf + PF_OFF_VERDICTS + 4, gt_r); st32(pf + PF_OFF_VERDICTS + 8, dist_gt); st32(pf + PF_OFF_VERDICTS + 12, dist_le);
-  bool chain_ok = P.chain_id_len <= 50;
-  for (uint32_t k = 0; k < P.chain_id_len && k < 50; k++) chain_ok = chain_ok && (pf[PF_OFF_CID52 + 2 + k] == P.chain_id[k]);
+  const bool chain_ok = s_eq[8] != 0;
   const uint64_t height_a = ld64(pf + PF_OFF_HEIGHT);
   const bool all_sigdata = tp[0] == 0, all_eddsa = true /* patched by the verdict merge */, varint_ok = tp[1] == 0, no_overflow = tp[2] == 0;
   bool checks[16];
   int nc = 0;
   if (skip) {
-    checks[nc++] = eq32(incl_root(3), pr + PR_OFF_HASH);          // verify.rs:374-379
-    checks[nc++] = eq32(root_r, pf + PF_OFF_LEAFX + 2);           // verify.rs:382-389
-    checks[nc++] = eq32(root_t, pf + PF_OFF_LEAFV + 2);           // verify.rs:279-280
-    checks[nc++] = eq32(incl_root(2), hdr_hash);                  // verify.rs:283-286
-    checks[nc++] = eq32(incl_root(0), hdr_hash);                  // verify.rs:205-209
+    checks[nc++] = s_eq[0];                                       // verify.rs:374-379
+    checks[nc++] = s_eq[1];                                       // verify.rs:382-389
+    checks[nc++] = s_eq[2];                                       // verify.rs:279-280
+    checks[nc++] = s_eq[3];                                       // verify.rs:283-286
+    checks[nc++] = s_eq[4];                                       // verify.rs:205-209
     checks[nc++] = chain_ok;                                      // verify.rs:211-221
-    checks[nc++] = eq32(incl_root(1), hdr_hash);                  // shared.rs:197-203
+    checks[nc++] = s_eq[5];                                       // shared.rs:197-203
     checks[nc++] = height_a == block_b;                           // shared.rs:206
     checks[nc++] = all_sigdata; checks[nc++] = all_eddsa; checks[nc++] = no_overflow; checks[nc++] = varint_ok;
     checks[nc++] = (round_ >> 63) == 0;                           // validator.rs:73-78 (asserted at :141)
   } else {
-    checks[nc++] = eq32(root_t, pf + PF_OFF_LEAFV + 2);
-    checks[nc++] = eq32(incl_root(2), hdr_hash);
-    checks[nc++] = eq32(incl_root(0), hdr_hash);
+    checks[nc++] = s_eq[0];
+    checks[nc++] = s_eq[1];
+    checks[nc++] = s_eq[2];
     checks[nc++] = chain_ok;
-    checks[nc++] = eq32(incl_root(1), hdr_hash);
+    checks[nc++] = s_eq[3];
     checks[nc++] = height_a == block_b;
     checks[nc++] = all_sigdata; checks[nc++] = all_eddsa; checks[nc++] = no_overflow; checks[nc++] = varint_ok;
-    checks[nc++] = eq32(incl_root(3), hdr_hash);                          // verify.rs:144-147
-    checks[nc++] = eq32(pf + PF_OFF_LEAFX + 2, pr + PR_OFF_HASH);         // verify.rs:150-153
-    checks[nc++] = eq32(incl_root(4), pr + PR_OFF_HASH);                  // verify.rs:166-170
-    checks[nc++] = eq32(pf + PF_OFF_LEAFV + 2, pf + PF_OFF_LEAFY + 2);    // verify.rs:173-177
+    checks[nc++] = s_eq[4];                                       // verify.rs:144-147
+    checks[nc++] = s_eq[5];                                       // verify.rs:150-153
+    checks[nc++] = s_eq[6];                                       // verify.rs:166-170
+    checks[nc++] = s_eq[7];                                       // verify.rs:173-177
     checks[nc++] = (round_ >> 63) == 0;
   }
   bool all_ok = true;
@@ -693,16 +808,19 @@ __global__ __launch_bounds__(TINY_THREADS) void k_tiny(TinyEd E, TinyProof PA, T
   const uint32_t b = blockIdx.x;
   const uint32_t proof_blocks = PA.n_proofs * roles_per_proof;
   if (b < E.n_lanes) {
+    if (TINY_DBG(0x1)) return;
     tiny_lane<KW, BW>(E, b, lds.lane);
   } else if (b < E.n_lanes + proof_blocks) {
     const uint32_t r = b - E.n_lanes, p = r / roles_per_proof, role = r % roles_per_proof;
     uint32_t* tp = E.tiny + TN_WORDS + TN_PER_PROOF * p;
     // roles of a proof: 0 target tree, 1 header, 2 tallies, 3 trusted tree (skip only)
+    if (TINY_DBG(role == 1 ? 0x4 : role == 2 ? 0x8 : 0x2)) return;
     if (role == 0) tiny_tree(PA, p, 0, tp, lds.leaf);
     else if (role == 1) tiny_header(PA, p, tp, lds.hdr);
     else if (role == 2) tiny_tally(PA, p, tp, lds.tally);
     else tiny_tree(PA, p, 1, tp, lds.leaf);
   } else if (SA.out) {  // input role: two serializer spans per workgroup
+    if (TINY_DBG(0x10)) return;
     const uint32_t r = b - E.n_lanes - proof_blocks;
     const uint32_t per = 2 * SA.n_blocks, proof = r / per, k = r - proof * per;
     const uint32_t span = __builtin_amdgcn_readfirstlane(SA.first_block * 4 + 2 * k + (threadIdx.x >> 6));
@@ -710,42 +828,44 @@ __global__ __launch_bounds__(TINY_THREADS) void k_tiny(TinyEd E, TinyProof PA, T
   }
 }
 
-// behind k_tiny on the same stream: workgroup p < n_proofs finishes proof p (checks, verdict merge, the sections that carry them, the
-// seam spans); the others expand the sections that needed k_tiny's results, four spans each
-__global__ __launch_bounds__(256) void k_tiny_tail(TinyProof PA, TinySer SA, const uint8_t* __restrict__ ed, uint32_t ed_stride, RowOut rowout, uint32_t* tiny) {
-  const uint32_t b = blockIdx.x;
-  if (b >= PA.n_proofs) {
-    if (!SA.out) return;
-    const uint32_t r = b - PA.n_proofs, proof = r / SA.n_blocks, k = r - proof * SA.n_blocks;
-    const uint32_t span = __builtin_amdgcn_readfirstlane((SA.first_block + k) * 4 + (threadIdx.x >> 6));
-    serialize_span<256>(SA.S, SA.lut, SA.wave_sec, SA.out, SA.mask, proof, span);
+// behind k_tiny on the same stream.  Workgroup p < n_proofs finishes proof p: checks, verdict merge, then the few elements from the first
+// one that depends on them to the row end; workgroup n_proofs + p expands the seam spans of row p in front of that point; the others
+// expand whole spans, sixteen each, of every section that needed k_tiny's results.
+constexpr uint32_t TINY_TAIL_THREADS = 1024;
+__global__ __launch_bounds__(TINY_TAIL_THREADS) void k_tiny_tail(TinyProof PA, TinySer SA, const uint8_t* __restrict__ ed, uint32_t ed_stride, uint32_t* tiny) {
+  const uint32_t b = blockIdx.x, T = blockDim.x;
+  const SerializeProgram& S = SA.S;
+  if (b >= 2 * PA.n_proofs) {
+    if (!SA.out || TINY_DBG(0x2000)) return;
+    const uint32_t per = (SA.n_blocks + 3) / 4;  // workgroups per proof: sixteen spans = four span blocks each
+    const uint32_t r = b - 2 * PA.n_proofs, proof = r / per, k = r - proof * per;
+    const uint32_t span = __builtin_amdgcn_readfirstlane(SA.first_block * 4 + k * 16 + (threadIdx.x >> 6));
+    if (span < (SA.first_block + SA.n_blocks) * 4 && span < SA.tail_first_span) serialize_span<256>(S, SA.lut, SA.wave_sec, SA.out, SA.mask, proof, span);
     return;
   }
-  const uint32_t proof = b, T = blockDim.x;
-  if (threadIdx.x == 0) tiny_final_checks(PA, proof, tiny + TN_WORDS + TN_PER_PROOF * proof);
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x < 64) {  // verdict_body for this proof (it indexes by blockIdx.x == proof)
-    verdict_body(PA.P.kind, PA.P.n, ed, ed_stride, PA.pf, PA.reports, rowout);
-  }
-  __threadfence();
-  __syncthreads();
-  if (!SA.out) return;
-  const SerializeProgram& S = SA.S;
-  uint64_t* row = SA.out + (size_t)proof * S.elem_stride;
-  for (uint32_t k = 0; k < S.n_sections; k++) {
-    if (!((SA.tail_mask >> k) & 1u)) continue;
-    const Section sc = S.sec[k];
-    const uint32_t lo = sc.elem_start, hi = lo + sc.lane_elems * sc.n_lanes;
-    for (uint32_t e0 = lo + threadIdx.x; e0 < hi; e0 += 2 * T) {
-      const uint32_t e1 = e0 + T;
-      const uint64_t v0 = serialize_one(sc, SA.lut, proof, e0), v1 = e1 < hi ? serialize_one(sc, SA.lut, proof, e1) : 0;
-      row[e0] = v0;
-      if (e1 < hi) row[e1] = v1;
+  if (b >= PA.n_proofs) {  // seam spans in front of the dependent tail
+    if (!SA.out || TINY_DBG(0x8000)) return;
+    const uint32_t proof = b - PA.n_proofs;
+    uint64_t* row = SA.out + (size_t)proof * S.elem_stride;
+    for (uint32_t i = threadIdx.x; i < SA.n_seams * S.span; i += T) {
+      const uint32_t sp = SA.seam_waves[i / S.span], e = sp * S.span + i % S.span;
+      if (sp < SA.tail_first_span && e < S.elem_stride) row[e] = e < S.elem_count ? serialize_one(S.sec[section_of(S, e)], SA.lut, proof, e) : 0;
     }
+    return;
   }
-  for (uint32_t i = threadIdx.x; i < SA.n_seams * S.span; i += T) {
-    const uint32_t e = SA.seam_waves[i / S.span] * S.span + i % S.span;
-    if (e < S.elem_stride) row[e] = e < S.elem_count ? serialize_one(S.sec[section_of(S, e)], SA.lut, proof, e) : 0;
+  const uint32_t proof = b;
+  if (TINY_DBG(0x1000)) return;
+  __shared__ uint32_t s_eq[10];
+  if (!TINY_DBG(0x4000)) tiny_final_checks(PA, proof, tiny + TN_WORDS + TN_PER_PROOF * proof, s_eq);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the record is patched and read back inside this workgroup only)
+  __syncthreads();
+  if (threadIdx.x < 64) {  // verdict merge of this proof (verdict_body indexes by blockIdx.x == proof); the lanes' D.1b elements are in the rows already
+    verdict_body(PA.P.kind, PA.P.n, ed, ed_stride, PA.pf, PA.reports, RowOut{});
   }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __syncthreads();
+  if (!SA.out || TINY_DBG(0x8000)) return;
+  uint64_t* row = SA.out + (size_t)proof * S.elem_stride;
+  for (uint32_t e = SA.tail_first_span * S.span + threadIdx.x; e < S.elem_stride; e += T)
+    row[e] = e < S.elem_count ? serialize_one(S.sec[section_of(S, e)], SA.lut, proof, e) : 0;
 }

@@ -37,6 +37,7 @@ def test_hit_and_miss_counters(tmx, oracle):
     with tmx.Context(n, b"celestia", max_batch=P) as ctx:
         st0 = ctx.key_cache_stats()
         assert st0["enabled"] == 1 and st0["resident_keys"] == 0 and st0["capacity_keys"] >= 1024 and st0["bytes_per_key"] > 200_000
+        ctx.key_cache_config(True, max_keys=4096)   # (room for more than one launch's worth of new keys: no eviction in this test)
         first, _ = _check(ctx, oracle, a, n)
         st = ctx.key_cache_stats()
         assert (st["last_new_keys"], st["last_hit_keys"], st["last_hit_lanes"], st["last_built_keys"]) == (n, 0, 0, n)
