@@ -246,6 +246,7 @@ struct Knobs {
   int walk_parts = -1;       // TMX_WALK_PARTS=0|1: the table walk follows the table build part by part (default: from 65536 lanes)
   bool ext_events = true;    // TMX_EXT_EVENTS=0: record packets instead of completion signals on the chain kernels
   int warm_schedule = -1;    // TMX_SCHEDULE=warm|cold: the EdDSA schedule for resident / new keys (default: by what the last launch saw)
+  bool proof_roles = true;   // TMX_PROOF_ROLES=0: k_proof as one workgroup per proof (the round-3 kernel) instead of four role workgroups
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
 static Knobs read_knobs() {
@@ -260,6 +261,7 @@ static Knobs read_knobs() {
   k.ext_events = !((v = std::getenv("TMX_EXT_EVENTS")) && v[0] == '0');
   k.warm_schedule = (v = std::getenv("TMX_SCHEDULE")) ? (v[0] == 'w' ? 1 : 0) : -1;
   k.tiny = (v = std::getenv("TMX_TINY")) ? (v[0] != '0' ? 1 : 0) : -1;
+  k.proof_roles = !((v = std::getenv("TMX_PROOF_ROLES")) && v[0] == '0');
   return k;
 }
 
@@ -412,8 +414,16 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_leaves launch: ") + hipGetErrorString((hipError_t)rc));
     if (!K.ext_events) HIPCK(c, hipEventRecord(c->ev_leaves, c->side));
   }
-  rc = launch_proof(proof_params(c, kind, leaves_first), n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf, c->d_nodes_t,
-                    c->d_nodes_r, reports, c->side, xp ? evs[0] : nullptr, xp ? evs[1] : nullptr);
+  // k_proof as four role workgroups per proof where its latency is the call's (a handful of proofs, or no EdDSA stage beside it: the
+  // validator-sharded finish); as one workgroup per proof in a batch, where 2048 role waves held up the EdDSA chain (256 proofs: 0.60
+  // vs 0.41 ms) and k_proof is hidden behind it anyway (32 / 64 proofs: +-1 %)
+  const uint64_t lanes_all = (uint64_t)n_proofs * n;
+  const bool roles = K.proof_roles && c->d_tiny && (lanes_all <= 2048 || (!eddsa_writes_rows && lanes_all <= 16384));
+  rc = roles
+           ? launch_proof_roles(proof_params(c, kind, leaves_first), n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf,
+                                c->d_nodes_t, c->d_nodes_r, reports, c->d_tiny, c->side, xp ? evs[0] : nullptr, xp ? evs[1] : nullptr)
+           : launch_proof(proof_params(c, kind, leaves_first), n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf,
+                          c->d_nodes_t, c->d_nodes_r, reports, c->side, xp ? evs[0] : nullptr, xp ? evs[1] : nullptr);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_proof launch: ") + hipGetErrorString((hipError_t)rc));
   if (!xp) HIPCK(c, hipEventRecord(evs[1], c->side));
   // side3: the sections that are a pure expansion of the input records (42 % of a skip row) -- HBM is idle while EdDSA runs.

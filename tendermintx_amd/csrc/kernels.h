@@ -127,6 +127,10 @@ struct TinyLaunch {
   uint32_t tail_dep_elem;  // first element of a row that depends on the final checks
 };
 size_t tiny_counter_words(uint32_t max_proofs);
+// k_proof as four (step: three) workgroups per proof, the last of them to finish running the checks (tiny.hpp: k_proof_roles)
+int launch_proof_roles(const ProofParams& P, uint32_t n_proofs, const void* d_proofs, const void* d_target, const void* d_trusted, void* d_lt,
+                       uint32_t lt_stride, void* d_lr, void* d_pf, void* d_nodes_t, void* d_nodes_r, void* d_reports, void* d_tiny, void* stream,
+                       void* started = nullptr, void* done = nullptr);
 int launch_tiny(const TinyLaunch& T, void* stream, void* started = nullptr, void* done = nullptr);
 int launch_tiny_tail(const TinyLaunch& T, void* stream, void* started = nullptr, void* done = nullptr);
 

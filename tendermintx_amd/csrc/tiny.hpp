@@ -408,7 +408,12 @@ __device__ __forceinline__ void tiny_tree(const TinyProof& A, uint32_t p, uint32
     uint8_t* o = set ? A.lr + ((size_t)p * n + i) * LANE_STRIDE : A.lt + ((size_t)p * n + i) * A.lt_stride;
     if (ld64(rec + (set ? HR_OFF_POWER : VR_OFF_POWER)) >> 63) bad++;  // marshal_int64_varint asserts bit 63 == 0 (shared.rs:80)
     uint32_t dig[8], pkw[8];
-    marshal_and_leaf(rec, set != 0, o, dig, pkw);
+    if (A.P.leaves_done) {  // (k_leaves has run: very large batches serialize the leaf sections early)
+#pragma unroll
+      for (int k = 0; k < 8; k++) dig[k] = bswap32(ld32(o + LN_OFF_LEAF + 4 * k));
+    } else {
+      marshal_and_leaf(rec, set != 0, o, dig, pkw);
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) s_leaf[i][k] = dig[k];
   }
@@ -694,8 +699,7 @@ __device__ __forceinline__ void tiny_tally(const TinyProof& A, uint32_t p, uint3
 }
 
 // thresholds, checks, verdict of one proof from what the roles left in the proof record, the tree nodes and the counters (proof_body
-// phase 5).  The whole workgroup: the 32-byte comparisons are one byte per thread (a wave does two of them, a ballot each), the chain-id
-// bytes one per thread of the next wave; thread 0 assembles.  Owns [PF_OFF_VERDICTS, PF_OFF_HEIGHT) of the record and the report.
+// phase 5).  The whole workgroup (any size): the 32-byte comparisons and the chain-id bytes are one byte per thread; thread 0 assembles.  Owns [PF_OFF_VERDICTS, PF_OFF_HEIGHT) of the record and the report.
 __device__ __forceinline__ void tiny_final_checks(const TinyProof& A, uint32_t p, uint32_t* tp, uint32_t* s_eq /*[10]*/) {
   const ProofParams& P = A.P;
   const bool skip = P.kind == 0;
@@ -707,25 +711,25 @@ __device__ __forceinline__ void tiny_final_checks(const TinyProof& A, uint32_t p
   const uint8_t* root_r = P.tree_nodes ? A.nodes_r + ((size_t)p * P.tree_nodes + P.tree_nodes - 1) * 32 : A.lr + (size_t)p * n * LANE_STRIDE + LN_OFF_LEAF;
   const uint8_t* hdr_hash = pf + PF_OFF_HEADER;
   auto incl_root = [&](int q) { return (const uint8_t*)(pf + PF_OFF_PROOFD + 160 * q + 128); };
-  if (t < 256) {  // comparison c = t / 32, byte t % 32
-    const uint32_t c = t >> 5, k = t & 31u;
-    const uint8_t *x, *y;
-    if (skip) {
-      x = c == 0 ? incl_root(3) : c == 1 ? root_r : c == 2 ? root_t : c == 3 ? incl_root(2) : c == 4 ? incl_root(0) : incl_root(1);
-      y = c == 0 ? pr + PR_OFF_HASH : c == 1 ? pf + PF_OFF_LEAFX + 2 : c == 2 ? pf + PF_OFF_LEAFV + 2 : hdr_hash;
+  if (t < 10) s_eq[t] = t == 8 ? (P.chain_id_len <= 50 ? 1u : 0u) : 1u;
+  __syncthreads();
+  for (uint32_t idx = t; idx < 320; idx += blockDim.x) {
+    if (idx < 256) {  // comparison c = idx / 32, byte idx % 32
+      const uint32_t c = idx >> 5, k = idx & 31u;
+      const uint8_t *x, *y;
+      if (skip) {
+        x = c == 0 ? incl_root(3) : c == 1 ? root_r : c == 2 ? root_t : c == 3 ? incl_root(2) : c == 4 ? incl_root(0) : incl_root(1);
+        y = c == 0 ? pr + PR_OFF_HASH : c == 1 ? pf + PF_OFF_LEAFX + 2 : c == 2 ? pf + PF_OFF_LEAFV + 2 : hdr_hash;
+      } else {
+        x = c == 0 ? root_t : c == 1 ? incl_root(2) : c == 2 ? incl_root(0) : c == 3 ? incl_root(1) : c == 4 ? incl_root(3)
+            : c == 5 ? pf + PF_OFF_LEAFX + 2 : c == 6 ? incl_root(4) : pf + PF_OFF_LEAFV + 2;
+        y = c == 0 ? pf + PF_OFF_LEAFV + 2 : c <= 4 ? hdr_hash : c == 5 ? pr + PR_OFF_HASH : c == 6 ? pr + PR_OFF_HASH : pf + PF_OFF_LEAFY + 2;
+      }
+      if (c < (skip ? 6u : 8u) && x[k] != y[k]) s_eq[c] = 0;  // (every writer stores the same value)
     } else {
-      x = c == 0 ? root_t : c == 1 ? incl_root(2) : c == 2 ? incl_root(0) : c == 3 ? incl_root(1) : c == 4 ? incl_root(3)
-          : c == 5 ? pf + PF_OFF_LEAFX + 2 : c == 6 ? incl_root(4) : pf + PF_OFF_LEAFV + 2;
-      y = c == 0 ? pf + PF_OFF_LEAFV + 2 : c <= 4 ? hdr_hash : c == 5 ? pr + PR_OFF_HASH : c == 6 ? pr + PR_OFF_HASH : pf + PF_OFF_LEAFY + 2;
+      const uint32_t k = idx - 256;
+      if (k < P.chain_id_len && k < 50 && pf[PF_OFF_CID52 + 2 + k] != P.chain_id[k]) s_eq[8] = 0;
     }
-    const bool live = c < (skip ? 6u : 8u);
-    const uint64_t ne = __ballot(live && x[k] != y[k]);
-    if ((t & 63u) == 0) { s_eq[2 * (t >> 6)] = (uint32_t)ne == 0; s_eq[2 * (t >> 6) + 1] = (uint32_t)(ne >> 32) == 0; }
-  } else if (t < 320) {
-    const uint32_t k = t - 256;
-    const bool bad = k < P.chain_id_len && k < 50 && pf[PF_OFF_CID52 + 2 + k] != P.chain_id[k];
-    const uint64_t ne = __ballot(bad);
-    if (k == 0) s_eq[8] = (ne == 0 && P.chain_id_len <= 50) ? 1u : 0u;
   }
   __syncthreads();
   if (t != 0) return;
@@ -868,4 +872,29 @@ __global__ __launch_bounds__(TINY_TAIL_THREADS) void k_tiny_tail(TinyProof PA, T
   uint64_t* row = SA.out + (size_t)proof * S.elem_stride;
   for (uint32_t e = SA.tail_first_span * S.span + threadIdx.x; e < S.elem_stride; e += T)
     row[e] = e < S.elem_count ? serialize_one(S.sec[section_of(S, e)], SA.lut, proof, e) : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ k_proof as roles (any batch size)
+// The classic launch graph's k_proof was one workgroup per proof running its phases one after the other (120 us for one proof, 260 us
+// inside a 256-proof step).  The same values from FOUR workgroups per proof (three for step) that run side by side -- target tree, header
+// (+ inclusion proofs + sign-bytes checks), tallies (+ N x N match), trusted tree -- and the workgroup that finishes LAST for a proof
+// (an agent-scope counter; nobody waits for anybody) runs the thresholds / checks / verdict on what all of them left.
+__global__ __launch_bounds__(TINY_THREADS) void k_proof_roles(TinyProof PA, uint32_t* __restrict__ tiny, uint32_t roles) {
+  __shared__ union { uint32_t leaf[TMX_N_LIMIT][8]; uint32_t hdr[2][28][8]; TinyTallyLds tally; } lds;
+  __shared__ uint32_t s_last, s_eq[10];
+  if (gridDim.x >= 2048) __builtin_amdgcn_s_setprio(2);  // (large batches: ahead of the EdDSA throughput waves, as k_proof did)
+  const uint32_t b = blockIdx.x, p = b / roles, role = b - p * roles;
+  uint32_t* tp = tiny + TN_WORDS + TN_PER_PROOF * p;
+  if (role == 0) tiny_tree(PA, p, 0, tp, lds.leaf);
+  else if (role == 1) tiny_header(PA, p, tp, lds.hdr);
+  else if (role == 2) tiny_tally(PA, p, tp, lds.tally);
+  else tiny_tree(PA, p, 1, tp, lds.leaf);
+  __threadfence();  // release: this workgroup's records, for whichever workgroup turns out to be the last
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(&tp[3], 1u) == roles - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();  // acquire: the other roles' records
+  if (threadIdx.x == 0) tp[3] = 0;
+  tiny_final_checks(PA, p, tp, s_eq);
 }
