@@ -53,7 +53,8 @@ typedef enum {
   TMX_ERR_HIP = -3,           /* no device / HIP runtime error (message in tmx_last_error) */
   TMX_ERR_CAPACITY = -4,      /* output buffer or context batch capacity too small */
   TMX_ERR_PARSE = -5,         /* malformed fixture / RPC JSON */
-  TMX_ERR_MSG_TOO_LONG = -6   /* sign-bytes longer than 124 B -- conversion.rs:52 `try_into().unwrap()` */
+  TMX_ERR_MSG_TOO_LONG = -6,  /* sign-bytes longer than 124 B -- conversion.rs:52 `try_into().unwrap()` */
+  TMX_ERR_RCCL = -7           /* RCCL not loadable / a collective failed (message in tmx_last_error) -- SURVEY 8(b) error convention */
 } tmx_status;
 
 /* One lane of `target_block_validators` (ValidatorType, reference circuits/variables.rs:69-79) before
@@ -201,6 +202,32 @@ int32_t tmx_sync(tmx_ctx* ctx);
  * walked a per-key table (a key resident in the key cache, or a new key with >= 8 lanes per key on average; TMX_DEDUP=0|1|2 forces
  * never / automatic / whenever a table fits).  Blocks. */
 int32_t tmx_last_dedup(tmx_ctx* ctx, uint32_t* n_unique, uint32_t* used_tables);
+
+/* ---- multi-GPU: one process per GPU, the exchange step behind this ABI so that the host the reference actually has -- the
+ * Rust process of bin/skip.rs, reached only through SkipOffchainInputs::hint (reference circuits/skip.rs:64-102) -- can shard without
+ * any Python.  RCCL is resolved at run time from the host process (no DT_NEEDED, like the HIP runtime): an already loaded librccl is
+ * used, else $TMX_RCCL_LIB, else librccl.so.1 / librccl.so by the loader's search path.  Bootstrap as with NCCL: ONE rank calls
+ * tmx_comm_unique_id, hands the 128 bytes to the others by whatever channel the host has (a file, its RPC, MPI ...), then every rank calls
+ * tmx_comm_create(ctx, id, rank, world) on a context of ITS device.  world = 1 needs no id and loads nothing.
+ *   tmx_shard_range                       contiguous [lo, hi) of n_items for `rank` of `world`; sizes differ by at most one
+ *   tmx_witness_batch_sharded_device      BASELINE configs[3]: n_total independent proofs, every rank holds all input records and an output
+ *                                         buffer for all rows; rank r computes rows [lo_r, hi_r) in place; gather != 0 then makes every row
+ *                                         (and report) resident on every rank -- one grouped RCCL exchange, each rank broadcasting its slice
+ *                                         in place: no padding, no staging copy.  gather = 0: no data-path collective at all.
+ *   tmx_witness_validator_sharded_device  BASELINE configs[4]: the n_proofs * n_max validator lanes split across the ranks for the EdDSA stage,
+ *                                         ONE grouped exchange of the 448-byte lane records, then every rank finishes every proof
+ *                                         (tmx_finish_batch_device on the reassembled records): full rows + reports on every rank.
+ * Both are asynchronous on hip_stream like tmx_witness_batch_device; n_total / the lanes may be smaller than the world (empty shards). */
+#define TMX_UNIQUE_ID_BYTES 128
+void tmx_shard_range(uint64_t n_items, uint32_t rank, uint32_t world, uint64_t* lo, uint64_t* hi);
+int32_t tmx_comm_unique_id(uint8_t out[TMX_UNIQUE_ID_BYTES]);
+int32_t tmx_comm_create(tmx_ctx* ctx, const uint8_t unique_id[TMX_UNIQUE_ID_BYTES] /* NULL iff world == 1 */, uint32_t rank, uint32_t world);
+int32_t tmx_comm_destroy(tmx_ctx* ctx);
+int32_t tmx_comm_info(const tmx_ctx* ctx, uint32_t* rank, uint32_t* world);  /* (0, 1) before tmx_comm_create */
+int32_t tmx_witness_batch_sharded_device(tmx_ctx* ctx, int32_t kind, uint32_t n_total, const void* d_proofs, const void* d_targets,
+                                         const void* d_trusteds, void* d_out_elems, void* d_reports, uint32_t gather, void* hip_stream);
+int32_t tmx_witness_validator_sharded_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
+                                             const void* d_trusteds, void* d_out_elems, void* d_reports, void* hip_stream);
 
 /* ---- persistent per-key table cache.  h*A of a lane is 32 additions from a 655-KB window table of its public key instead of 252
  * doublings + 64 additions; the context keeps those tables in a content-addressed cache in HBM (key = the 32 public-key bytes, all 32

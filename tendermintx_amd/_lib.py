@@ -158,6 +158,16 @@ def lib():
     L.tmx_eddsa_lanes_device.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tmx_finish_batch_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tmx_shard_range.restype = None
+    L.tmx_shard_range.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.tmx_comm_unique_id.argtypes = [C.c_char_p]
+    L.tmx_comm_create.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32]
+    L.tmx_comm_destroy.argtypes = [C.c_void_p]
+    L.tmx_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.tmx_witness_batch_sharded_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_uint32, C.c_void_p]
+    L.tmx_witness_validator_sharded_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                       C.c_void_p]
     L.tmx_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.tmx_kernel_ms_mean.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
     L.tmx_ctx_stream.restype = C.c_void_p

@@ -198,6 +198,26 @@ class Context:
         check(self._L.tmx_finish_batch_device(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_ed, d_out, d_reports, self._stream(stream)),
               self._h)
 
+    # ---- multi-GPU: the RCCL exchange behind the C ABI (include/tmx.h "multi-GPU")
+    def comm_create(self, unique_id, rank, world):
+        check(self._L.tmx_comm_create(self._h, bytes(unique_id) if unique_id is not None else None, rank, world), self._h)
+
+    def comm_destroy(self):
+        check(self._L.tmx_comm_destroy(self._h), self._h)
+
+    def comm_info(self):
+        r, w = C.c_uint32(), C.c_uint32()
+        check(self._L.tmx_comm_info(self._h, C.byref(r), C.byref(w)), self._h)
+        return r.value, w.value
+
+    def witness_batch_sharded_device(self, kind, n_total, d_proofs, d_targets, d_trusteds, d_out, d_reports, gather=False, stream=None):
+        check(self._L.tmx_witness_batch_sharded_device(self._h, kind, n_total, d_proofs, d_targets, d_trusteds, d_out, d_reports,
+                                                       1 if gather else 0, self._stream(stream)), self._h)
+
+    def witness_validator_sharded_device(self, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports, stream=None):
+        check(self._L.tmx_witness_validator_sharded_device(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports,
+                                                           self._stream(stream)), self._h)
+
     def last_kernel_ms(self):
         ms = (C.c_float * _lib.N_KERNELS)()
         check(self._L.tmx_last_kernel_ms(self._h, ms), self._h)

@@ -310,6 +310,8 @@ struct tmx_ctx {
   hipStream_t side3 = nullptr;  // early serialization of the input-only sections
   hipEvent_t ev_join3 = nullptr;
   uint32_t parity = 0;  // which of the two counter sets this launch uses
+  void* comm = nullptr;        // ncclComm_t of this context's device (tmx_comm_create), or null
+  uint32_t comm_rank = 0, comm_world = 1;
   void* d_tiny = nullptr;      // counters of the small-launch path (kernels.h: tiny_counter_words), zero between launches
   void* d_shadow = nullptr;    // key bytes + flags of the lanes of a small launch (TINY_MAX_LANES records): what its key pipeline reads
   bool slot_tiny[EV_RING_DECL] = {};  // which event sets of the ring belong to small launches (their four events mark other points)
@@ -804,6 +806,7 @@ const char* tmx_status_str(int32_t s) {
     case TMX_ERR_CAPACITY: return "capacity too small";
     case TMX_ERR_PARSE: return "malformed JSON";
     case TMX_ERR_MSG_TOO_LONG: return "sign-bytes longer than 124 bytes";
+    case TMX_ERR_RCCL: return "RCCL error";
     default: return "unknown";
   }
 }
@@ -934,6 +937,7 @@ extern "C" {
 
 void tmx_ctx_destroy(tmx_ctx* c) {
   if (!c) return;
+  (void)tmx_comm_destroy(c);
   if (c->have_streams) {  // side streams may still hold work enqueued by the last call (hash-table reset for the next launch)
     (void)hipSetDevice(c->cfg.device);
     (void)hipDeviceSynchronize();
@@ -1773,6 +1777,192 @@ int32_t tmx_poseidon_permute(tmx_ctx* c, uint32_t n, const uint64_t* in, uint64_
   if (d_out) (void)hipFree(d_out);
   if (e != hipSuccess) return fail(c, TMX_ERR_HIP, std::string("tmx_poseidon_permute: ") + hipGetErrorString(e));
   return TMX_OK;
+}
+
+}  // extern "C"
+
+// ---- multi-GPU: RCCL behind the C ABI (include/tmx.h "multi-GPU") -------------------------------------------------------
+// RCCL is bound at run time: dlopen / dlsym, never a DT_NEEDED -- the process that loads libtmx decides which librccl (and which HIP
+// runtime under it) it runs on.  PyTorch bundles its own; a C / Rust host gets /opt/rocm's.
+#include <dlfcn.h>
+#include <link.h>
+
+namespace {
+struct RcclId { char internal[TMX_UNIQUE_ID_BYTES]; };
+static_assert(sizeof(RcclId) == 128, "ncclUniqueId is 128 bytes");
+struct Rccl {
+  void* lib = nullptr;
+  std::string err;
+  int (*GetUniqueId)(RcclId*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+std::mutex g_rccl_mu;
+Rccl g_rccl;
+int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
+  if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl")) {
+    *reinterpret_cast<std::string*>(out) = info->dlpi_name;
+    return 1;
+  }
+  return 0;
+}
+// null on success, else why not
+const char* rccl_load() {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  Rccl& R = g_rccl;
+  if (R.lib) return nullptr;
+  std::string loaded;
+  (void)dl_iterate_phdr(find_loaded_rccl, &loaded);  // the copy the process already runs on (PyTorch's), if any
+  std::vector<std::string> names;
+  if (!loaded.empty()) names.push_back(loaded);
+  if (const char* v = std::getenv("TMX_RCCL_LIB")) names.push_back(v);
+  names.push_back("librccl.so.1");
+  names.push_back("librccl.so");
+  names.push_back("/opt/rocm/lib/librccl.so.1");
+  void* h = nullptr;
+  for (const std::string& nm : names)
+    if ((h = dlopen(nm.c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!h) { R.err = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?"); return R.err.c_str(); }
+  auto sym = [&](const char* n) { return dlsym(h, n); };
+  R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(sym("ncclGetUniqueId"));
+  R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(sym("ncclCommInitRank"));
+  R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
+  R.Broadcast = reinterpret_cast<decltype(R.Broadcast)>(sym("ncclBroadcast"));
+  R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(sym("ncclGroupStart"));
+  R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(sym("ncclGroupEnd"));
+  R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
+  if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.Broadcast || !R.GroupStart || !R.GroupEnd || !R.GetErrorString) {
+    R.err = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclBroadcast / ncclGroupStart / ncclGroupEnd / ncclGetErrorString";
+    return R.err.c_str();
+  }
+  R.lib = h;
+  return nullptr;
+}
+int32_t rccl_fail(tmx_ctx* c, const char* what, int rc) {
+  return fail(c, TMX_ERR_RCCL, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+}
+constexpr int RCCL_UINT8 = 1;  // ncclUint8
+// every rank's slice [lo_r, hi_r) of `n_items` records of `rec_bytes` becomes resident on every rank: one grouped exchange, in place
+int32_t exchange_slices(tmx_ctx* c, void* d_buf, uint64_t n_items, size_t rec_bytes, hipStream_t s) {
+  if (!c->comm) return TMX_OK;
+  int rc = g_rccl.GroupStart();
+  if (rc) return rccl_fail(c, "ncclGroupStart", rc);
+  for (uint32_t r = 0; r < c->comm_world; r++) {
+    uint64_t lo, hi;
+    tmx_shard_range(n_items, r, c->comm_world, &lo, &hi);
+    if (hi == lo) continue;
+    uint8_t* p = reinterpret_cast<uint8_t*>(d_buf) + lo * rec_bytes;
+    rc = g_rccl.Broadcast(p, p, (size_t)(hi - lo) * rec_bytes, RCCL_UINT8, (int)r, c->comm, s);
+    if (rc) { (void)g_rccl.GroupEnd(); return rccl_fail(c, "ncclBroadcast", rc); }
+  }
+  rc = g_rccl.GroupEnd();
+  if (rc) return rccl_fail(c, "ncclGroupEnd", rc);
+  return TMX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+void tmx_shard_range(uint64_t n_items, uint32_t rank, uint32_t world, uint64_t* lo, uint64_t* hi) {
+  if (world == 0) world = 1;
+  if (rank >= world) rank = world - 1;
+  const uint64_t base = n_items / world, rem = n_items % world;
+  const uint64_t a = (uint64_t)rank * base + (rank < rem ? rank : rem);
+  if (lo) *lo = a;
+  if (hi) *hi = a + base + (rank < rem ? 1 : 0);
+}
+
+int32_t tmx_comm_unique_id(uint8_t out[TMX_UNIQUE_ID_BYTES]) {
+  if (!out) return TMX_ERR_BAD_ARG;
+  if (rccl_load()) return TMX_ERR_RCCL;
+  RcclId id;
+  std::memset(&id, 0, sizeof id);
+  if (g_rccl.GetUniqueId(&id)) return TMX_ERR_RCCL;
+  std::memcpy(out, id.internal, TMX_UNIQUE_ID_BYTES);
+  return TMX_OK;
+}
+
+int32_t tmx_comm_create(tmx_ctx* c, const uint8_t* unique_id, uint32_t rank, uint32_t world) {
+  if (!c || world == 0 || rank >= world || (world > 1 && !unique_id)) return TMX_ERR_BAD_ARG;
+  if (unique_id && c->cfg.device < 0) return TMX_ERR_BAD_ARG;
+  int32_t st = tmx_comm_destroy(c);
+  if (st) return st;
+  if (world == 1 && !unique_id) { c->comm_rank = 0; c->comm_world = 1; return TMX_OK; }  // nothing to exchange, nothing to load
+  // (world == 1 WITH an id makes a real one-rank communicator: the exchange then runs through RCCL -- a broadcast to itself -- which is
+  // how the 1-GPU boxes exercise this path)
+  if (const char* why = rccl_load()) return fail(c, TMX_ERR_RCCL, why);
+  HIPCK(c, hipSetDevice(c->cfg.device));
+  RcclId id;
+  std::memcpy(id.internal, unique_id, TMX_UNIQUE_ID_BYTES);
+  void* comm = nullptr;
+  const int rc = g_rccl.CommInitRank(&comm, (int)world, id, (int)rank);
+  if (rc) return rccl_fail(c, "ncclCommInitRank", rc);
+  c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+  return TMX_OK;
+}
+
+int32_t tmx_comm_destroy(tmx_ctx* c) {
+  if (!c) return TMX_ERR_BAD_ARG;
+  if (c->comm) {
+    if (c->have_streams) { (void)hipSetDevice(c->cfg.device); (void)hipDeviceSynchronize(); }
+    const int rc = g_rccl.CommDestroy ? g_rccl.CommDestroy(c->comm) : 0;
+    c->comm = nullptr;
+    if (rc) return rccl_fail(c, "ncclCommDestroy", rc);
+  }
+  c->comm_rank = 0; c->comm_world = 1;
+  return TMX_OK;
+}
+
+int32_t tmx_comm_info(const tmx_ctx* c, uint32_t* rank, uint32_t* world) {
+  if (!c) return TMX_ERR_BAD_ARG;
+  if (rank) *rank = c->comm_rank;
+  if (world) *world = c->comm_world;
+  return TMX_OK;
+}
+
+int32_t tmx_witness_batch_sharded_device(tmx_ctx* c, int32_t kind, uint32_t n_total, const void* d_proofs, const void* d_targets,
+                                         const void* d_trusteds, void* d_out_elems, void* d_reports, uint32_t gather, void* hip_stream) {
+  int32_t st = check_batch_args(c, kind, 0, d_proofs, d_targets, d_trusteds);
+  if (st) return st;
+  if (n_total == 0) return TMX_OK;
+  if (gather && c->comm_world > 1 && (!d_out_elems || !d_reports)) return fail(c, TMX_ERR_BAD_ARG, "gather needs the row and report buffers");
+  uint64_t lo, hi;
+  tmx_shard_range(n_total, c->comm_rank, c->comm_world, &lo, &hi);
+  if (hi - lo > c->cfg.max_batch) return fail(c, TMX_ERR_CAPACITY, "this rank's shard exceeds the context's max_batch");
+  const uint32_t n = c->cfg.n_max;
+  const size_t row_bytes = (size_t)tmx_elem_stride(kind, n) * 8;
+  auto at = [](const void* p, size_t off) { return p ? reinterpret_cast<const uint8_t*>(p) + off : nullptr; };
+  if (hi > lo) {
+    st = tmx_witness_batch_device(c, kind, (uint32_t)(hi - lo), at(d_proofs, lo * PR_STRIDE), at(d_targets, lo * n * VR_STRIDE),
+                                  at(d_trusteds, lo * n * HR_STRIDE), const_cast<uint8_t*>(at(d_out_elems, lo * row_bytes)),
+                                  const_cast<uint8_t*>(at(d_reports, lo * sizeof(tmx_report))), hip_stream);
+    if (st) return st;
+  }
+  if (!gather) return TMX_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  if ((st = exchange_slices(c, d_out_elems, n_total, row_bytes, s))) return st;
+  return exchange_slices(c, d_reports, n_total, sizeof(tmx_report), s);
+}
+
+int32_t tmx_witness_validator_sharded_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
+                                             const void* d_trusteds, void* d_out_elems, void* d_reports, void* hip_stream) {
+  int32_t st = check_batch_args(c, kind, n_proofs, d_proofs, d_targets, d_trusteds);
+  if (st) return st;
+  if (n_proofs == 0) return TMX_OK;
+  const uint64_t lanes = (uint64_t)n_proofs * c->cfg.n_max;
+  uint64_t lo, hi;
+  tmx_shard_range(lanes, c->comm_rank, c->comm_world, &lo, &hi);
+  uint8_t* ed = reinterpret_cast<uint8_t*>(c->d_ed);
+  if (hi > lo) {
+    st = tmx_eddsa_lanes_device(c, (uint32_t)(hi - lo), reinterpret_cast<const uint8_t*>(d_targets) + lo * VR_STRIDE, ed + lo * ED_STRIDE, hip_stream);
+    if (st) return st;
+  }
+  if ((st = exchange_slices(c, ed, lanes, ED_STRIDE, reinterpret_cast<hipStream_t>(hip_stream)))) return st;
+  return tmx_finish_batch_device(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, ed, d_out_elems, d_reports, hip_stream);
 }
 
 }  // extern "C"

@@ -1,78 +1,70 @@
-"""Multi-GPU partitioning of the witness path: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+"""Multi-GPU partitioning of the witness path: one process per GPU, the exchange behind the C ABI (include/tmx.h "multi-GPU").
 
-Two modes:
+Two modes, both implemented in libtmx (`tmx_witness_batch_sharded_device`, `tmx_witness_validator_sharded_device`) so that
+the host the reference actually has -- the Rust process behind `SkipOffchainInputs::hint`, reference circuits/skip.rs:64-102 -- can use them
+without Python; this module is the thin Python caller the tests and bench.py drive:
 
-* proof-sharded batch (BASELINE config 4): proofs are independent, rank r takes a contiguous slice, there is NO data-path
-  collective; `gather_rows` optionally reassembles the rows on every rank with one all-gather.
-* validator-sharded single proof (BASELINE config 5): the N lanes of one proof are split across ranks for the EdDSA stage
-  (the only expensive stage); the 448-byte lane records are exchanged with ONE all-gather (N*448 B = 224 KB at N = 512:
-  latency-bound, a direct all-gather uses every xGMI link once), then each rank finishes the proof on the reassembled
-  records (Merkle trees, tallies, serialization are cheap and replicated).
+* proof-sharded batch (BASELINE configs[3]): proofs are independent, rank r computes a contiguous slice of the rows in place in a
+  full-size buffer; `gather=True` makes every row resident on every rank with ONE grouped RCCL exchange (each rank broadcasts its slice
+  in place: no padding, no staging copy).  Without it there is no data-path collective at all.
+* validator-sharded proofs (BASELINE configs[4]): the lanes are split across the ranks for the EdDSA stage, ONE grouped exchange of the
+  448-byte lane records (224 KB at N = 512: latency-bound), then every rank finishes the proof on the reassembled records.
 
-The compute steps are injected callables so that the partition/exchange logic is testable on CPU with gloo (the tests
-inject the oracle there; the product default is the HIP path of `Context`, which needs a GPU).
+The only thing `torch.distributed` carries here is the bootstrap: the 128-byte RCCL unique id from rank 0 to the others (any channel
+would do: a file, the host's RPC) and barriers around timed regions.
 """
-import torch
-import torch.distributed as dist
+import ctypes as C
+
+from . import _lib
 
 ED_STRIDE = 448
 
 
 def shard_range(n_items, rank, world):
-    """Contiguous [lo, hi) of `n_items` for `rank`; sizes differ by at most one."""
-    base, rem = divmod(n_items, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    """Contiguous [lo, hi) of `n_items` for `rank`; sizes differ by at most one.  The C ABI's tmx_shard_range: one partition rule for every host."""
+    lo, hi = C.c_uint64(), C.c_uint64()
+    _lib.lib().tmx_shard_range(n_items, rank, world, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
 
 
-def gather_rows(local_rows, n_total, group=None):
-    """All-gather equally-shaped per-rank row blocks (padded to the largest shard) and strip the padding.
-    local_rows: [n_local, width] tensor on the rank's device.  Returns [n_total, width]."""
-    world = dist.get_world_size(group)
-    per = (n_total + world - 1) // world
-    width = local_rows.shape[1]
-    pad = torch.zeros((per, width), dtype=local_rows.dtype, device=local_rows.device)
-    pad[:local_rows.shape[0]] = local_rows
-    out = torch.empty((world * per, width), dtype=local_rows.dtype, device=local_rows.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
-    pieces = []
-    for r in range(world):
-        lo, hi = shard_range(n_total, r, world)
-        pieces.append(out[r * per:r * per + (hi - lo)])
-    return torch.cat(pieces, dim=0)
+def unique_id():
+    """128-byte RCCL unique id (rank 0 creates it and hands it to the other ranks)."""
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.lib().tmx_comm_unique_id(buf))
+    return buf.raw
 
 
-def validator_sharded_eddsa(target_lanes, eddsa_fn, group=None):
-    """target_lanes: uint8 tensor [N, 256] (identical on every rank).  Each rank runs `eddsa_fn(lanes[lo:hi]) -> uint8
-    [hi-lo, 448]` on its slice; returns the reassembled [N, 448] records on every rank (one all-gather)."""
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    n = target_lanes.shape[0]
-    lo, hi = shard_range(n, rank, world)
-    local = eddsa_fn(target_lanes[lo:hi])
-    assert local.shape == (hi - lo, ED_STRIDE) and local.dtype == torch.uint8
-    return gather_rows(local, n, group)
+def connect(ctx, group=None):
+    """Give `ctx` an RCCL communicator over the ranks of the torch.distributed `group`: the id travels through the group's own backend (gloo
+    or nccl), the data path afterwards is libtmx's.  world_size 1: no id, nothing loaded."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        ctx.comm_create(None, 0, 1)
+        return 0, 1
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    ctx.comm_create(box[0], rank, world)
+    return rank, world
 
 
-def make_gpu_eddsa_fn(ctx, stream=None):
-    """Product default: k_eddsa on this rank's GPU through the C ABI (tmx_eddsa_lanes_device)."""
-    def fn(lanes):
-        lanes = lanes.contiguous()
-        out = torch.empty((lanes.shape[0], ED_STRIDE), dtype=torch.uint8, device=lanes.device)
-        s = stream if stream is not None else int(torch.cuda.current_stream(lanes.device).cuda_stream)
-        ctx.eddsa_lanes_device(lanes.shape[0], lanes.data_ptr(), out.data_ptr(), s)
-        return out
-    return fn
+def proof_sharded_batch(ctx, kind, n_total, d_proofs, d_targets, d_trusteds, d_out, d_reports, gather=False, stream=None):
+    """All arguments are device tensors holding ALL n_total proofs / rows (identical inputs on every rank); this rank fills its rows,
+    `gather` fills the others'."""
+    ctx.witness_batch_sharded_device(kind, n_total, d_proofs.data_ptr(), d_targets.data_ptr(), d_trusteds.data_ptr() if d_trusteds is not None else None,
+                                     d_out.data_ptr() if d_out is not None else None, d_reports.data_ptr(), gather, stream)
 
 
-def validator_sharded_skip(ctx, kind, proof, target, trusted, group=None):
-    """One proof, lanes split across the ranks' GPUs.  proof/target/trusted: uint8 device tensors (identical on every
-    rank).  Returns (elements int64 [elem_count], report uint8 [64]) on every rank."""
+def validator_sharded_skip(ctx, kind, proof, target, trusted, n_proofs=1, stream=None):
+    """Lanes split across the ranks' GPUs.  proof/target/trusted: uint8 device tensors (identical on every rank).  Returns
+    (elements int64 [n_proofs, elem_stride], reports uint8 [n_proofs * 64]) on every rank; one proof: ([elem_count], [64]) as before."""
+    import torch
     dev = target.device
-    n = ctx.n_max
-    ed = validator_sharded_eddsa(target.view(n, 256), make_gpu_eddsa_fn(ctx), group).contiguous()
-    out = torch.zeros(ctx.elem_stride(kind), dtype=torch.int64, device=dev)
-    rep = torch.zeros(64, dtype=torch.uint8, device=dev)
-    s = int(torch.cuda.current_stream(dev).cuda_stream)
-    ctx.finish_batch_device(kind, 1, proof.data_ptr(), target.data_ptr(), trusted.data_ptr() if trusted is not None else None,
-                            ed.data_ptr(), out.data_ptr(), rep.data_ptr(), s)
-    return out[:ctx.elem_count(kind)], rep
+    out = torch.zeros((n_proofs, ctx.elem_stride(kind)), dtype=torch.int64, device=dev)
+    rep = torch.zeros(n_proofs * 64, dtype=torch.uint8, device=dev)
+    ctx.witness_validator_sharded_device(kind, n_proofs, proof.data_ptr(), target.data_ptr(), trusted.data_ptr() if trusted is not None else None,
+                                         out.data_ptr(), rep.data_ptr(), stream)
+    if n_proofs == 1:
+        return out[0, :ctx.elem_count(kind)], rep
+    return out, rep

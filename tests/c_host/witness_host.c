@@ -9,7 +9,13 @@
  *   threads <fixtures> <n_max> <chain_id> <out.bin> <trusted_block> <trusted_hash_hex> <target_block> <iters>
  *           two host threads, each with a context of its own, run the same skip witness `iters` times concurrently (the calling pattern of
  *           a tokio host with several hint workers, reference circuits/skip.rs:37-44: contexts of one device share the library's internal
- *           streams); every row of every iteration must equal the first one; prints ms per call alone and with both threads running.   */
+ *           streams); every row of every iteration must equal the first one; prints ms per call alone and with both threads running.
+ *   sharded <fixtures> <n_max> <chain_id> <out.bin> <trusted_block> <trusted_hash_hex> <target_block>
+ *           the multi-GPU entry points from a compiled host, on the ranks this box has (one): tmx_comm_unique_id -> tmx_comm_create with
+ *           the id (a real RCCL communicator; librccl is dlopen'ed by libtmx, this program does not link it) ->
+ *           tmx_witness_validator_sharded_device (lanes split, the lane records exchanged through RCCL, finish) on device buffers this
+ *           program owns, then tmx_witness_batch_sharded_device with the row exchange: both rows must be the same; writes the row.     */
+#include <hip/hip_runtime_api.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -179,6 +185,41 @@ int main(int argc, char** argv) {
            solo.ms_per_call, w[0].ms_per_call, w[1].ms_per_call);
     dump(out, w[1].first, count * 8);
     return (solo.mismatches || w[0].mismatches || w[1].mismatches || !same) ? 1 : 0;
+  }
+  if (!strcmp(mode, "sharded")) {
+    tmx_ctx* ctx = make_ctx(n, chain);
+    uint8_t id[TMX_UNIQUE_ID_BYTES];
+    int32_t st = tmx_comm_unique_id(id);
+    if (st) { fprintf(stderr, "tmx_comm_unique_id: %s\n", tmx_status_str(st)); return 1; }
+    st = tmx_comm_create(ctx, id, 0, 1);
+    if (st) { fprintf(stderr, "tmx_comm_create: %s -- %s\n", tmx_status_str(st), tmx_last_error(ctx)); return 1; }
+    uint32_t rank = 9, world = 9;
+    tmx_comm_info(ctx, &rank, &world);
+    uint64_t lo = 9, hi = 9;
+    tmx_shard_range(n, rank, world, &lo, &hi);
+    const uint64_t stride = tmx_elem_stride(TMX_KIND_SKIP, n);
+    void *d_p = 0, *d_t = 0, *d_r = 0, *d_o = 0, *d_o2 = 0, *d_rep = 0;
+    hipStream_t s = 0;
+    if (hipStreamCreate(&s) || hipMalloc(&d_p, sizeof in.proof) || hipMalloc(&d_t, n * sizeof *in.tg) || hipMalloc(&d_r, n * sizeof *in.tr) ||
+        hipMalloc(&d_o, stride * 8) || hipMalloc(&d_o2, stride * 8) || hipMalloc(&d_rep, sizeof rep)) { fprintf(stderr, "hipMalloc failed\n"); return 1; }
+    hipMemcpy(d_p, &in.proof, sizeof in.proof, hipMemcpyHostToDevice);
+    hipMemcpy(d_t, in.tg, n * sizeof *in.tg, hipMemcpyHostToDevice);
+    hipMemcpy(d_r, in.tr, n * sizeof *in.tr, hipMemcpyHostToDevice);
+    st = tmx_witness_validator_sharded_device(ctx, TMX_KIND_SKIP, 1, d_p, d_t, d_r, d_o, d_rep, s);
+    if (st) { fprintf(stderr, "tmx_witness_validator_sharded_device: %s -- %s\n", tmx_status_str(st), tmx_last_error(ctx)); return 1; }
+    st = tmx_witness_batch_sharded_device(ctx, TMX_KIND_SKIP, 1, d_p, d_t, d_r, d_o2, d_rep, 1, s);
+    if (st) { fprintf(stderr, "tmx_witness_batch_sharded_device: %s -- %s\n", tmx_status_str(st), tmx_last_error(ctx)); return 1; }
+    if (hipStreamSynchronize(s)) { fprintf(stderr, "stream failed\n"); return 1; }
+    uint64_t *a = (uint64_t*)malloc(count * 8), *b = (uint64_t*)malloc(count * 8);
+    hipMemcpy(a, d_o, count * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(b, d_o2, count * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(&rep, d_rep, sizeof rep, hipMemcpyDeviceToHost);
+    print_report(&rep, count);
+    printf("rank %u world %u shard_lo %llu shard_hi %llu rows_equal %d\n", rank, world, (unsigned long long)lo, (unsigned long long)hi, memcmp(a, b, count * 8) == 0);
+    dump(out, a, count * 8);
+    st = tmx_comm_destroy(ctx);
+    tmx_ctx_destroy(ctx);
+    return st ? 1 : (memcmp(a, b, count * 8) == 0 ? 0 : 1);
   }
   fprintf(stderr, "unknown mode %s\n", mode);
   return 2;

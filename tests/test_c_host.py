@@ -21,7 +21,7 @@ def host(built_lib, tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("c_host") / "witness_host")
     libdir = os.path.join(ROOT, "tendermintx_amd")
     subprocess.check_call(["gcc", "-O1", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "c_host", "witness_host.c"), "-I" + os.path.join(ROOT, "include"),
-                           "-L" + libdir, "-ltmx", "-L/opt/rocm/lib", "-lamdhip64", "-lstdc++", "-lpthread", "-Wl,-rpath," + libdir + ":/opt/rocm/lib"])
+                           "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L" + libdir, "-ltmx", "-L/opt/rocm/lib", "-lamdhip64", "-lstdc++", "-lpthread", "-Wl,-rpath," + libdir + ":/opt/rocm/lib"])
     return exe
 
 
@@ -86,5 +86,21 @@ def test_two_host_threads_two_contexts(host, oracle, cases, tmp_path):
     r = subprocess.run([host, "threads", FX, "32", "mocha-4", out, "10000", c["proof"][32:96], "10500", "40"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     print(r.stdout.strip())          # mismatch counts, ms per call alone and with both threads running (-s shows it; DESIGN.md quotes it)
+    want, _ = _oracle_row(oracle, c)
+    assert np.array_equal(np.fromfile(out, dtype=np.uint64), want)
+
+
+def test_sharded_entry_points_from_c_host(host, oracle, cases, tmp_path):
+    """tmx_comm_unique_id -> tmx_comm_create -> tmx_witness_validator_sharded_device / tmx_witness_batch_sharded_device from compiled C with
+    device buffers of its own: the exchange runs through a real (one-rank) RCCL communicator that libtmx dlopens -- the program does not
+    link librccl -- and the row equals the oracle's (the Rust shim binds exactly these calls: rust-shim/gpu.rs.example)"""
+    c = cases["skip_10000_10500_n32"]
+    out = str(tmp_path / "row.bin")
+    r = subprocess.run([host, "sharded", FX, "32", "mocha-4", out, "10000", c["proof"][32:96], "10500"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.split("\n") if ln.startswith(("header ", "all_ok ", "rank "))]   # (RCCL prints a version banner of its own)
+    assert lines[0] == "header " + c["header"]
+    f = _fields(lines[2])
+    assert (f["rank"], f["world"], f["shard_lo"], f["shard_hi"], f["rows_equal"]) == ("0", "1", "0", "32", "1")
     want, _ = _oracle_row(oracle, c)
     assert np.array_equal(np.fromfile(out, dtype=np.uint64), want)

@@ -540,31 +540,44 @@ def test_device_path_flags_nb_above_n(tmx, oracle):
     assert [r["precond"] for r in oreps] == [0, 1, 2] and all(r["all_ok"] for r in oreps)   # in-circuit: all enabled, same verdict
 
 
-def test_validator_sharded_single_proof(tmx, oracle):
-    """BASELINE config 5 path (lanes sharded, one all-gather of the EdDSA lane records, replicated finish) on the ranks
-    available here (world_size 1 over RCCL); the 2-rank exchange logic is covered on CPU by tests/test_sharding_gloo.py."""
+def test_sharded_entry_points_through_rccl(tmx, oracle):
+    """BASELINE configs[3] / [4] through the C entry points (tmx_witness_batch_sharded_device, tmx_witness_validator_sharded_device) on the
+    ranks available here: ONE, with a real RCCL communicator (tmx_comm_unique_id + tmx_comm_create with an id), so the grouped exchange is
+    RCCL's; two ranks: tests/test_multi_gpu.py (needs two GPUs), the partition / reassembly rule on CPU: tests/test_sharding_gloo.py."""
     import torch
-    import torch.distributed as dist
     from tendermintx_amd import sharding
     from tendermintx_amd.synth import Workload
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    try:
-        n = 512
-        wl = Workload(0, n, 1, 400, chain_id=b"celestia", seed=2024, signed_permille=900)
+    # ---- validator-sharded: one proof at N = 512 (configs[4]), then three proofs at N = 32
+    for n, P, nb in ((512, 1, 400), (32, 3, 29)):
+        wl = Workload(0, n, P, nb, chain_id=b"celestia", seed=2024 + n, signed_permille=900)
         d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) for b in (wl.proofs, wl.targets, wl.trusteds)]
-        with tmx.Context(n, b"celestia", max_batch=1) as ctx:
-            elems, rep = sharding.validator_sharded_skip(ctx, 0, d[0], d[1], d[2])
+        with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+            assert ctx.comm_info() == (0, 1)
+            ctx.comm_create(sharding.unique_id(), 0, 1)
+            elems, rep = sharding.validator_sharded_skip(ctx, 0, d[0], d[1], d[2], n_proofs=P)
             torch.cuda.synchronize(dev)
-            got = elems.cpu().numpy().view(np.uint64)
-        want, orep = oracle.witness(0, wl.proofs, wl.targets, wl.trusteds, b"celestia", 100800)
-        assert np.array_equal(got, want) and orep["all_ok"]
-        assert bytes(rep.cpu().numpy()[:32]) == orep["header"]
-    finally:
-        dist.destroy_process_group()
+            got = elems.cpu().numpy().view(np.uint64).reshape(P, -1)[:, :ctx.elem_count(0)]
+            ctx.comm_destroy()
+            assert ctx.comm_info() == (0, 1)
+        want, oreps = oracle.witness_batch(0, P, wl.proofs, wl.targets, wl.trusteds, n, b"celestia", 100800)
+        assert np.array_equal(got, want) and all(r["all_ok"] for r in oreps)
+        assert bytes(rep.cpu().numpy()[:32]) == oreps[0]["header"]
+    # ---- proof-sharded with the row exchange
+    n, P = 16, 7
+    wl = Workload(0, n, P, 13, chain_id=b"celestia", seed=77, signed_permille=900)
+    d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) for b in (wl.proofs, wl.targets, wl.trusteds)]
+    with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+        ctx.comm_create(sharding.unique_id(), 0, 1)
+        out = torch.zeros((P, ctx.elem_stride(0)), dtype=torch.int64, device=dev)
+        rep = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
+        sharding.proof_sharded_batch(ctx, 0, P, d[0], d[1], d[2], out, rep, gather=True)
+        torch.cuda.synchronize(dev)
+        want, _ = oracle.witness_batch(0, P, wl.proofs, wl.targets, wl.trusteds, n, b"celestia", 100800)
+        assert np.array_equal(out[:, :ctx.elem_count(0)].cpu().numpy().view(np.uint64), want)
+        with pytest.raises(tmx.TmxError):
+            ctx.comm_create(None, 0, 2)          # a world of two needs the id
 
 
 KNOBS = [

@@ -27,27 +27,34 @@ def _worker(rank, world, port, q):
         import tendermintx_amd as tmx
         from tendermintx_amd import sharding
         from tendermintx_amd.synth import Workload
-        # ---- BASELINE configs[3]: one batch sharded over the ranks, rows all-gathered (RCCL), bit-exact vs the oracle on every rank
+        # ---- BASELINE configs[3]: one batch sharded over the ranks through the C entry point (tmx_witness_batch_sharded_device: slices in
+        # place, one grouped RCCL exchange), bit-exact vs the oracle on every rank
         n, P = 32, 11
         wl = Workload(0, n, P, 29, chain_id=b"celestia", seed=4321, signed_permille=900)
+        d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) for b in (wl.proofs, wl.targets, wl.trusteds)]
         lo, hi = sharding.shard_range(P, rank, world)
-        d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
-             for b in (wl.proofs[lo * 2336:hi * 2336], wl.targets[lo * n * 256:hi * n * 256], wl.trusteds[lo * n * 48:hi * n * 48])]
         with tmx.Context(n, b"celestia", device=rank, max_batch=hi - lo) as ctx:
-            out = torch.zeros((hi - lo, ctx.elem_stride(0)), dtype=torch.int64, device=dev)
-            rep = torch.zeros((hi - lo) * 64, dtype=torch.uint8, device=dev)
-            ctx.witness_batch_device(0, hi - lo, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), out.data_ptr(), rep.data_ptr(),
-                                     torch.cuda.current_stream(dev).cuda_stream)
-            full = sharding.gather_rows(out, P)
+            assert sharding.connect(ctx) == (rank, world) and ctx.comm_info() == (rank, world)
+            out = torch.zeros((P, ctx.elem_stride(0)), dtype=torch.int64, device=dev)
+            rep = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
+            sharding.proof_sharded_batch(ctx, 0, P, d[0], d[1], d[2], out, rep, gather=True)
             torch.cuda.synchronize(dev)
             count = ctx.elem_count(0)
-        want, _ = oc.witness_batch(0, P, wl.proofs, wl.targets, wl.trusteds, n, b"celestia", 100800, n_threads=4)
-        assert np.array_equal(full[:, :count].cpu().numpy().view(np.uint64), want)
-        # ---- BASELINE configs[4]: one proof, validator lanes sharded, one all-gather of the EdDSA lane records
+            want, oreps = oc.witness_batch(0, P, wl.proofs, wl.targets, wl.trusteds, n, b"celestia", 100800, n_threads=4)
+            assert np.array_equal(out[:, :count].cpu().numpy().view(np.uint64), want)
+            assert [bool(rep.cpu().numpy()[64 * p + 32]) for p in range(P)] == [bool(r["all_ok"]) for r in oreps]
+            # without the gather only this rank's rows are written
+            out.zero_()
+            sharding.proof_sharded_batch(ctx, 0, P, d[0], d[1], d[2], out, rep, gather=False)
+            torch.cuda.synchronize(dev)
+            got = out[:, :count].cpu().numpy().view(np.uint64)
+            assert np.array_equal(got[lo:hi], want[lo:hi]) and not got[:lo].any() and not got[hi:].any()
+        # ---- BASELINE configs[4]: one proof, validator lanes sharded, one exchange of the EdDSA lane records (tmx_witness_validator_sharded_device)
         n = 64
         wl = Workload(0, n, 1, 50, chain_id=b"celestia", seed=99, signed_permille=900)
         d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) for b in (wl.proofs, wl.targets, wl.trusteds)]
         with tmx.Context(n, b"celestia", device=rank, max_batch=1) as ctx:
+            sharding.connect(ctx)
             elems, rep = sharding.validator_sharded_skip(ctx, 0, d[0], d[1], d[2])
             torch.cuda.synchronize(dev)
             got = elems.cpu().numpy().view(np.uint64)
