@@ -274,6 +274,24 @@ uint64_t tmx_trace_elem_count(int32_t kind, uint32_t n_max);
 int32_t tmx_trace_rows_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const void* d_targets, const void* d_trusteds, void* d_trace_out,
                               uint32_t sections, void* hip_stream);
 
+/* ---- the commit pipeline on the device: what the reference's `prove` does with the trace in ONE process -- witness ->
+ * trace -> low-degree extension -> Merkle commit (reference circuits/skip.rs:119-133, through plonky2x / starkyx / plonky2, absent here) --
+ * chained on the GPU so that only the cap leaves it: the rows of ONE section of every proof of the batch (d_trace_rows: what
+ * tmx_trace_rows_device wrote; row-major, tmx_trace_elem_count() elements per proof) become n_proofs * width columns of 2^log_rows
+ * elements (zero rows behind a proof's own; a tiled transpose), every column is extended to the coset shift <omega_(2^log_rows << log_blowup)>
+ * (tmx_lde_goldilocks_device), and the Merkle tree over the extended rows (leaf = row across ALL columns of the batch, hash_no_pad; inner
+ * nodes two_to_one: tmx_poseidon_merkle_device) is reduced to its cap: d_cap receives 4 << cap_height u64.
+ * section: ONE of TMX_TRACE_LADDERS / SHA512 / SHA256 / TREE / HEADER (the N x N match bits are not a row table).
+ * Same caveats as its stages: own row layout, natural (not bit-reversed) row order, no salt, Poseidon constants as set on the context --
+ * parity is pinned against the CPU chain under oracle/c (tmxo_trace -> tmxo_ntt -> tmxo_poseidon), not against plonky2.
+ * Scratch (columns, extended columns, tree levels) is owned by the context and grows on demand: (1 + 3 * 2^log_blowup) * n_proofs * width *
+ * 2^log_rows * 8 B -- 30 GB for the SHA-512 section of 256 proofs at N = 128, 8 x blow-up.  Asynchronous on hip_stream. */
+int32_t tmx_trace_commit_shape(int32_t kind, uint32_t n_max, uint32_t section, uint32_t* log_rows, uint32_t* width);
+int32_t tmx_trace_commit_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, uint32_t section, uint32_t log_blowup, uint32_t cap_height,
+                                const void* d_trace_rows, uint64_t* d_cap, void* hip_stream);
+/* HIP-event times (ms) of the stages of the LAST tmx_trace_commit_device: columns, LDE, Merkle; blocks until they finished */
+int32_t tmx_trace_commit_last_ms(tmx_ctx* ctx, float ms[3]);
+
 /* ---- per-lane Level-1 EdDSA values only (unit-test / profiling hook of the dominant kernel).
  * d_out: 448 B per lane = digest[64] | h[32] | A.x A.y R.x R.y sB.x sB.y hA.x hA.y sum.x sum.y [10][32] | ok u32 |
  * decode_ok u32 | pad.  Host variant copies in/out. */

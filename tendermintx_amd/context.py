@@ -198,6 +198,20 @@ class Context:
         check(self._L.tmx_finish_batch_device(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_ed, d_out, d_reports, self._stream(stream)),
               self._h)
 
+    # ---- the commit pipeline on the device: section rows -> columns -> LDE -> Poseidon Merkle cap
+    def trace_commit_shape(self, kind, section):
+        lg, w = C.c_uint32(), C.c_uint32()
+        check(self._L.tmx_trace_commit_shape(kind, self.n_max, section, C.byref(lg), C.byref(w)), self._h)
+        return lg.value, w.value
+
+    def trace_commit_device(self, kind, n_proofs, section, log_blowup, cap_height, d_trace_rows, d_cap, stream=None):
+        check(self._L.tmx_trace_commit_device(self._h, kind, n_proofs, section, log_blowup, cap_height, d_trace_rows, d_cap, self._stream(stream)), self._h)
+
+    def trace_commit_last_ms(self):
+        ms = (C.c_float * 3)()
+        check(self._L.tmx_trace_commit_last_ms(self._h, ms), self._h)
+        return {"columns": ms[0], "lde": ms[1], "merkle": ms[2]}
+
     # ---- multi-GPU: the RCCL exchange behind the C ABI (include/tmx.h "multi-GPU")
     def comm_create(self, unique_id, rank, world):
         check(self._L.tmx_comm_create(self._h, bytes(unique_id) if unique_id is not None else None, rank, world), self._h)

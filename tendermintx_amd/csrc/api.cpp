@@ -310,6 +310,9 @@ struct tmx_ctx {
   hipStream_t side3 = nullptr;  // early serialization of the input-only sections
   hipEvent_t ev_join3 = nullptr;
   uint32_t parity = 0;  // which of the two counter sets this launch uses
+  void* d_commit = nullptr;    // scratch of tmx_trace_commit_device: columns | extended columns | tree levels (grows on demand)
+  size_t commit_bytes = 0;
+  hipEvent_t ev_commit[4] = {};
   void* comm = nullptr;        // ncclComm_t of this context's device (tmx_comm_create), or null
   uint32_t comm_rank = 0, comm_world = 1;
   void* d_tiny = nullptr;      // counters of the small-launch path (kernels.h: tiny_counter_words), zero between launches
@@ -944,7 +947,7 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   }
   void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_owner_of, c->d_slot_of_owner, c->d_slot_of_uid, c->d_owners, c->d_keyrec,
                   c->d_anchors, c->d_keytab, c->kc.d_hash, c->kc.d_pk, c->kc.d_used, c->kc.d_free, c->kc.d_state, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
-                  c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out, c->d_pack, c->d_trace_tmp, c->d_tiny, c->d_shadow};
+                  c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out, c->d_pack, c->d_trace_tmp, c->d_tiny, c->d_shadow, c->d_commit};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (void* w : c->d_ntt_w)
@@ -974,6 +977,8 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   for (hipEvent_t e : c->ev_trace)
     if (e) (void)hipEventDestroy(e);
   if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+  for (hipEvent_t e : c->ev_commit)
+    if (e) (void)hipEventDestroy(e);
   if (c->have_streams) release_streams(c->cfg.device);
   delete c;
 }
@@ -1963,6 +1968,79 @@ int32_t tmx_witness_validator_sharded_device(tmx_ctx* c, int32_t kind, uint32_t 
   }
   if ((st = exchange_slices(c, ed, lanes, ED_STRIDE, reinterpret_cast<hipStream_t>(hip_stream)))) return st;
   return tmx_finish_batch_device(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, ed, d_out_elems, d_reports, hip_stream);
+}
+
+}  // extern "C"
+
+// ---- the commit pipeline on the device: section rows -> columns -> LDE -> Poseidon Merkle cap (include/tmx.h) ---------------------------
+extern "C" {
+
+int32_t tmx_trace_commit_shape(int32_t kind, uint32_t n, uint32_t section, uint32_t* log_rows, uint32_t* width) {
+  if ((kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP) || n == 0 || n > TMX_N_MAX_LIMIT) return TMX_ERR_BAD_ARG;
+  uint64_t off, rows;
+  uint32_t w;
+  if (!trace_section_geom((uint32_t)kind, n, section, &off, &rows, &w)) return TMX_ERR_BAD_ARG;
+  uint32_t lg = 6;  // (the transpose moves 64 rows per workgroup)
+  while (((uint64_t)1 << lg) < rows) lg++;
+  if (log_rows) *log_rows = lg;
+  if (width) *width = w;
+  return TMX_OK;
+}
+
+int32_t tmx_trace_commit_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, uint32_t section, uint32_t log_blowup, uint32_t cap_height,
+                                const void* d_trace_rows, uint64_t* d_cap, void* hip_stream) {
+  if (!c || !d_trace_rows || !d_cap || n_proofs == 0) return TMX_ERR_BAD_ARG;
+  uint32_t log_n = 0, width = 0;
+  if (tmx_trace_commit_shape(kind, c->cfg.n_max, section, &log_n, &width)) return fail(c, TMX_ERR_BAD_ARG, "section must be one row table of the trace block");
+  const uint32_t log_m = log_n + log_blowup;
+  if (log_m > TMX_NTT_MAX_LOG) return fail(c, TMX_ERR_CAPACITY, "log_rows + log_blowup exceeds TMX_NTT_MAX_LOG");
+  if (cap_height > log_m) return fail(c, TMX_ERR_BAD_ARG, "cap_height exceeds the height of the tree");
+  const uint64_t n_cols64 = (uint64_t)n_proofs * width;
+  if (n_cols64 > 0xffffffffull) return fail(c, TMX_ERR_CAPACITY, "too many columns");
+  const uint32_t n_cols = (uint32_t)n_cols64;
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  uint64_t off, rows;
+  uint32_t w;
+  (void)trace_section_geom((uint32_t)kind, c->cfg.n_max, section, &off, &rows, &w);
+  const size_t cols_b = ((size_t)n_cols << log_n) * 8, lde_b = ((size_t)n_cols << log_m) * 8;
+  const size_t lev_b = (size_t)tmx_poseidon_merkle_digests(log_m, cap_height) * 32, want = cols_b + lde_b + lev_b;
+  HIPCK(c, hipSetDevice(c->cfg.device));
+  if (c->commit_bytes < want) {
+    if (c->d_commit) { HIPCK(c, hipStreamSynchronize(s)); HIPCK(c, hipFree(c->d_commit)); c->d_commit = nullptr; c->commit_bytes = 0; }
+    size_t free_b = 0, total_b = 0;
+    // (the LDE's own scratch is twice the extended columns again: refuse what cannot fit instead of driving the device out of memory)
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want + 2 * lde_b > free_b + c->ntt_tmp_bytes)
+      return fail(c, TMX_ERR_CAPACITY, "commit pipeline needs " + std::to_string((want + 2 * lde_b) >> 20) + " MiB of scratch, " + std::to_string(free_b >> 20) + " MiB free");
+    HIPCK(c, hipMalloc(&c->d_commit, want));
+    c->commit_bytes = want;
+  }
+  for (auto& e : c->ev_commit)
+    if (!e) HIPCK(c, hipEventCreate(&e));
+  uint8_t* base = reinterpret_cast<uint8_t*>(c->d_commit);
+  uint64_t* cols = reinterpret_cast<uint64_t*>(base);
+  uint64_t* lde = reinterpret_cast<uint64_t*>(base + cols_b);
+  uint64_t* levels = reinterpret_cast<uint64_t*>(base + cols_b + lde_b);
+  HIPCK(c, hipEventRecord(c->ev_commit[0], s));
+  int rc = launch_trace_to_columns(d_trace_rows, trace_elems((uint32_t)kind, c->cfg.n_max), off, rows, width, log_n, n_proofs, cols, s);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_trace_to_columns launch: ") + hipGetErrorString((hipError_t)rc));
+  HIPCK(c, hipEventRecord(c->ev_commit[1], s));
+  int32_t st = tmx_lde_goldilocks_device(c, log_n, log_blowup, n_cols, cols, lde, hip_stream);
+  if (st) return st;
+  HIPCK(c, hipEventRecord(c->ev_commit[2], s));
+  st = tmx_poseidon_merkle_device(c, log_m, n_cols, lde, cap_height, levels, hip_stream);
+  if (st) return st;
+  const uint64_t n_dig = tmx_poseidon_merkle_digests(log_m, cap_height), n_cap = (uint64_t)1 << cap_height;
+  HIPCK(c, hipMemcpyAsync(d_cap, levels + 4 * (n_dig - n_cap), n_cap * 32, hipMemcpyDeviceToDevice, s));
+  HIPCK(c, hipEventRecord(c->ev_commit[3], s));
+  return TMX_OK;
+}
+
+int32_t tmx_trace_commit_last_ms(tmx_ctx* c, float ms[3]) {
+  if (!c || !ms) return TMX_ERR_BAD_ARG;
+  if (!c->ev_commit[3]) return fail(c, TMX_ERR_BAD_ARG, "no tmx_trace_commit_device call yet");
+  HIPCK(c, hipEventSynchronize(c->ev_commit[3]));
+  for (int k = 0; k < 3; k++) HIPCK(c, hipEventElapsedTime(&ms[k], c->ev_commit[k], c->ev_commit[k + 1]));
+  return TMX_OK;
 }
 
 }  // extern "C"

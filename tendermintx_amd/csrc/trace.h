@@ -26,4 +26,9 @@ struct TraceLevel1 {
 int launch_trace_rest(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_trusted, const TraceLevel1& L1, void* d_out,
                       uint32_t sections, void* stream);
 
+// the commit pipeline's first stage (api.cpp: tmx_trace_commit_device): one section as a row-major matrix, and its columns for the LDE
+bool trace_section_geom(uint32_t kind, uint32_t n, uint32_t section, uint64_t* off, uint64_t* rows, uint32_t* width);
+int launch_trace_to_columns(const void* d_trace, uint64_t proof_stride, uint64_t sec_off, uint64_t rows, uint32_t width, uint32_t log_n, uint32_t n_proofs,
+                            void* d_cols, void* stream);
+
 }  // namespace tmx

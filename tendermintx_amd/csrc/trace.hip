@@ -539,6 +539,50 @@ static uint64_t trace_off_tree(uint32_t kind, uint32_t n) {
   const uint64_t sets = kind == 0 ? 2 : 1;
   return (uint64_t)n * (2ull * TR_LADDER_ROWS * TR_LADDER_ROW + 2ull * 80 * TR_SHA512_ROW + sets * 64 * TR_SHA256_ROW) + (kind == 0 ? (uint64_t)n * n : 0);
 }
+// one section of a proof's trace block as a row-major matrix: offset, rows, row width (elements).  The N x N match bits have no row
+// structure of their own (false: not a committed table).
+bool trace_section_geom(uint32_t kind, uint32_t n, uint32_t section, uint64_t* off, uint64_t* rows, uint32_t* width) {
+  const uint64_t sets = kind == 0 ? 2 : 1, tn = tree_slots(n);
+  const uint64_t o_sha512 = (uint64_t)n * 2ull * TR_LADDER_ROWS * TR_LADDER_ROW, o_sha256 = o_sha512 + (uint64_t)n * 2ull * 80 * TR_SHA512_ROW;
+  switch (section) {
+    case 1u: *off = 0; *rows = 2ull * n * TR_LADDER_ROWS; *width = TR_LADDER_ROW; return true;
+    case 2u: *off = o_sha512; *rows = 2ull * n * 80; *width = TR_SHA512_ROW; return true;
+    case 4u: *off = o_sha256; *rows = sets * n * 64; *width = TR_SHA256_ROW; return true;
+    case 16u: *off = trace_off_tree(kind, n); *rows = sets * tn * 128; *width = TR_SHA256_ROW; return tn != 0;
+    case 32u: *off = trace_off_tree(kind, n) + sets * tn * TR_SHA256_2; *rows = (kind == 0 ? 4ull : 5ull) * 5 * 128; *width = TR_SHA256_ROW; return true;
+    default: return false;
+  }
+}
+
+// Row-major rows of one section of every proof -> column-major columns for the LDE: column (p, c) = element c of every row of proof p,
+// zero-padded to 2^log_n rows, at cols[(p * width + c) << log_n].  A workgroup moves 64 rows: one coalesced read of 64 * width
+// consecutive elements, staged in LDS, width runs of 64 consecutive elements (512 B) out.
+__global__ __launch_bounds__(256) void k_trace_to_columns(const uint64_t* __restrict__ trace, uint64_t proof_stride, uint64_t sec_off, uint64_t rows,
+                                                          uint32_t width, uint32_t log_n, uint64_t* __restrict__ cols) {
+  extern __shared__ uint64_t s_tile[];  // [width][65] (one pad word per column: conflict-free column reads)
+  const uint32_t p = blockIdx.y, t = threadIdx.x;
+  const uint64_t r0 = (uint64_t)blockIdx.x * 64;
+  const uint64_t* src = trace + (size_t)p * proof_stride + sec_off + r0 * width;
+  const uint32_t n_el = 64 * width;
+  for (uint32_t e = t; e < n_el; e += 256) {
+    const uint32_t r = e / width, c = e - r * width;
+    s_tile[c * 65 + r] = r0 + r < rows ? src[e] : 0ull;
+  }
+  __syncthreads();
+  uint64_t* dst = cols + (((size_t)p * width) << log_n) + r0;
+  for (uint32_t e = t; e < n_el; e += 256) {
+    const uint32_t c = e >> 6, r = e & 63u;
+    dst[((size_t)c << log_n) + r] = s_tile[c * 65 + r];
+  }
+}
+int launch_trace_to_columns(const void* d_trace, uint64_t proof_stride, uint64_t sec_off, uint64_t rows, uint32_t width, uint32_t log_n, uint32_t n_proofs,
+                            void* d_cols, void* stream) {
+  if (n_proofs == 0) return 0;
+  hipLaunchKernelGGL(k_trace_to_columns, dim3((uint32_t)(((uint64_t)1 << log_n) / 64), n_proofs), dim3(256), (size_t)width * 65 * 8, S_(stream),
+                     reinterpret_cast<const uint64_t*>(d_trace), proof_stride, sec_off, rows, width, log_n, reinterpret_cast<uint64_t*>(d_cols));
+  return (int)hipGetLastError();
+}
+
 uint64_t trace_elems(uint32_t kind, uint32_t n) {
   return trace_off_tree(kind, n) + ((kind == 0 ? 2ull : 1ull) * tree_slots(n) + (kind == 0 ? 4ull : 5ull) * 5) * TR_SHA256_2;
 }
