@@ -141,8 +141,14 @@ def main():
         d_p, d_t, d_r = dev_bytes(wl.proofs), dev_bytes(wl.targets), dev_bytes(wl.trusteds)
         ctx = Context(n, b"celestia", 100800, device=local_rank, max_batch=1)
 
+        if world == 1:   # a real one-rank RCCL communicator, so that the exchange runs through RCCL on a 1-GPU box too
+            ctx.comm_create(sharding.unique_id(), 0, 1)
+            comm_world = 1
+        else:            # the 128-byte id travels through torch.distributed once; the data path is libtmx's own communicator
+            comm_world = sharding.connect(ctx)[1]
+
         def step():
-            return sharding.validator_sharded_skip(ctx, KIND_SKIP, d_p, d_t, d_r)
+            return sharding.validator_sharded_skip(ctx, KIND_SKIP, d_p, d_t, d_r)   # tmx_witness_validator_sharded_device
 
         for _ in range(args.warmup):
             step()
@@ -152,17 +158,7 @@ def main():
             elems, rep = step()
         barrier()
         ms_per_step = 1e3 * max_over_ranks(time.perf_counter() - t0) / args.steps
-        # the exchange alone: all-gather of the padded 448-byte lane records
-        lo, hi = sharding.shard_range(n, rank, world)
-        local = torch.zeros((hi - lo, 448), dtype=torch.uint8, device=dev)
-        for _ in range(5):
-            sharding.gather_rows(local, n)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            sharding.gather_rows(local, n)
-        barrier()
-        gather_ms = 1e3 * max_over_ranks(time.perf_counter() - t0) / args.steps
+        gather_ms = None
         ok = int(rep.cpu().numpy()[32:36].view(np.uint32)[0])
         if rank == 0:
             out_bytes = ctx.elem_stride(KIND_SKIP) * 8
@@ -173,7 +169,8 @@ def main():
                 "config": {"workload": f"BASELINE configs[4]: SkipCircuit VALIDATOR_SET_SIZE_MAX={n}, ONE proof, {wl.nb} validators, lanes sharded over "
                                        f"{world} GPU(s), one all-gather of {n} x 448 B EdDSA lane records, finish replicated on every rank",
                            "n_max": n, "parallelism": f"validator-sharded x{world}"},
-                "all_gather_ms": round(gather_ms, 5), "all_proofs_ok": bool(ok),
+                "rccl": {"torch_world": world, "libtmx_comm_world": comm_world, "entry_point": "tmx_witness_validator_sharded_device"},
+                "all_proofs_ok": bool(ok),
                 "roofline": {"kernel": "step", "bound": "hbm", "achieved": round(gbs(out_bytes, ms_per_step), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(gbs(out_bytes, ms_per_step) / HBM_PEAK_GBS, 5), "traffic": None,
                              "note": "a single proof is latency-bound (dependent EdDSA chain), not bandwidth-bound: DESIGN.md section 6"}}), flush=True)
@@ -193,17 +190,16 @@ def main():
     P = hi - lo
     seed = 0x544D58 + (rank if args.scaling == "weak" else 0)
     wl_all = bench_workload(args.workload, n, P_total if args.scaling == "strong" else P, seed=seed)
-    if args.scaling == "strong":  # every rank builds the same batch and keeps its slice
-        proofs, targets, trusteds = (wl_all.proofs[lo * 2336:hi * 2336], wl_all.targets[lo * n * 256:hi * n * 256],
-                                     wl_all.trusteds[lo * n * 48:hi * n * 48])
-    else:
-        proofs, targets, trusteds = wl_all.proofs, wl_all.targets, wl_all.trusteds
+    # (strong: every rank holds the whole batch and a full-size row buffer; tmx_witness_batch_sharded_device fills this rank's rows in place)
+    proofs, targets, trusteds = wl_all.proofs, wl_all.targets, wl_all.trusteds
     ctx = Context(n, b"celestia", 100800, device=local_rank, max_batch=max(P, 1))
     stride, count = ctx.elem_stride(KIND_SKIP), ctx.elem_count(KIND_SKIP)
     d_proofs, d_targets, d_trusteds = dev_bytes(proofs), dev_bytes(targets), dev_bytes(trusteds)
-    d_out = torch.empty((max(P, 1), stride), dtype=torch.int64, device=dev)
-    d_rep = torch.zeros(max(P, 1) * 64, dtype=torch.uint8, device=dev)
+    rows_buf = P_total if args.scaling == "strong" else max(P, 1)
+    d_out = torch.empty((rows_buf, stride), dtype=torch.int64, device=dev)
+    d_rep = torch.zeros(rows_buf * 64, dtype=torch.uint8, device=dev)
     gather = args.gather and world > 1
+    comm_world = sharding.connect(ctx)[1] if (use_dist and not share_gpu) else 1
 
     def run(c, k, bufs=None, n_proofs=None):
         dp, dt, dr = bufs or (d_proofs, d_targets, d_trusteds)
@@ -212,9 +208,10 @@ def main():
                                    d_rep.data_ptr(), stream.cuda_stream)
 
     def step():
-        run(ctx, 1)
-        if gather:
-            return sharding.gather_rows(d_out[:P], P_total)
+        if args.scaling == "strong" and comm_world > 1:
+            sharding.proof_sharded_batch(ctx, KIND_SKIP, P_total, d_proofs, d_targets, d_trusteds, d_out, d_rep, gather=gather, stream=stream.cuda_stream)
+        else:
+            run(ctx, 1)
 
     for _ in range(args.warmup):
         step()
@@ -230,18 +227,19 @@ def main():
     kc = ctx.key_cache_stats()
 
     gather_ms = None
-    if gather:
+    if gather:   # the same step without the exchange, for the difference
         for _ in range(3):
-            sharding.gather_rows(d_out[:P], P_total)
+            sharding.proof_sharded_batch(ctx, KIND_SKIP, P_total, d_proofs, d_targets, d_trusteds, d_out, d_rep, gather=False, stream=stream.cuda_stream)
         barrier()
         t0 = time.perf_counter()
         for _ in range(10):
-            sharding.gather_rows(d_out[:P], P_total)
+            sharding.proof_sharded_batch(ctx, KIND_SKIP, P_total, d_proofs, d_targets, d_trusteds, d_out, d_rep, gather=False, stream=stream.cuda_stream)
         barrier()
-        gather_ms = 1e3 * max_over_ranks(time.perf_counter() - t0) / 10
+        gather_ms = ms_per_step - 1e3 * max_over_ranks(time.perf_counter() - t0) / 10
 
     # every proof of this rank must have verified (synthetic inputs are well-formed)
-    rep = d_rep.cpu().numpy().reshape(-1, 64)[:P]
+    row0 = lo if (args.scaling == "strong" and comm_world > 1) else 0   # (strong: this rank's rows sit at their place in the full-size buffer)
+    rep = d_rep.cpu().numpy().reshape(-1, 64)[row0:row0 + P]
     all_ok = int(rep[:, 32:36].copy().view(np.uint32).sum())
     ok_flag = torch.tensor([1 if all_ok == P else 0], device="cpu" if share_gpu else dev)
     if world > 1:
@@ -277,7 +275,8 @@ def main():
         }
         if gather_ms is not None:
             result["gather_rows"] = {"ms": round(gather_ms, 4), "bytes_per_rank_out": P_total * stride * 8,
-                                     "note": "RCCL all-gather of the padded row blocks alone (10 repetitions), every rank ends with all rows"}
+                                     "note": "the step with the grouped RCCL exchange of the row slices (tmx_witness_batch_sharded_device, gather = 1) minus the "
+                                             "same step without it (10 repetitions): every rank ends with all rows"}
         roofline = {"kernel": "step", "kernel_note": "the whole launch sequence of one batch (EdDSA kernels, k_proof, k_serialize on four streams), "
                     "timed by HIP events on the caller's stream", "bound": "hbm", "achieved": round(gbs(alg_bytes, step_ms_events), 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(gbs(alg_bytes, step_ms_events) / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": alg_bytes,
@@ -286,14 +285,71 @@ def main():
                             "nothing on this path is a dense contraction (no MFMA)"}
         result["roofline"] = roofline
 
+        result["rccl"] = {"torch_world": world, "libtmx_comm_world": comm_world,
+                          "note": "the data-path exchange (strong scaling with --gather, --mode c5) is RCCL inside libtmx (tmx_comm_create); torch.distributed "
+                                  "carries the unique id, the barriers and the max over ranks"}
         if not args.no_extras and world == 1:
             extras(args, result, roofline, ctx, run, wl_all, n, P, stride, count, dev, stream, d_out, d_rep, dev_bytes, kms, ms_per_step, alg_bytes)
+    # ---- more than one GPU: the OTHER scaling of the same record (a SCALE run of the default command then carries both the weak-scaled value
+    # and BASELINE configs[3] as written: 256 proofs sharded over the ranks, without and with the row exchange)
+    if world > 1 and not args.no_extras and not share_gpu:
+        other = both_scalings(args, ctx if args.scaling == "strong" else None, n, world, rank, local_rank, dev, stream, dev_bytes, barrier, max_over_ranks)
+        if rank == 0:
+            result["other_scaling"] = other
+    if rank == 0:
         print(json.dumps(result), flush=True)
     barrier()
     if use_dist:
         dist.destroy_process_group()
     ctx.close()
     return 0
+
+
+def both_scalings(args, strong_ctx, n, world, rank, local_rank, dev, stream, dev_bytes, barrier, max_over_ranks):
+    """Run by EVERY rank after the timed region: the scaling mode the command line did not ask for, 20 steps after 5 warm-up.
+    strong = --proofs proofs in total over the ranks through tmx_witness_batch_sharded_device (gather off / on); weak = --proofs per rank."""
+    import torch
+    from tendermintx_amd import KIND_SKIP, Context, sharding
+    from tendermintx_amd.synth import bench_workload
+    out = {}
+
+    def timed(fn, k=20, w=5):
+        for _ in range(w):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        barrier()
+        return 1e3 * max_over_ranks(time.perf_counter() - t0) / k
+
+    if args.scaling == "weak":
+        Pt = args.proofs
+        wl = bench_workload(args.workload, n, Pt, seed=0x544D58)
+        lo, hi = sharding.shard_range(Pt, rank, world)
+        c = Context(n, b"celestia", 100800, device=local_rank, max_batch=max(hi - lo, 1))
+        cw = sharding.connect(c)[1]
+        d = [dev_bytes(b) for b in (wl.proofs, wl.targets, wl.trusteds)]
+        o = torch.empty((Pt, c.elem_stride(KIND_SKIP)), dtype=torch.int64, device=dev)
+        r = torch.zeros(Pt * 64, dtype=torch.uint8, device=dev)
+        for g in (False, True):
+            ms = timed(lambda: sharding.proof_sharded_batch(c, KIND_SKIP, Pt, d[0], d[1], d[2], o, r, gather=g, stream=stream.cuda_stream))
+            out["strong" + ("_with_row_exchange" if g else "")] = {"ms_per_step": round(ms, 4), "value": round(ms / Pt, 6), "proofs_total": Pt,
+                                                                  "proofs_per_gpu": hi - lo, "libtmx_comm_world": cw}
+        out["note"] = ("BASELINE configs[3] as written: ONE batch of --proofs proofs sharded over the ranks (tmx_witness_batch_sharded_device), without a "
+                       "data-path collective and with the grouped RCCL exchange that leaves every row on every rank; value = ms per proof")
+        c.close()
+    else:
+        Pw = args.proofs
+        wl = bench_workload(args.workload, n, Pw, seed=0x544D58 + rank)
+        c = Context(n, b"celestia", 100800, device=local_rank, max_batch=Pw)
+        d = [dev_bytes(b) for b in (wl.proofs, wl.targets, wl.trusteds)]
+        o = torch.empty((Pw, c.elem_stride(KIND_SKIP)), dtype=torch.int64, device=dev)
+        r = torch.zeros(Pw * 64, dtype=torch.uint8, device=dev)
+        ms = timed(lambda: c.witness_batch_device(KIND_SKIP, Pw, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), o.data_ptr(), r.data_ptr(), stream.cuda_stream))
+        out["weak"] = {"ms_per_step": round(ms, 4), "value": round(ms / (Pw * world), 6), "proofs_total": Pw * world, "proofs_per_gpu": Pw}
+        c.close()
+    return out
 
 
 def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, stream, d_out, d_rep, dev_bytes, kms, ms_per_step, alg_bytes):
@@ -368,6 +424,9 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
                               "row_bytes": stride * 8, "workload": "proof 0 of the batch above (BASELINE configs[2]); device_ms / host_to_host with the "
                               "proof's validator set resident in the key cache (warm), device_ms_cold after tmx_key_cache_flush"}
     result["latency_single_proof_ms"] = result["single_proof"]["device_ms"]
+    # SURVEY 8(d)'s own metric definition beside `value` (which is the device-resident, batch-amortised kernel-side figure)
+    result["value_single_proof_ms"] = result["single_proof"]["device_ms"]
+    result["value_single_proof_host_to_host_ms"] = result["single_proof"]["host_to_host_ms"]
 
     # ---- the batch, host to host (PCIe-bound; never `value`)
     hh = []
@@ -389,6 +448,7 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
         h2h["hint_only"] = {"ms_per_step": round(min(hq), 3), "ms_per_proof": round(min(hq) / P, 5), "bytes_over_pcie": hbh,
                             "note": "only the hint section H of every row (what SkipOffchainInputs::hint writes, skip.rs:85-100) leaves the device"}
     result["host_to_host"] = h2h
+    result["value_host_to_host_ms"] = h2h["ms_per_proof"]
     del pinned, host_out
 
     # ---- k_serialize on its own (the step spreads it over overlapped launches): a second context with the split disabled
@@ -411,6 +471,14 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
     result["dedup"]["without_key_tables"] = {"ms_per_step": round(timed(ctx0, 10), 4), "k_eddsa_ms": round(ctx0.kernel_ms_mean(10)["k_eddsa"], 4)}
     ctx0.close()
 
+    # ---- HBM traffic of the step measured IN THIS RUN when rocprofv3 is on PATH: two --pmc passes (FETCH_SIZE / WRITE_SIZE never fit one) over
+    # tools/profile_step.py, the same workload; the committed profile is replayed below only if this fails
+    measured_traffic = measure_traffic(n, P, args.workload)
+    if measured_traffic:
+        roofline["traffic"] = measured_traffic["bytes_per_step"]
+        roofline["traffic_source"] = measured_traffic["source"]
+        roofline["traffic_detail"] = measured_traffic
+
     # ---- PMC figures of the committed rocprofv3 passes (profiles/pmc_latest.json), only if they were taken on this configuration.
     # NOT measured by this run: replayed from the builder's profile collection, and marked as such in the line
     try:
@@ -418,8 +486,9 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
         if pmc["config"] == {"n_max": n, "proofs_per_gpu": P, "workload": args.workload}:
             src = "profiles/pmc_latest.json (rocprofv3 --pmc passes over tools/profile_step.py, collected by the builder; replayed, not measured in this run)"
             pk = {g: v for g, v in pmc["kernels"].items() if g != "setup"}   # (setup = the once-per-context table of B)
-            roofline["traffic"] = int(sum(pk[g].get("fetch_kb", 0) + pk[g].get("write_kb", 0) for g in pk) * 1024)
-            roofline["traffic_source"] = src
+            if not measured_traffic:
+                roofline["traffic"] = int(sum(pk[g].get("fetch_kb", 0) + pk[g].get("write_kb", 0) for g in pk) * 1024)
+                roofline["traffic_source"] = src
             roofline["k_serialize"]["traffic"] = int((pk["k_serialize"]["fetch_kb"] + pk["k_serialize"]["write_kb"]) * 1024)
             roofline["k_serialize"]["traffic_source"] = src
             try:
@@ -451,6 +520,70 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
                         "[every fast-class instruction co-issued at 2.3 cycles, none co-issued]; the EdDSA kernels move ~1 % of HBM peak: their roof is this one"}
     except (OSError, KeyError, ValueError):
         pass
+
+    # ---- key-cache churn: warm (0 new keys per step) and cold (all 401) are two points of a curve.  Step j replaces the first proofs of the batch
+    # by proofs over FRESH validator keys (a new seed per step), so that exactly `new` keys miss per step; host clock around one call.
+    try:
+        from tendermintx_amd.synth import Workload
+        churn = {}
+        for new_keys, reps in ((0, 12), (4, 12), (40, 12), (401, 8)):
+            xs = []
+            for j in range(reps):
+                if new_keys == 0:
+                    bufs = None
+                elif new_keys == 401:
+                    wj = bench_workload(args.workload, n, P, seed=0x600000 + 977 * j)
+                    bufs = tuple(dev_bytes(b) for b in (wj.proofs, wj.targets, wj.trusteds))
+                else:   # one proof with `new_keys` fresh validators (the lanes behind them carry the dummy key, resident since the warm-up)
+                    wj = Workload(0, n, 1, new_keys, chain_id=b"celestia", seed=0x700000 + 31 * j + new_keys, signed_permille=1000)
+                    bufs = tuple(dev_bytes(a + b[len(a):]) for a, b in ((wj.proofs, wl.proofs), (wj.targets, wl.targets), (wj.trusteds, wl.trusteds)))
+                run(ctx, 2)                     # (the base batch resident again, the schedule hint back to warm)
+                xs.append(timed(ctx, 1, bufs))
+                seen = ctx.key_cache_stats()["last_new_keys"]   # (a fresh batch brings 400: the dummy key of the unsigned lanes is resident)
+            churn[str(seen)] = round(median(xs), 4)
+        result["key_cache"]["churn"] = {"ms_per_step_by_new_keys": churn, "proofs": P,
+                                        "note": "one 256-proof step in which exactly that many of the batch's 401 distinct keys are new to the context's cache "
+                                                "(decoded, table built inside the step), the schedule hint saying warm; median of 8-12, host clock"}
+        run(ctx, 3)
+    except Exception as e:
+        result["key_cache"]["churn"] = {"error": repr(e)}
+
+    # ---- the commit pipeline on the device (reference circuits/skip.rs:119-133): section rows -> columns -> coset LDE x8 -> Poseidon
+    # Merkle cap, only the cap leaves the GPU.  The SHA sections of the whole batch (the ladder section's 70 GB of extended columns + scratch do
+    # not fit beside the bench's other buffers: timed at 32 proofs)
+    try:
+        from tendermintx_amd import _lib as _l
+        te = ctx.trace_elem_count(KIND_SKIP)
+        d_tr = torch.empty(P * te, dtype=torch.int64, device=dev)
+        bi = tuple(dev_bytes(b) for b in (wl.proofs, wl.targets, wl.trusteds))
+        run(ctx, 1, bi)
+        ctx.trace_rows_device(KIND_SKIP, P, bi[1].data_ptr(), bi[2].data_ptr(), d_tr.data_ptr(), _l.TRACE_ALL, stream.cuda_stream)
+        cap = torch.zeros(4 << 4, dtype=torch.int64, device=dev)
+        cp = {}
+        for name, sec, pp in (("sha512", _l.TRACE_SHA512, P), ("sha256_leaves", _l.TRACE_SHA256, P), ("tree", _l.TRACE_TREE, P), ("header", _l.TRACE_HEADER, P),
+                              ("ladders", _l.TRACE_LADDERS, min(P, 32))):
+            log_rows, width = ctx.trace_commit_shape(KIND_SKIP, sec)
+            for _ in range(2):
+                ctx.trace_commit_device(KIND_SKIP, pp, sec, 3, 4, d_tr.data_ptr(), cap.data_ptr(), stream.cuda_stream)
+            ms = ctx.trace_commit_last_ms()
+            cols = pp * width
+            col_b, lde_b = (cols << log_rows) * 8, (cols << (log_rows + 3)) * 8
+            perms = (1 << (log_rows + 3)) * ((cols + 7) // 8) + (1 << (log_rows + 3))
+            cp[name] = {"proofs": pp, "columns": cols, "log_rows": log_rows, "log_rows_extended": log_rows + 3,
+                        "ms": {k: round(v, 4) for k, v in ms.items()}, "ms_total": round(sum(ms.values()), 4),
+                        "columns_stage": {"bytes": 2 * col_b, "frac_of_hbm": round(gbs(2 * col_b, ms["columns"]) / HBM_PEAK_GBS, 4)},
+                        "lde_stage": {"bytes_one_read_one_write_per_pass": 2 * (2 * col_b) + 2 * (2 * lde_b) + 2 * lde_b,
+                                      "frac_of_hbm": round(gbs(4 * col_b + 6 * lde_b, ms["lde"]) / HBM_PEAK_GBS, 4)},
+                        "merkle_stage": {"permutations": perms, "gperm_per_s": round(perms / (ms["merkle"] * 1e-3) / 1e9, 3),
+                                         "bytes_read": lde_b, "frac_of_hbm": round(gbs(lde_b, ms["merkle"]) / HBM_PEAK_GBS, 4)},
+                        "cap0": [int(x) & (2**64 - 1) for x in cap[:4].cpu().numpy()]}
+        result["commit_pipeline"] = {"what": "tmx_trace_commit_device per section: rows of every proof -> n_proofs x width columns (tiled transpose) -> coset LDE, "
+                                             "blow-up 8 -> Poseidon Merkle tree over the extended rows (leaf = the row across all columns), cap of 16 digests; "
+                                             "HIP events between the stages; parity of the chain vs oracle/c: tests/test_commit_pipeline.py (Poseidon constants: the "
+                                             "context's, by default the Grain stream -- parity unpinned against plonky2)", "sections": cp}
+        del d_tr
+    except Exception as e:
+        result["commit_pipeline"] = {"error": repr(e)}
 
     # ---- Level-2 trace rows of the same batch: the writer of 266 KB of ladder rows per lane
     try:
@@ -527,6 +660,48 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
     ossl = openssl_verify_us(wl, n)
     if ossl is not None:
         result["cpu_baseline"]["openssl_evp_digestverify"] = ossl
+
+
+def measure_traffic(n, P, workload):
+    """HBM bytes of one warm step from rocprofv3's FETCH_SIZE / WRITE_SIZE (KB; memory-side request counters of the L2), each in a pass of
+    its own over tools/profile_step.py (2 warm + 6 counted batches).  Uncorrected sums, as MI355X_MICROARCH.md prescribes for access patterns
+    that are not wide coalesced reads (the reads here are 1- and 4-byte gathers; writes dominate).  None when rocprofv3 is not usable."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    if not shutil.which("rocprofv3") or os.environ.get("TMX_BENCH_NO_PMC") == "1":
+        return None
+    tot, per_kernel = {}, {}
+    warm, steps = 2, 6
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            env = dict(os.environ, TMPDIR="/tmp", P=str(P), N=str(n), WORKLOAD=workload, WARM=str(warm), STEPS=str(steps))
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(tmp, counter)
+                r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "step", "--", sys.executable,
+                                    os.path.join(ROOT, "tools", "profile_step.py")], cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+                dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+                if r.returncode != 0 or not dbs:
+                    return None
+                db = sqlite3.connect(dbs[0])
+                starts = sorted(x[0] for x in db.execute("select distinct dispatch_id from counters_collection where kernel_name like '%k_proof%'"))
+                if len(starts) != warm + steps:
+                    return None
+                first = starts[warm]
+                for name, value in db.execute("select kernel_name, sum(value) from counters_collection where counter_name = ? and dispatch_id >= ? "
+                                              "and kernel_name like '%tmx::%' and kernel_name not like '%k_init_base%' group by kernel_name", (counter, first)):
+                    tot[counter] = tot.get(counter, 0.0) + value / steps
+                    short = name.split("(")[0].replace("void ", "").replace("tmx::", "")
+                    per_kernel.setdefault(short, {})[counter] = round(value / steps * 1024)
+        if "FETCH_SIZE" not in tot or "WRITE_SIZE" not in tot:
+            return None
+        return {"bytes_per_step": int((tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024), "fetch_bytes": int(tot["FETCH_SIZE"] * 1024),
+                "write_bytes": int(tot["WRITE_SIZE"] * 1024), "per_kernel_bytes": per_kernel,
+                "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over tools/profile_step.py, "
+                          f"mean of {steps} warm batches"}
+    except Exception:
+        return None
 
 
 def usable_cores():

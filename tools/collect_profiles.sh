@@ -9,7 +9,7 @@ OUT=gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 tools/microbench/valu_isa > "$OUT/valu_isa.txt" 2>&1
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- python bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
+TMX_BENCH_NO_PMC=1 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- python bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
 rocprofv3 --kernel-trace -d "$OUT/trace_step" -o step -- python tools/profile_step.py > "$OUT/step_trace.log" 2>&1
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   name=$(echo $pass | tr ' ' '_' | tr 'A-Z' 'a-z')
