@@ -563,6 +563,11 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
         for name, sec, pp in (("sha512", _l.TRACE_SHA512, P), ("sha256_leaves", _l.TRACE_SHA256, P), ("tree", _l.TRACE_TREE, P), ("header", _l.TRACE_HEADER, P),
                               ("ladders", _l.TRACE_LADDERS, min(P, 32))):
             log_rows, width = ctx.trace_commit_shape(KIND_SKIP, sec)
+            tn_, sz_ = 0, n
+            while sz_ > 1:
+                sz_ = (sz_ + 1) // 2
+                tn_ += sz_
+            rows = {"sha512": 2 * n * 80, "sha256_leaves": 2 * n * 64, "tree": 2 * tn_ * 128, "header": 4 * 5 * 128, "ladders": 2 * n * 256}[name]
             for _ in range(2):
                 ctx.trace_commit_device(KIND_SKIP, pp, sec, 3, 4, d_tr.data_ptr(), cap.data_ptr(), stream.cuda_stream)
             ms = ctx.trace_commit_last_ms()
@@ -571,7 +576,9 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
             perms = (1 << (log_rows + 3)) * ((cols + 7) // 8) + (1 << (log_rows + 3))
             cp[name] = {"proofs": pp, "columns": cols, "log_rows": log_rows, "log_rows_extended": log_rows + 3,
                         "ms": {k: round(v, 4) for k, v in ms.items()}, "ms_total": round(sum(ms.values()), 4),
-                        "columns_stage": {"bytes": 2 * col_b, "frac_of_hbm": round(gbs(2 * col_b, ms["columns"]) / HBM_PEAK_GBS, 4)},
+                        "rows_per_proof": rows,
+                        "columns_stage": {"bytes": cols * rows * 8 + col_b, "frac_of_hbm": round(gbs(cols * rows * 8 + col_b, ms["columns"]) / HBM_PEAK_GBS, 4),
+                                          "note": "the section's own rows read once, the zero-padded columns written once"},
                         "lde_stage": {"bytes_one_read_one_write_per_pass": 2 * (2 * col_b) + 2 * (2 * lde_b) + 2 * lde_b,
                                       "frac_of_hbm": round(gbs(4 * col_b + 6 * lde_b, ms["lde"]) / HBM_PEAK_GBS, 4)},
                         "merkle_stage": {"permutations": perms, "gperm_per_s": round(perms / (ms["merkle"] * 1e-3) / 1e9, 3),
