@@ -369,6 +369,12 @@ int32_t tmx_lde_goldilocks_device(tmx_ctx* ctx, uint32_t log_n, uint32_t log_blo
  * then each level above them down to the cap (the last 2^cap_height digests). */
 int32_t tmx_poseidon_set_constants(tmx_ctx* ctx, const uint64_t* round_constants /*[360]*/, const uint64_t* mds_circ /*[12]*/,
                                    const uint64_t* mds_diag /*[12]*/);
+/* 1 once tmx_poseidon_set_constants has been given round constants, 0 while the context still hashes with the DEFAULT ones -- the Poseidon
+ * paper's Grain stream, which can never equal plonky2's table (a seeded ChaCha stream): a cap computed with them is self-consistent and
+ * oracle-checked but is NOT the reference prover's commitment.  A host that wants drop-in caps must inject plonky2's ALL_ROUND_CONSTANTS,
+ * hand over the extended rows in plonky2's order (it commits bit-reversed, optionally salted LDE rows; this API hashes the columns as given,
+ * natural order, no salt) and should assert this returns 1. */
+int32_t tmx_poseidon_constants_injected(const tmx_ctx* ctx);
 uint64_t tmx_poseidon_merkle_digests(uint32_t log_n, uint32_t cap_height);
 int32_t tmx_poseidon_merkle_device(tmx_ctx* ctx, uint32_t log_n, uint32_t n_cols, const uint64_t* d_cols, uint32_t cap_height, uint64_t* d_levels,
                                    void* hip_stream);

@@ -149,6 +149,7 @@ def lib():
     L.tmx_ntt_goldilocks_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.tmx_lde_goldilocks_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tmx_poseidon_set_constants.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tmx_poseidon_constants_injected.argtypes = [C.c_void_p]
     L.tmx_poseidon_merkle_digests.restype = C.c_uint64
     L.tmx_poseidon_merkle_digests.argtypes = [C.c_uint32, C.c_uint32]
     L.tmx_poseidon_merkle_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]

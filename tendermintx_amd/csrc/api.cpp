@@ -341,6 +341,7 @@ struct tmx_ctx {
   std::vector<uint64_t> pos_consts;
   void* d_pos_consts = nullptr;
   bool pos_dirty = true, pos_mds_small = true;
+  bool pos_rc_injected = false;  // round constants came from tmx_poseidon_set_constants (the defaults are NOT plonky2's table)
 };
 
 static int32_t fail(tmx_ctx* c, int32_t st, const std::string& msg) {
@@ -1729,7 +1730,10 @@ int32_t tmx_poseidon_set_constants(tmx_ctx* c, const uint64_t* rc, const uint64_
   if (!c) return TMX_ERR_BAD_ARG;
   if (c->pos_consts.empty()) poseidon_default_constants(c->pos_consts);
   const uint64_t P = 0xffffffff00000001ull;
-  if (rc) for (uint32_t i = 0; i < POS_ROUNDS * POS_T; i++) c->pos_consts[i] = rc[i] % P;
+  if (rc) {
+    for (uint32_t i = 0; i < POS_ROUNDS * POS_T; i++) c->pos_consts[i] = rc[i] % P;
+    c->pos_rc_injected = true;
+  }
   if (circ) for (uint32_t i = 0; i < POS_T; i++) c->pos_consts[POS_ROUNDS * POS_T + i] = circ[i] % P;
   if (diag) for (uint32_t i = 0; i < POS_T; i++) c->pos_consts[POS_ROUNDS * POS_T + POS_T + i] = diag[i] % P;
   if (c->d_pos_consts) {  // kernels in flight may still read the old tables
@@ -1739,6 +1743,8 @@ int32_t tmx_poseidon_set_constants(tmx_ctx* c, const uint64_t* rc, const uint64_
   c->pos_dirty = true;
   return TMX_OK;
 }
+
+int32_t tmx_poseidon_constants_injected(const tmx_ctx* c) { return c ? (c->pos_rc_injected ? 1 : 0) : TMX_ERR_BAD_ARG; }
 
 uint64_t tmx_poseidon_merkle_digests(uint32_t log_n, uint32_t cap_height) {
   if (log_n > 30 || cap_height > log_n) return 0;

@@ -585,7 +585,10 @@ KNOBS = [
     {"TMX_WALK_PARTS": "1"}, {"TMX_WALK_PARTS": "1", "TMX_KEY_CACHE": "0"}, {"TMX_EXT_EVENTS": "0"}, {"TMX_LEAVES": "1"},
     {"TMX_LEAVES": "1", "TMX_SER_SPLIT": "0"}, {"TMX_SER_SPLIT": "0"}, {"TMX_SER_SPLIT": "0", "TMX_KEY_CACHE": "0"}, {"TMX_SCHEDULE": "warm"},
     {"TMX_SCHEDULE": "cold"}, {"TMX_SCHEDULE": "warm", "TMX_KEY_CACHE_KEYS": "40"}, {"TMX_SCHEDULE": "warm", "TMX_DEDUP": "0"},
-    {"TMX_SCHEDULE": "cold", "TMX_LEAVES": "1", "TMX_WALK_PARTS": "1"}]
+    {"TMX_SCHEDULE": "cold", "TMX_LEAVES": "1", "TMX_WALK_PARTS": "1"},
+    # round 4: the small path (two launches for <= 1024 lanes) and k_proof as role workgroups, off / forced / combined with the others
+    {"TMX_TINY": "0"}, {"TMX_PROOF_ROLES": "0"}, {"TMX_TINY": "0", "TMX_PROOF_ROLES": "0"}, {"TMX_TINY": "1", "TMX_SCHEDULE": "cold"},
+    {"TMX_TINY": "1", "TMX_KEY_CACHE": "0"}, {"TMX_TINY": "1", "TMX_EXT_EVENTS": "0"}, {"TMX_TINY": "1", "TMX_KEY_CACHE_KEYS": "40"}]
 
 
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
@@ -606,6 +609,12 @@ def test_schedule_knobs_give_the_same_bits(tmx, oracle, monkeypatch, knobs):
             _, reps = _check_vs_oracle(tmx, oracle, 0, n, wl.proofs, bytes(targets), wl.trusteds, b"celestia", ctx=ctx)
             assert reps[0]["first_bad_sig"] == lane and not reps[0]["all_ok"] and all(r["first_bad_sig"] == -1 for r in reps[1:])
         _check_vs_oracle(tmx, oracle, 0, n, wl.proofs[2336:2 * 2336], bytes(targets[n * 256:2 * n * 256]), wl.trusteds[n * 48:2 * n * 48], b"celestia", ctx=ctx)
+        # small launches: the proof with the failing lane alone (the finish's long way: R decoded, R + h*A formed), four proofs, and twelve
+        # (1536 lanes: the classic graph with k_proof as role workgroups)
+        for p0, p1 in ((0, 1), (0, 4), (3, 15)):
+            _, reps = _check_vs_oracle(tmx, oracle, 0, n, wl.proofs[p0 * 2336:p1 * 2336], bytes(targets[p0 * n * 256:p1 * n * 256]),
+                                       wl.trusteds[p0 * n * 48:p1 * n * 48], b"celestia", ctx=ctx)
+            assert [r["first_bad_sig"] for r in reps] == ([lane] if p0 == 0 else [-1]) + [-1] * (p1 - p0 - 1)
 
 
 def test_many_distinct_keys_take_the_throughput_forms(tmx, oracle):

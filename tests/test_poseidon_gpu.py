@@ -48,6 +48,16 @@ def test_default_constants_are_the_grain_stream(ctx, oracle):
     assert [int(x) for x in ctx.poseidon_permute(z)[0]] == pm.Poseidon().permute([0] * 12)
 
 
+def test_default_constants_are_flagged(tmx, built_lib):
+    """the context says whether its round constants were injected (the Grain defaults are not the reference prover's: ADVICE r3)"""
+    with tmx.Context(4, b"x") as c:
+        assert built_lib.tmx_poseidon_constants_injected(c._h) == 0
+        c.poseidon_set_constants(mds_circ=[17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20])
+        assert built_lib.tmx_poseidon_constants_injected(c._h) == 0          # an MDS alone does not pin the constants
+        c.poseidon_set_constants(round_constants=list(range(1, 361)))
+        assert built_lib.tmx_poseidon_constants_injected(c._h) == 1
+
+
 def test_injected_constants_and_general_mds(tmx, oracle):
     """another table (as a maintainer would inject plonky2's): large MDS entries take the general product path"""
     import poseidon_model as pm
