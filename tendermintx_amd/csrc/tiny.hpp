@@ -629,6 +629,7 @@ struct TinyTallyLds {
   uint8_t sgn[TMX_N_LIMIT];
   uint8_t matched[TMX_N_LIMIT];
   u96 wave_tot[PROOF_THREADS_WIDE / 64];
+  uint32_t htab[2 * TMX_N_LIMIT];  // open-addressing table of the target lanes that signed (lane index, or 0xffffffff)
 };
 __device__ __forceinline__ void tiny_tally(const TinyProof& A, uint32_t p, uint32_t* tp, TinyTallyLds& L) {
   const ProofParams& P = A.P;
@@ -648,19 +649,29 @@ __device__ __forceinline__ void tiny_tally(const TinyProof& A, uint32_t p, uint3
   }
   __syncthreads();
   if (skip) {
+    // flag[j] = OR_i signed[i] && pk_target[i] == pk_trusted[j] (verify.rs:398-418).  Not as N x N comparisons (164 us of this role at
+    // N = 512): the target lanes that signed go into a hash table in LDS -- every one of them, duplicates of a key in slots of their own --
+    // and a trusted lane probes its key's run, comparing all 32 bytes with every entry it meets: the same OR, in O(N).
+    for (uint32_t h = t; h < 2 * TMX_N_LIMIT; h += blockDim.x) L.htab[h] = DEDUP_EMPTY;
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += blockDim.x) {
+      if (!L.sgn[i]) continue;
+      uint32_t h = pk_hash(L.pk[i]) & (2 * TMX_N_LIMIT - 1);
+      while (atomicCAS(&L.htab[h], DEDUP_EMPTY, i) != DEDUP_EMPTY) h = (h + 1) & (2 * TMX_N_LIMIT - 1);
+    }
+    __syncthreads();
     for (uint32_t j = t; j < n; j += blockDim.x) {
       uint32_t pkr[8];
 #pragma unroll
       for (int w = 0; w < 8; w++) pkr[w] = ld32(tr + (size_t)j * HR_STRIDE + 4 * w);
       bool m = false;
-#pragma unroll 4
-      for (uint32_t i = 0; i < n; i++) {
-        if (L.pk[i][0] == pkr[0]) {
-          uint32_t d = 0;
+      for (uint32_t h = pk_hash(pkr) & (2 * TMX_N_LIMIT - 1);; h = (h + 1) & (2 * TMX_N_LIMIT - 1)) {
+        const uint32_t i = L.htab[h];
+        if (i == DEDUP_EMPTY) break;  // (at most N of the 2 N slots are taken: every run ends)
+        uint32_t d = 0;
 #pragma unroll
-          for (int w = 1; w < 8; w++) d |= L.pk[i][w] ^ pkr[w];
-          m = m || (d == 0 && L.sgn[i]);
-        }
+        for (int w = 0; w < 8; w++) d |= L.pk[i][w] ^ pkr[w];
+        m = m || d == 0;
       }
       L.matched[j] = m;
       st32(lrp + (size_t)j * LANE_STRIDE + LN_OFF_FLAGS, (j < nbt ? 1u : 0u) | (m ? 1u << 8 : 0u));
