@@ -96,7 +96,7 @@ int launch_pack_rows(const void* d_rows, void* d_out, uint32_t elem_stride, uint
 
 
 // ---- the small-launch path (tiny.hpp): a whole batch of <= TINY_MAX_LANES validator lanes as TWO launches on the caller's stream
-constexpr uint32_t TINY_MAX_LANES = 1024;
+constexpr uint32_t TINY_MAX_LANES = 2048;
 struct TinyLaunch {
   // EdDSA lanes
   uint32_t n_lanes;

@@ -586,7 +586,7 @@ KNOBS = [
     {"TMX_LEAVES": "1", "TMX_SER_SPLIT": "0"}, {"TMX_SER_SPLIT": "0"}, {"TMX_SER_SPLIT": "0", "TMX_KEY_CACHE": "0"}, {"TMX_SCHEDULE": "warm"},
     {"TMX_SCHEDULE": "cold"}, {"TMX_SCHEDULE": "warm", "TMX_KEY_CACHE_KEYS": "40"}, {"TMX_SCHEDULE": "warm", "TMX_DEDUP": "0"},
     {"TMX_SCHEDULE": "cold", "TMX_LEAVES": "1", "TMX_WALK_PARTS": "1"},
-    # round 4: the small path (two launches for <= 1024 lanes) and k_proof as role workgroups, off / forced / combined with the others
+    # round 4: the small path (two launches for <= 2048 lanes) and k_proof as role workgroups, off / forced / combined with the others
     {"TMX_TINY": "0"}, {"TMX_PROOF_ROLES": "0"}, {"TMX_TINY": "0", "TMX_PROOF_ROLES": "0"}, {"TMX_TINY": "1", "TMX_SCHEDULE": "cold"},
     {"TMX_TINY": "1", "TMX_KEY_CACHE": "0"}, {"TMX_TINY": "1", "TMX_EXT_EVENTS": "0"}, {"TMX_TINY": "1", "TMX_KEY_CACHE_KEYS": "40"}]
 
@@ -610,7 +610,7 @@ def test_schedule_knobs_give_the_same_bits(tmx, oracle, monkeypatch, knobs):
             assert reps[0]["first_bad_sig"] == lane and not reps[0]["all_ok"] and all(r["first_bad_sig"] == -1 for r in reps[1:])
         _check_vs_oracle(tmx, oracle, 0, n, wl.proofs[2336:2 * 2336], bytes(targets[n * 256:2 * n * 256]), wl.trusteds[n * 48:2 * n * 48], b"celestia", ctx=ctx)
         # small launches: the proof with the failing lane alone (the finish's long way: R decoded, R + h*A formed), four proofs, and twelve
-        # (1536 lanes: the classic graph with k_proof as role workgroups)
+        # (1536 lanes: the small path too; with TMX_TINY=0 the classic graph with k_proof as role workgroups)
         for p0, p1 in ((0, 1), (0, 4), (3, 15)):
             _, reps = _check_vs_oracle(tmx, oracle, 0, n, wl.proofs[p0 * 2336:p1 * 2336], bytes(targets[p0 * n * 256:p1 * n * 256]),
                                        wl.trusteds[p0 * n * 48:p1 * n * 48], b"celestia", ctx=ctx)
@@ -654,14 +654,14 @@ def test_key_dedup_paths(tmx, oracle):
     def cat(wls):
         return b"".join(w.proofs for w in wls), b"".join(w.targets for w in wls), b"".join(w.trusteds for w in wls)
 
-    same = Workload(0, n, 80, 16, chain_id=b"celestia", seed=1, signed_permille=1000)  # 1280 lanes (launches of <= 1024 lanes take the small path, which never waits for fresh tables)
+    same = Workload(0, n, 160, 16, chain_id=b"celestia", seed=1, signed_permille=1000)  # 2560 lanes (launches of <= 2048 lanes take the small path, which never waits for fresh tables)
     distinct = [Workload(0, n, 1, 16, chain_id=b"celestia", seed=100 + i, signed_permille=1000) for i in range(24)]
     mixed = [Workload(0, n, 12, 16, chain_id=b"celestia", seed=7, signed_permille=900)] + distinct[:6]
-    with tmx.Context(n, b"celestia", max_batch=80) as ctx:
+    with tmx.Context(n, b"celestia", max_batch=160) as ctx:
         _, reps = _check_vs_oracle(tmx, oracle, 0, n, same.proofs, same.targets, same.trusteds, b"celestia", ctx=ctx)
         assert all(r["all_ok"] for r in reps)
         uniq, tables = ctx.last_dedup()
-        assert uniq == 16 and tables                      # 1280 lanes, 16 keys
+        assert uniq == 16 and tables                      # 2560 lanes, 16 keys
         p, t, r = cat(distinct)
         _, reps = _check_vs_oracle(tmx, oracle, 0, n, p, t, r, b"celestia", ctx=ctx)
         assert all(x["all_ok"] for x in reps)

@@ -32,7 +32,7 @@ def _sets(n, P, seeds, nb=None):
 
 def test_hit_and_miss_counters(tmx, oracle):
     """cold call: every key new, tables built; same batch again: every lane hits, nothing new; another validator set: all new again"""
-    n, P = 32, 40                # 1280 lanes: above the 1024 up to which a launch takes the small path, which never waits for fresh tables
+    n, P = 32, 80                # 2560 lanes: above the 2048 up to which a launch takes the small path, which never waits for fresh tables
     a, b = _sets(n, P, (11, 12))
     with tmx.Context(n, b"celestia", max_batch=P) as ctx:
         st0 = ctx.key_cache_stats()
