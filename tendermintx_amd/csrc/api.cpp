@@ -246,6 +246,7 @@ struct Knobs {
   int walk_parts = -1;       // TMX_WALK_PARTS=0|1: the table walk follows the table build part by part (default: from 65536 lanes)
   bool ext_events = true;    // TMX_EXT_EVENTS=0: record packets instead of completion signals on the chain kernels
   int warm_schedule = -1;    // TMX_SCHEDULE=warm|cold: the EdDSA schedule for resident / new keys (default: by what the last launch saw)
+  int phase1_max = -1;       // TMX_PHASE1_MAX=<lanes>: up to that many lanes the warm schedule runs s*B as a role of the hash launch (default 16384: 128 proofs at N = 128)
   bool proof_roles = true;   // TMX_PROOF_ROLES=0: k_proof as one workgroup per proof (the round-3 kernel) instead of four role workgroups
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
@@ -262,6 +263,7 @@ static Knobs read_knobs() {
   k.warm_schedule = (v = std::getenv("TMX_SCHEDULE")) ? (v[0] == 'w' ? 1 : 0) : -1;
   k.tiny = (v = std::getenv("TMX_TINY")) ? (v[0] != '0' ? 1 : 0) : -1;
   k.proof_roles = !((v = std::getenv("TMX_PROOF_ROLES")) && v[0] == '0');
+  if ((v = std::getenv("TMX_PHASE1_MAX"))) k.phase1_max = std::atoi(v);
   return k;
 }
 
@@ -723,7 +725,10 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
 
   if (tiny || warm) {
     // hash role (tiny: all of phase 1 -- a launch of a few waves is pure latency, its roles side by side) on s
-    rc = tiny ? launch_ed_phase1(Q, s, x ? c->ev_hash : nullptr) : launch_ed_hash(Q, s, x ? c->ev_hash : nullptr);
+    // (a few thousand lanes: s*B as a role of the same launch as the hash, as in a tiny launch -- on side2 it started behind three empty
+    // launches, ran into the walk and held the finish back by ~50 us: profiles/r04_p32_timeline.txt)
+    const bool sb_with_hash = tiny || (K.phase1_max >= 0 ? n_lanes <= (uint32_t)K.phase1_max : n_lanes <= 16384);
+    rc = sb_with_hash ? launch_ed_phase1(Q, s, x ? c->ev_hash : nullptr) : launch_ed_hash(Q, s, x ? c->ev_hash : nullptr);
     if (rc) return rc;
     if (!x && (e = hipEventRecord(c->ev_hash, s)) != hipSuccess) return (int)e;
     c->ev_hash_recorded = true;
@@ -737,7 +742,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     if (rc) return rc;
     if (!xt && (e = hipEventRecord(c->ev_part[0], c->side2)) != hipSuccess) return (int)e;
     if (!tiny) {  // s*B (only the finish needs it) beside the hash role and the walk, then the table-free lanes: ev_direct = both done
-      rc = launch_ed_base(Q, c->side2);
+      rc = sb_with_hash ? 0 : launch_ed_base(Q, c->side2);
       if (rc) return rc;
       if ((rc = direct_on_side2(false))) return rc;
     }
