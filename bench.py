@@ -500,7 +500,16 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
                 return insts * ((1 - fast_share) * CYCLES_SLOW + fast_share * CYCLES_FAST), insts * CYCLES_SLOW
 
             lo = hi = 0.0
-            for kname, v in pmc.get("per_kernel", {}).items():
+            per_kernel_insts = {k: {"valu_insts": v} for k, v in measured_traffic["valu_insts_per_kernel"].items()} if (measured_traffic and measured_traffic.get("valu_insts_per_kernel")) else pmc.get("per_kernel", {})
+            if measured_traffic and measured_traffic.get("valu_insts_per_kernel"):
+                src = measured_traffic["source"]
+                grp = lambda k: "k_serialize" if "k_serialize" in k else "k_proof" if "k_proof" in k else "k_verdict" if "k_verdict" in k else "k_eddsa"
+                pk = {}
+                for k, v in per_kernel_insts.items():
+                    pk.setdefault(grp(k), {"valu_insts": 0})["valu_insts"] += v["valu_insts"]
+                for g in ("k_eddsa", "k_proof", "k_serialize"):
+                    pk.setdefault(g, {"valu_insts": 0})
+            for kname, v in per_kernel_insts.items():
                 if "valu_insts" not in v or "init_base" in kname:
                     continue
                 share = mix.get(kname.split("<")[0], {}).get("fast_class_share", 0.0)
@@ -684,7 +693,7 @@ def measure_traffic(n, P, workload):
     try:
         with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
             env = dict(os.environ, TMPDIR="/tmp", P=str(P), N=str(n), WORKLOAD=workload, WARM=str(warm), STEPS=str(steps))
-            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
                 out = os.path.join(tmp, counter)
                 r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "step", "--", sys.executable,
                                     os.path.join(ROOT, "tools", "profile_step.py")], cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
@@ -700,13 +709,14 @@ def measure_traffic(n, P, workload):
                                               "and kernel_name like '%tmx::%' and kernel_name not like '%k_init_base%' group by kernel_name", (counter, first)):
                     tot[counter] = tot.get(counter, 0.0) + value / steps
                     short = name.split("(")[0].replace("void ", "").replace("tmx::", "")
-                    per_kernel.setdefault(short, {})[counter] = round(value / steps * 1024)
+                    per_kernel.setdefault(short, {})[counter] = round(value / steps * (1 if counter == "SQ_INSTS_VALU" else 1024))
         if "FETCH_SIZE" not in tot or "WRITE_SIZE" not in tot:
             return None
+        valu = {k: v["SQ_INSTS_VALU"] for k, v in per_kernel.items() if "SQ_INSTS_VALU" in v}
         return {"bytes_per_step": int((tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024), "fetch_bytes": int(tot["FETCH_SIZE"] * 1024),
-                "write_bytes": int(tot["WRITE_SIZE"] * 1024), "per_kernel_bytes": per_kernel,
-                "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over tools/profile_step.py, "
-                          f"mean of {steps} warm batches"}
+                "write_bytes": int(tot["WRITE_SIZE"] * 1024), "per_kernel": per_kernel, "valu_insts_per_kernel": valu,
+                "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU (three passes) over "
+                          f"tools/profile_step.py, mean of {steps} warm batches"}
     except Exception:
         return None
 

@@ -588,7 +588,8 @@ KNOBS = [
     {"TMX_SCHEDULE": "cold", "TMX_LEAVES": "1", "TMX_WALK_PARTS": "1"},
     # round 4: the small path (two launches for <= 2048 lanes) and k_proof as role workgroups, off / forced / combined with the others
     {"TMX_TINY": "0"}, {"TMX_PROOF_ROLES": "0"}, {"TMX_TINY": "0", "TMX_PROOF_ROLES": "0"}, {"TMX_TINY": "1", "TMX_SCHEDULE": "cold"},
-    {"TMX_TINY": "1", "TMX_KEY_CACHE": "0"}, {"TMX_TINY": "1", "TMX_EXT_EVENTS": "0"}, {"TMX_TINY": "1", "TMX_KEY_CACHE_KEYS": "40"}]
+    {"TMX_TINY": "1", "TMX_KEY_CACHE": "0"}, {"TMX_TINY": "1", "TMX_EXT_EVENTS": "0"}, {"TMX_TINY": "1", "TMX_KEY_CACHE_KEYS": "40"},
+    {"TMX_PHASE1_MAX": "0"}, {"TMX_PHASE1_MAX": "1000000", "TMX_TINY": "0"}]
 
 
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
