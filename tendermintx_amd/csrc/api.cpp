@@ -564,7 +564,11 @@ static void tiny_common(tmx_ctx* c, TinyLaunch& T, uint32_t n_lanes, const void*
 // the previous launch left on the side stream (it may still be inserting keys into the cache this launch probes)
 static int32_t tiny_order(tmx_ctx* c, hipStream_t s) {
   if (c->last_stream_valid && c->last_stream != s) HIPCK(c, hipStreamWaitEvent(s, c->ev_done, 0));
-  HIPCK(c, hipStreamWaitEvent(s, c->ev_hash_clean, 0));
+  // (an isolated call finds the previous key pipeline long finished: a host-side query instead of a wait packet in front of the first launch)
+  if (hipEventQuery(c->ev_hash_clean) != hipSuccess) {
+    (void)hipGetLastError();
+    HIPCK(c, hipStreamWaitEvent(s, c->ev_hash_clean, 0));
+  }
   return TMX_OK;
 }
 // the cache bookkeeping of a small launch: the classic key pipeline on side2, behind k_tiny (event `after`), over the shadow records
