@@ -632,10 +632,14 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
             "sections": l2, "ms_per_batch": l2["all"]["ms"], "ms_per_proof": round(l2["all"]["ms"] / P, 5),
             "roofline": {"kernel": "k_trace_ladder_pass1 + _pass2", "bound": "hbm", "achieved": l2["ladders"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(l2["ladders"]["gbs"] / HBM_PEAK_GBS, 4), "algorithmic_bytes": l2["ladders"]["bytes"], "traffic": None,
-                         "note": "pass 1 (the double-and-add chain, one thread per ladder) is one latency-bound wave per SIMD, pass 2 (inversions, "
-                                 "canonical limbs, stores) waits for its loads at two waves per SIMD; 5.6 k instructions per row put the issue-bound "
-                                 "ceiling at 0.45 of HBM, and the 21 GB the two passes move (4 GB of projective points written and read back) at "
-                                 "~4.8 ms: DESIGN.md 'The writer, measured'"}}
+                         "note": "pass 1 (the double-and-add chain + the running product of the Z's, one thread per ladder) is one latency-bound "
+                                 "wave per SIMD; pass 2 (one inversion per 16 rows, Montgomery's trick walked backwards over the stored prefix "
+                                 "products, canonical limbs, stores) runs beside the next segment's chain at four waves per SIMD; ~3.3 k + ~3.7 k "
+                                 "instructions per row: DESIGN.md 'The writer, measured'"}}
+        l2_traffic = measure_level2_traffic(n, P, args.workload)  # (extras() runs on rank 0 of a one-GPU run only)
+        if l2_traffic:
+            result["level2_trace_rows"]["roofline"]["traffic"] = l2_traffic["bytes_per_call"]
+            result["level2_trace_rows"]["roofline"]["traffic_detail"] = l2_traffic
         tr0 = d_tr[:te].cpu().numpy().view(np.uint64)
         del d_tr
     except Exception as e:  # the trace rows are a widening row: never let them take the headline line down
@@ -717,6 +721,44 @@ def measure_traffic(n, P, workload):
                 "write_bytes": int(tot["WRITE_SIZE"] * 1024), "per_kernel": per_kernel, "valu_insts_per_kernel": valu,
                 "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU (three passes) over "
                           f"tools/profile_step.py, mean of {steps} warm batches"}
+    except Exception:
+        return None
+
+
+def measure_level2_traffic(n, P, workload):
+    """HBM bytes of one call of the Level-2 ladder section (k_trace_ladder_pass1 + _pass2 of every segment) from rocprofv3's FETCH_SIZE /
+    WRITE_SIZE, each in a pass of its own over tools/trace_bench.py (SECTIONS=ladders: 2 warm + 5 timed calls, all counted -- the kernels do
+    the same work every call).  None when rocprofv3 is not usable."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    if not shutil.which("rocprofv3") or os.environ.get("TMX_BENCH_NO_PMC") == "1":
+        return None
+    calls, tot, per_kernel = 7, {}, {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            env = dict(os.environ, TMPDIR="/tmp", P=str(P), N=str(n), WORKLOAD=workload, SECTIONS="ladders")
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(tmp, counter)
+                r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "l2", "--", sys.executable,
+                                    os.path.join(ROOT, "tools", "trace_bench.py")], cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+                dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+                if r.returncode != 0 or not dbs:
+                    return None
+                db = sqlite3.connect(dbs[0])
+                for name, value in db.execute("select kernel_name, sum(value) from counters_collection where counter_name = ? "
+                                              "and kernel_name like '%k_trace_ladder%' group by kernel_name", (counter,)):
+                    tot[counter] = tot.get(counter, 0.0) + value / calls
+                    short = "k_trace_ladder_pass1" if "pass1" in name else "k_trace_ladder_pass2"
+                    per_kernel.setdefault(short, {})[counter] = per_kernel.get(short, {}).get(counter, 0) + round(value / calls * 1024)
+        if "FETCH_SIZE" not in tot or "WRITE_SIZE" not in tot:
+            return None
+        return {"bytes_per_call": int((tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024), "fetch_bytes": int(tot["FETCH_SIZE"] * 1024),
+                "write_bytes": int(tot["WRITE_SIZE"] * 1024), "per_kernel": per_kernel,
+                "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over tools/trace_bench.py "
+                          f"(SECTIONS=ladders), mean of {calls} calls; uncorrected sums (MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced "
+                          "reads by 2x -- pass 2 reads the 5.4 GB of scratch pass 1 writes with 16-byte loads)"}
     except Exception:
         return None
 

@@ -326,7 +326,7 @@ struct tmx_ctx {
   // staging for the host-buffer entry points
   void *d_in_proofs = nullptr, *d_in_targets = nullptr, *d_in_trusteds = nullptr, *d_out = nullptr;
   uint64_t d_out_elems = 0;
-  hipEvent_t ev_trace[5] = {};  // ladder segments done (4) + the side stream's pass 2 done
+  hipEvent_t ev_trace[17] = {};  // ladder segments done (up to 16) + [16] the side stream's pass 2 done
   void* d_trace_tmp = nullptr;  // projective ladder points between the two passes of the Level-2 ladder kernels (allocated on first use)
   void* d_pack = nullptr;  // dense / narrowed rows for tmx_witness_batch_opts (allocated on first use)
   uint64_t d_pack_bytes = 0;
@@ -1241,7 +1241,7 @@ int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const
   // the trace kernels read the Level-1 lane records of the context: they must be those of a batch of this kind and at least this size
   if (c->last_kind != kind || c->last_n_proofs < n_proofs)
     return fail(c, TMX_ERR_BAD_ARG, "tmx_trace_rows_device: call tmx_witness_batch_device for the same batch (kind, >= n_proofs) first");
-  if ((sections & TMX_TRACE_LADDERS) && !c->d_trace_tmp) {  // 61 KB per ladder between the two ladder passes: allocated (blocking) on the first call
+  if ((sections & TMX_TRACE_LADDERS) && !c->d_trace_tmp) {  // 82 KB per ladder between the two ladder passes: allocated (blocking) on the first call
     HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, hipMalloc(&c->d_trace_tmp, trace_tmp_bytes(c->cfg.n_max, c->cfg.max_batch)));
   }
@@ -1250,9 +1250,11 @@ int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const
   const uint32_t n = c->cfg.n_max;
   int rc = 0;
   if (sections & TMX_TRACE_LADDERS) {
-    // The chain (pass 1: 1024 latency-bound waves per 256 proofs) in four segments of 64 rows on the caller's stream; the affine rows of a
-    // segment (pass 2: issue-bound) follow on the side stream while the next segment is being doubled (one after the other: 7.25 vs 6.7 ms).
-    const uint32_t segs = 4;
+    // The chain (pass 1: 1024 latency-bound waves per 256 proofs) in segments on the caller's stream; the affine rows of a segment (pass 2)
+    // follow on the side stream while the next segment is being doubled.  Measured per 256-proof batch at N = 128 (round 4 kernels): two
+    // segments of 128 rows 4.95 ms, four 5.4, eight 6.7; both passes one after the other on one stream 6.4.  TMX_TRACE_SEGS overrides.
+    static const uint32_t segs_env = std::getenv("TMX_TRACE_SEGS") ? (uint32_t)std::atoi(std::getenv("TMX_TRACE_SEGS")) : 2u;
+    const uint32_t segs = (segs_env == 1 || segs_env == 4 || segs_env == 8 || segs_env == 16) ? segs_env : 2u;
     for (auto& e : c->ev_trace)
       if (!e) HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (uint32_t g = 0; g < segs && !rc; g++) {
@@ -1267,7 +1269,7 @@ int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const
       rc = launch_trace_ladder_pass2((uint32_t)kind, n, n_proofs, d_targets, edr, TL_STRIDE, c->d_trace_tmp, d_trace_out, r0, r1, p2);
     }
     if (!rc) {
-      HIPCK(c, hipEventRecord(c->ev_trace[4], c->side));
+      HIPCK(c, hipEventRecord(c->ev_trace[16], c->side));
     }
   }
   if (!rc && (sections & ~(uint32_t)TMX_TRACE_LADDERS)) {
@@ -1275,7 +1277,7 @@ int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const
     rc = launch_trace_rest((uint32_t)kind, n, n_proofs, d_targets, d_trusteds, L1, d_trace_out, sections, s);
   }
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_trace launch: ") + hipGetErrorString((hipError_t)rc));
-  if ((sections & TMX_TRACE_LADDERS) && c->ev_trace[4]) HIPCK(c, hipStreamWaitEvent(s, c->ev_trace[4], 0));  // the call ends on the caller's stream
+  if ((sections & TMX_TRACE_LADDERS) && c->ev_trace[16]) HIPCK(c, hipStreamWaitEvent(s, c->ev_trace[16], 0));  // the call ends on the caller's stream
   return TMX_OK;
 }
 

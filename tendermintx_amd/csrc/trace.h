@@ -8,7 +8,7 @@ namespace tmx {
 
 // elements of one proof's trace block (DESIGN.md "Level-2 trace rows")
 uint64_t trace_elems(uint32_t kind, uint32_t n);
-// Ladder rows [row0, row1) (multiples of eight) of every lane: pass 1 = the double-and-add chain into the scratch buffer d_tmp
+// Ladder rows [row0, row1) (row1 - row0 a multiple of eight) of every lane: pass 1 = the double-and-add chain + running Z products into d_tmp
 // (trace_tmp_bytes; a segment with row0 > 0 continues from the buffer), pass 2 = affine rows out of it.  d_ed: the Level-1 EdDSA lane
 // records of the SAME batch (h, A, decode flag).  Each returns a hipError_t value.
 size_t trace_tmp_bytes(uint32_t n, uint32_t n_proofs);

@@ -34,7 +34,6 @@ __device__ __constant__ const uint32_t T_DUMMY_SIG[16] = {0x9e681437u, 0x11c2785
 __device__ __constant__ const uint32_t T_BX[8] = {0x8f25d51au, 0xc9562d60u, 0x9525a7b2u, 0x692cc760u, 0xfdd6dc5cu, 0xc0a4e231u, 0xcd6e53feu, 0x216936d3u};
 __device__ __constant__ const uint32_t T_BY[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u};
 
-constexpr int CH = 8;  // ladder rows per inversion batch (2 CH points)
 
 // flush `nv` staged values of every thread's current row group: value e of thread j goes to out[base[j] + off + e]
 template <int NV>
@@ -51,16 +50,26 @@ __device__ __forceinline__ void coop_flush(const uint32_t (*stage)[NV + 1], cons
 }
 
 // ---- ladders, in two passes so that the expensive half (inversions, canonical limbs, the stores) is not a 256-step chain:
-//   pass 1  one thread per (lane, ladder): the double-and-add chain in extended coordinates; (X:Y:Z) of dbl_r and add_r of every row go
-//           to a scratch buffer (240 B per row, laid out [block][row][word][thread] so that every store / load instruction is coalesced)
-//   pass 2  one thread per (ladder, batch of eight rows), a wave = the same 64 ladders as in pass 1: the 16 points of the batch plus the
-//           accumulator it starts from made affine together (Montgomery's trick around one safegcd inversion), rows staged in LDS and
-//           written by the whole wave (every store instruction covers 512 contiguous bytes of ONE ladder).
-// 32 x the threads of the one-pass form for the part that is 60 % of the instructions.  Measured per 256-proof batch at N = 128: one pass
-// 8.3 ms (7.2 ms at 32 proofs: a pure latency chain); two passes 2.75 + 4.25 ms (1.9 ms at 32 proofs).
+//   pass 1  one thread per (lane, ladder): the double-and-add chain in extended coordinates.  (X:Y:Z) of dbl_r and add_r of every row go to
+//           a scratch buffer together with the PREFIX PRODUCT of all Z's up to that point (P_2r = Z(dbl_0) Z(add_0) ... Z(dbl_r),
+//           P_2r+1 = P_2r Z(add_r): two more products per row, off the point chain) -- 320 B per row, every store / load instruction a
+//           contiguous run of 16 bytes per lane (layout below).
+//   pass 2  one thread per (ladder, R rows), a wave = the same 64 ladders as in pass 1: ONE safegcd inversion of P at the thread's last
+//           point, then Montgomery's trick walked BACKWARDS -- 1 / Z_k = inv(P_k) P_k-1, inv(P_k-1) = inv(P_k) Z_k: two products per
+//           point and nothing recomputed (the first version swept the Z's of its rows three times for the suffix products it could not keep:
+//           14 products per row against 8) --, the affine words staged in LDS and written by the whole wave.
+// What a thread writes per row is the 65 CONTIGUOUS elements  dbl_r | add_r | nxt_r | bit_r+1 | acc_r+1  (acc_r+1 = nxt_r: elements 17 ... 64
+// of row r and 0 ... 16 of row r + 1), so that no thread needs the affine form of the point its rows start from; the thread with row 0 adds
+// the ladder's first 17 elements (bit_0, the identity), the one with row 255 stops after nxt.
+// Measured per 256-proof batch at N = 128 (8.7 GB of rows): one pass 8.3 ms; two passes with suffix products 6.1 ms (round 3); this form
+// 4.95 ms -- pass 2 alone 0.52 ms per 64-row segment without its stores, 0.8 - 0.9 with them: what is left is the write stream of 520-byte
+// pieces 130 KB apart (DESIGN.md "The writer, measured").
+// (the scalar as a VECTOR: a wave-uniform dynamic index into a vector is a register select; into an array it became a scratch load per row,
+// and every scratch load waits for ALL memory operations of the wave -- vmcnt counts in order -- i.e. for the stores of the row before)
+typedef uint32_t tr_u32x8 __attribute__((ext_vector_type(8)));
 struct LadderIn {
-  uint32_t sc[8];  // the scalar
-  ge_affc P;       // the point that is added
+  tr_u32x8 sc;  // the scalar
+  ge_affc P;    // the point that is added
   bool decoded;
 };
 __device__ __forceinline__ LadderIn ladder_inputs(uint32_t lane, uint32_t k, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
@@ -83,162 +92,196 @@ __device__ __forceinline__ LadderIn ladder_inputs(uint32_t lane, uint32_t k, con
   }
   return L;
 }
-__device__ __forceinline__ uint32_t scalar_bit(const uint32_t sc[8], int r) {  // bit 255 - r
+__device__ __forceinline__ uint32_t scalar_bit(const tr_u32x8& sc, int r) {  // bit 255 - r
   const int b = 255 - r;
-  uint32_t word = sc[0];
-#pragma unroll
-  for (int w = 1; w < 8; w++) word = (b >> 5) == w ? sc[w] : word;
-  return (word >> (b & 31)) & 1u;
+  return (sc[(b >> 5) & 7] >> (b & 31)) & 1u;
 }
-constexpr uint32_t TR_PT_WORDS = 60;  // per row in the scratch buffer: dbl (X, Y, Z), add (X, Y, Z), ten limbs each
+// The scratch buffer: per block of 64 ladders and per row eight field elements -- dbl (X, Y, Z), add (X, Y, Z), P(dbl), P(add) --, each as
+// 640 words [part][thread][words of the part] with parts of 4, 4 and 2 limbs: a wave moves one element with three instructions (16, 16 and
+// 8 bytes per lane, every one of them a contiguous run: 24 loads or stores per row instead of 80 of one word -- a wave may have 63 in flight).
+constexpr uint32_t TR_FE_WORDS = 640, TR_PT_FES = 8, TR_ROW_WORDS = TR_FE_WORDS * TR_PT_FES;
+enum : uint32_t { TR_DX = 0, TR_DY = 1, TR_DZ = 2, TR_AX = 3, TR_AY = 4, TR_AZ = 5, TR_PD = 6, TR_PA = 7 };
+typedef int32_t tr_i32x4 __attribute__((ext_vector_type(4)));
+typedef int32_t tr_i32x2 __attribute__((ext_vector_type(2)));
+// `blk` = the block's part of the buffer; t = the thread
+__device__ __forceinline__ const int32_t* pt_at(const int32_t* __restrict__ blk, int row, uint32_t which) {
+  return blk + ((size_t)row * TR_PT_FES + which) * TR_FE_WORDS;
+}
+__device__ __forceinline__ fe pt_load(const int32_t* __restrict__ p, uint32_t t) {
+  const tr_i32x4 a = *reinterpret_cast<const tr_i32x4*>(p + 4 * t), b = *reinterpret_cast<const tr_i32x4*>(p + 256 + 4 * t);
+  const tr_i32x2 c = *reinterpret_cast<const tr_i32x2*>(p + 512 + 2 * t);
+  fe v;
+  v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w; v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w; v.v[8] = c.x; v.v[9] = c.y;
+  return v;
+}
+__device__ __forceinline__ void pt_store(int32_t* __restrict__ p, uint32_t t, const fe& v) {
+  tr_i32x4 a, b;
+  tr_i32x2 c;
+  a.x = v.v[0]; a.y = v.v[1]; a.z = v.v[2]; a.w = v.v[3]; b.x = v.v[4]; b.y = v.v[5]; b.z = v.v[6]; b.w = v.v[7]; c.x = v.v[8]; c.y = v.v[9];
+  *reinterpret_cast<tr_i32x4*>(p + 4 * t) = a;
+  *reinterpret_cast<tr_i32x4*>(p + 256 + 4 * t) = b;
+  *reinterpret_cast<tr_i32x2*>(p + 512 + 2 * t) = c;
+}
 
 __global__ __launch_bounds__(64) void k_trace_ladder_pass1(uint32_t n_lanes, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
                                                            uint32_t ed_stride, int32_t* __restrict__ pts, uint32_t row0, uint32_t row1) {
   const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t;
   const bool live = id < 2u * n_lanes;
   const LadderIn L = ladder_inputs(live ? id >> 1 : 0u, id & 1u, in_target, ed, ed_stride, true);
-  int32_t* o = pts + (size_t)blockIdx.x * TR_LADDER_ROWS * TR_PT_WORDS * 64u + t;
+  int32_t* blk = pts + (size_t)blockIdx.x * TR_LADDER_ROWS * TR_ROW_WORDS;
   ge_proj acc = ext_to_proj(ge_identity());
-  if (row0) {  // a later segment of the chain: the accumulator is row0 - 1's nxt, already in the scratch buffer
-    const int32_t* prev = o + (size_t)(row0 - 1) * TR_PT_WORDS * 64u + (size_t)scalar_bit(L.sc, (int)row0 - 1) * 30u * 64u;
-#pragma unroll
-    for (int l = 0; l < 10; l++) { acc.X.v[l] = prev[l * 64]; acc.Y.v[l] = prev[(10 + l) * 64]; acc.Z.v[l] = prev[(20 + l) * 64]; }
+  fe prod = fe_one();
+  __builtin_amdgcn_s_setprio(3);  // the chain is the latency of the whole section; pass 2 of the previous segment runs beside it as throughput work
+  if (row0) {  // a later segment of the chain: the accumulator is row0 - 1's nxt, the running product its P(add) -- both in the scratch buffer
+    const uint32_t w = scalar_bit(L.sc, (int)row0 - 1) ? TR_AX : TR_DX;
+    acc.X = pt_load(pt_at(blk, (int)row0 - 1, w), t); acc.Y = pt_load(pt_at(blk, (int)row0 - 1, w + 1), t); acc.Z = pt_load(pt_at(blk, (int)row0 - 1, w + 2), t);
+    prod = pt_load(pt_at(blk, (int)row0 - 1, TR_PA), t);
   }
 #pragma unroll 1
   for (int r = (int)row0; r < (int)row1; r++) {
     const uint32_t bit = scalar_bit(L.sc, r);
     const ge_ext d = comp_to_ext(ge_double(acc));
     const ge_proj a = comp_to_proj(ge_add_affc(d, L.P));  // (the sum's T is never needed: the next step doubles from (X : Y : Z))
-    int32_t* row = o + (size_t)r * TR_PT_WORDS * 64u;
-#pragma unroll
-    for (int l = 0; l < 10; l++) {
-      row[(0 + l) * 64] = d.X.v[l]; row[(10 + l) * 64] = d.Y.v[l]; row[(20 + l) * 64] = d.Z.v[l];
-      row[(30 + l) * 64] = a.X.v[l]; row[(40 + l) * 64] = a.Y.v[l]; row[(50 + l) * 64] = a.Z.v[l];
-    }
+    const fe pd = fe_mul(prod, d.Z);
+    prod = fe_mul(pd, a.Z);
+    int32_t* row = blk + (size_t)r * TR_ROW_WORDS;
+    pt_store(row + TR_DX * TR_FE_WORDS, t, d.X); pt_store(row + TR_DY * TR_FE_WORDS, t, d.Y); pt_store(row + TR_DZ * TR_FE_WORDS, t, d.Z);
+    pt_store(row + TR_AX * TR_FE_WORDS, t, a.X); pt_store(row + TR_AY * TR_FE_WORDS, t, a.Y); pt_store(row + TR_AZ * TR_FE_WORDS, t, a.Z);
+    pt_store(row + TR_PD * TR_FE_WORDS, t, pd); pt_store(row + TR_PA * TR_FE_WORDS, t, prod);
     acc.X = fe_select(d.X, a.X, bit); acc.Y = fe_select(d.Y, a.Y, bit); acc.Z = fe_select(d.Z, a.Z, bit);
   }
 }
 
-// Everything below is unrolled with compile-time indices: no indexed private array (the first version kept X, Y, Z, prefix products and the
-// affine words of a batch in 4 KB of scratch per thread -- 8 GB of spill traffic per 256-proof batch, twice the rows themselves).
-// Montgomery's trick with SUFFIX products so that the points come out in row order: total = Z_0 ... Z_16, then for i = 0, 1, ...:
-// 1 / Z_i = inv_i * suf_{i+1} with inv_i = 1 / suf_i, inv_{i+1} = inv_i * Z_i.  Only suf_4, suf_8, suf_12, suf_16 are kept (40 VGPRs);
-// the three in between are recomputed per group of four from the Z's (re-read from the scratch buffer: coalesced, mostly L2).
-// One safegcd inversion serves GCH batches (the inversion was 35 % of this pass's instructions with one per batch): a first backward
-// sweep over the Z's of all GCH batches leaves the suffix products at the batch boundaries in LDS, the inversion of the total gives
-// 1 / (everything from batch 0 on), and every batch then runs the schedule above with "everything behind this batch" folded into its
-// suffix products; the running inverse ends a batch as the inverse of what is left, i.e. where the next batch starts.
-template <int GCH>
+// The stores of pass 2.  Row r of a ladder yields the 65 contiguous elements  dbl_r | add_r | nxt_r | bit_r+1 | acc_r+1  (its "unit", at element
+// U = 65 r + 17 of the ladder: nxt = acc of the next row = bit_r ? add : dbl).  520 bytes at an arbitrary multiple of 8: written unit by unit,
+// every unit left two partially written 64-byte lines for the unit beside it to complete tens of microseconds later -- measured, the same
+// kernel with 512-byte aligned pseudo-rows ran 1.4x faster (0.71 vs 1.01 ms per segment; without any store 0.52).  So a flush writes WHOLE
+// LINES: from the first line boundary in the unit to the first line boundary behind it, i.e. without the unit's first d = -U mod 8 elements
+// (the row below writes them) and with the first c elements of the unit above (its dbl words, kept from the previous flush): 64 elements,
+// 72 when the unit itself starts on a boundary.  Only the first and the last unit of a thread's rows end inside a line.
+//   staged words of a thread: [0, 16) dbl, [16, 32) add, [32] bit_r+1, [33, 40) / [40, 47) the first seven dbl words of the odd / even rows
+//   (a row leaves its own there while the flush reads those of the row above); stride 47 (odd)
+//   element k of the span -> staged word through a 4 x 72-byte table in LDS (by bit_r: nxt and acc are add or dbl; by the parity of r)
+// One ladder per store instruction: 64 lanes x 8 bytes; what belongs to the ladder (address, bit, bounds of its span) is read from the owning
+// lane's registers into SGPRs (v_readlane with a constant lane) -- the address is scalar base + lane offset, nothing waits for LDS but the data.
+constexpr uint32_t TR_STAGE = 47, TR_ST_BIT = 32, TR_ST_CARRY = 33, TR_SPAN_MAX = 72;
+// element k of (unit of row r | carried head of the unit of row r + 1) -> staged word;  sel = bit_r | (r & 1) << 1
+__device__ __forceinline__ uint32_t span_word(uint32_t k, uint32_t sel) {
+  const uint32_t up = (sel & 1u) ? 16u : 0u, above = (sel & 2u) ? 7u : 0u;  // (row r + 1 is even where r is odd: the second carry area)
+  return k < 32 ? k : (k < 48 ? k - 32 + up : (k == 48 ? TR_ST_BIT : (k < 65 ? k - 49 + up : TR_ST_CARRY + above + (k - 65))));
+}
+// my_info: bit_r | (r & 1) << 1 | live << 2 | k_lo << 3 (3 bits) | (k_hi - k_lo) << 6;  my_dst: element index of unit element k_lo in `out`
+__device__ __forceinline__ void ladder_flush(const uint32_t (*stage)[TR_STAGE], const uint8_t* lut, uint64_t my_dst, uint32_t my_info, uint64_t* __restrict__ out) {
+  __syncthreads();
+  const uint32_t e = threadIdx.x;
+  const uint32_t dst_lo = (uint32_t)my_dst, dst_hi = (uint32_t)(my_dst >> 32);
+  const char* sb = reinterpret_cast<const char*>(&stage[0][0]);
+  // The usual flush: every ladder of the wave has the same alignment and a span of exactly 64 elements -- then a lane's staged word depends
+  // on the ladder's bit only, and the two candidates are looked up once per row instead of once per ladder (no table read, no exec mask
+  // and so nothing between the LDS reads of consecutive ladders: they overlap).  Any other ladder takes the general path below.
+  const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)my_info, 0);
+  const uint32_t fast_key = ((ref & 4u) && (ref >> 6) == 64u) ? (ref & ~1u) : 0xffffffffu;
+  const uint32_t kk = ((ref >> 3) & 7u) + ((ref >> 1) & 1u) * (2u * TR_SPAN_MAX);
+  const uint32_t a0 = 4u * lut[kk + e], a1 = 4u * lut[kk + TR_SPAN_MAX + e];
+#pragma unroll 8
+  for (int j = 0; j < 64; j++) {
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)my_info, j);
+    uint64_t* dst = out + ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dst_lo, j) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dst_hi, j) << 32));
+    if ((b & ~1u) == fast_key) {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(sb + (size_t)j * (TR_STAGE * 4u) + ((b & 1u) ? a1 : a0));
+      __builtin_nontemporal_store((uint64_t)v, dst + e);
+      continue;
+    }
+    if (!(b & 4u)) continue;  // (ladders that do not exist are at the end of the last block)
+    const uint32_t k0 = ((b >> 3) & 7u) + (b & 3u) * TR_SPAN_MAX, n = b >> 6;  // (scalar)
+    const uint32_t w = lut[k0 + e];
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(sb + (size_t)j * (TR_STAGE * 4u) + 4u * w);
+    if (e < n) __builtin_nontemporal_store((uint64_t)v, dst + e);
+    if (n > 64u) {  // (a unit that starts on a line boundary, or the lowest row of a thread: up to eight more elements)
+      const uint32_t w2 = lut[k0 + 64u + (e & 7u)];
+      const uint32_t v2 = *reinterpret_cast<const uint32_t*>(sb + (size_t)j * (TR_STAGE * 4u) + 4u * w2);
+      if (e < n - 64u) __builtin_nontemporal_store((uint64_t)v2, dst + 64 + e);
+    }
+  }
+  __syncthreads();
+}
+
+// what pass 2 reads for one row: P(dbl), add (X, Y, Z), P(add) of the row before, dbl (X, Y, Z)
+struct LadderRow {
+  fe pd, ax, ay, az, pp, dx, dy, dz;
+};
+__device__ __forceinline__ LadderRow ladder_row_load(const int32_t* __restrict__ blk, int r, uint32_t t) {
+  LadderRow w;
+  w.pd = pt_load(pt_at(blk, r, TR_PD), t);
+  w.az = pt_load(pt_at(blk, r, TR_AZ), t);
+  w.ax = pt_load(pt_at(blk, r, TR_AX), t);
+  w.ay = pt_load(pt_at(blk, r, TR_AY), t);
+  w.pp = r > 0 ? pt_load(pt_at(blk, r - 1, TR_PA), t) : fe_one();
+  w.dz = pt_load(pt_at(blk, r, TR_DZ), t);
+  w.dx = pt_load(pt_at(blk, r, TR_DX), t);
+  w.dy = pt_load(pt_at(blk, r, TR_DY), t);
+  return w;
+}
+
+template <int R>
 __global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t n_lanes, uint32_t n, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
                                                            uint32_t ed_stride, const int32_t* __restrict__ pts, uint64_t* __restrict__ out,
-                                                           uint64_t proof_stride, uint32_t chunk0) {
-  __shared__ uint32_t stage[64][TR_LADDER_ROW + 1];
-  __shared__ uint64_t s_base[64];
-  __shared__ uint8_t s_live[64];
-  __shared__ int32_t s_behind[GCH > 1 ? GCH - 1 : 1][10][64];  // [q - 1]: product of the Z's of batches q .. GCH - 1 of this thread
-  const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t, c_first = chunk0 + blockIdx.y * GCH;  // batch c = rows CH c .. CH c + CH - 1
+                                                           uint64_t proof_stride, uint32_t row0) {
+  __shared__ uint32_t stage[64][TR_STAGE];
+  __shared__ uint8_t lut[4 * TR_SPAN_MAX + 16];
+  const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t;
+  const int r_first = (int)(row0 + blockIdx.y * R), r_end = r_first + R;  // this thread's rows
   const bool live = id < 2u * n_lanes;
   const uint32_t lane = live ? id >> 1 : 0u, k = id & 1u;
-  {
-    const uint32_t p = lane / n, i = lane - p * n;
-    s_base[t] = (uint64_t)p * proof_stride + (uint64_t)((2u * i + k) * TR_LADDER_ROWS) * TR_LADDER_ROW;
-    s_live[t] = live ? 1 : 0;
-  }
+  const uint64_t base = (uint64_t)(lane / n) * proof_stride + (uint64_t)((2u * (lane % n) + k) * TR_LADDER_ROWS) * TR_LADDER_ROW;
+  for (uint32_t i = t; i < 4 * TR_SPAN_MAX + 16; i += 64) lut[i] = i < 4 * TR_SPAN_MAX ? (uint8_t)span_word(i % TR_SPAN_MAX, i / TR_SPAN_MAX) : (uint8_t)0;
   const LadderIn L = ladder_inputs(lane, k, in_target, ed, ed_stride, false);
-  const int32_t* src = pts + (size_t)blockIdx.x * TR_LADDER_ROWS * TR_PT_WORDS * 64u + t;
-  static_assert(CH == 8, "the unrolled schedule below is written for batches of eight rows (17 points)");
-  // point i of batch c: 0 = the accumulator the batch starts from (row CH c - 1's nxt; the identity for c = 0); 1 + 2j / 2 + 2j = dbl / add of row j
-  auto coord = [&](uint32_t c, uint32_t start_bit, int i, int which_coord) -> fe {  // which_coord: 0 X, 1 Y, 2 Z
-    fe v;
-    if (i == 0 && c == 0) { v = which_coord == 0 ? fe_zero() : fe_one(); return v; }
-    const int r = i == 0 ? (int)(CH * c) - 1 : (int)(CH * c) + (i - 1) / 2;
-    const uint32_t which = i == 0 ? start_bit : (uint32_t)((i - 1) & 1);
-    const int32_t* row = src + (size_t)r * TR_PT_WORDS * 64u + (size_t)(which * 30u + (uint32_t)which_coord * 10u) * 64u;
-#pragma unroll
-    for (int l = 0; l < 10; l++) v.v[l] = row[l * 64];
-    return v;
-  };
-  auto start_bit_of = [&](uint32_t c) -> uint32_t { return c ? scalar_bit(L.sc, (int)(CH * c) - 1) : 0u; };
-  // sweep 1: the product of every Z of the GCH batches, suffixes at the batch boundaries to LDS
-  fe inv;
-  {
-    fe tot = fe_one();
-#pragma unroll 1
-    for (int q = GCH - 1; q >= 0; q--) {
-      const uint32_t c = c_first + (uint32_t)q, sb = start_bit_of(c);
-#pragma unroll
-      for (int i = 16; i >= 0; i--) tot = (q == GCH - 1 && i == 16) ? coord(c, sb, 16, 2) : fe_mul(coord(c, sb, i, 2), tot);
-      if (q > 0) {
-#pragma unroll
-        for (int l = 0; l < 10; l++) s_behind[q - 1][l][t] = tot.v[l];
-      }
-    }
-    inv = fe_invert_safegcd(tot);
-  }
+  const int32_t* blk = pts + (size_t)blockIdx.x * TR_LADDER_ROWS * TR_ROW_WORDS;
   const uint32_t z = L.decoded ? 0xffffffffu : 0u;  // an undecodable lane: all-zero rows (Level-1 reports zero points there too)
-  uint32_t accw[16], dblw[16];
+  if (r_first == 0 && live) {  // the head of the ladder: bit_0 | acc_0 = the identity (0, 1)
+    uint64_t* dst = out + base;
+    dst[0] = scalar_bit(L.sc, 0) & z;
+#pragma unroll
+    for (int q = 0; q < 16; q++) dst[1 + q] = q == 8 ? (1u & z) : 0u;
+  }
+  fe inv = fe_invert_safegcd(pt_load(pt_at(blk, r_end - 1, TR_PA), t));  // 1 / P(add of the last row)
+  uint32_t bit_above = r_end < (int)TR_LADDER_ROWS ? scalar_bit(L.sc, r_end) : 0u;
+  const uint32_t out_align = (uint32_t)(reinterpret_cast<uintptr_t>(out) >> 3);  // (lines are 64 bytes of the ADDRESS, not of the element index)
 #pragma unroll 1
-  for (int q = 0; q < GCH; q++) {
-    const uint32_t c = c_first + (uint32_t)q, start_bit = start_bit_of(c);
-    const bool last = q == GCH - 1;
-    fe behind = fe_one();  // product of everything behind this batch
-    if (!last) {
+  for (int r = r_end - 1; r >= r_first; r--) {
+    // a point's four elements are requested together, the second point's while the first is being made affine (the first form loaded each
+    // element where it used it: six exposed memory latencies per row)
+    const fe pd = pt_load(pt_at(blk, r, TR_PD), t), az = pt_load(pt_at(blk, r, TR_AZ), t), ax = pt_load(pt_at(blk, r, TR_AX), t),
+             ay = pt_load(pt_at(blk, r, TR_AY), t);
+    {  // add_r: 1 / Z = inv(P_add) P_dbl, then inv(P_dbl) = inv(P_add) Z
+      uint32_t o[16];
+      const fe zinv = fe_mul(inv, pd);
+      inv = fe_mul(inv, az);
+      fe_to_words(fe_mul(ax, zinv), o);
+      fe_to_words(fe_mul(ay, zinv), o + 8);
 #pragma unroll
-      for (int l = 0; l < 10; l++) behind.v[l] = s_behind[last ? 0 : q][l][t];
+      for (int q = 0; q < 16; q++) stage[t][16 + q] = o[q] & z;
     }
-    fe ck[4];  // suf_4, suf_8, suf_12, suf_16 (each times `behind`)
-    {
-      fe tot = last ? coord(c, start_bit, 16, 2) : fe_mul(coord(c, start_bit, 16, 2), behind);
-      ck[3] = tot;
+    {  // dbl_r: 1 / Z = inv(P_dbl) P_add(r - 1)   (row 0: the empty product)
+      uint32_t o[16];
+      const fe zinv = r > 0 ? fe_mul(inv, pt_load(pt_at(blk, r - 1, TR_PA), t)) : inv;
+      if (r > r_first) inv = fe_mul(inv, pt_load(pt_at(blk, r, TR_DZ), t));
+      fe_to_words(fe_mul(pt_load(pt_at(blk, r, TR_DX), t), zinv), o);
+      fe_to_words(fe_mul(pt_load(pt_at(blk, r, TR_DY), t), zinv), o + 8);
 #pragma unroll
-      for (int i = 15; i >= 1; i--) {
-        tot = fe_mul(coord(c, start_bit, i, 2), tot);
-        if (i == 12) ck[2] = tot;
-        if (i == 8) ck[1] = tot;
-        if (i == 4) ck[0] = tot;
-      }
+      for (int q = 0; q < 16; q++) stage[t][q] = o[q] & z;
+#pragma unroll
+      for (int q = 0; q < 7; q++) stage[t][TR_ST_CARRY + ((r & 1) ? 0 : 7) + q] = o[q] & z;  // (for the flush of the row below)
     }
-    auto affine = [&](int i, const fe& zinv, uint32_t w[16]) {
-      fe_to_words(fe_mul(coord(c, start_bit, i, 0), zinv), w);
-      fe_to_words(fe_mul(coord(c, start_bit, i, 1), zinv), w + 8);
-    };
-    auto emit_point = [&](int i, const fe& zinv) {  // points arrive in order: start, dbl_0, add_0, dbl_1, ...
-      uint32_t w[16];
-      affine(i, zinv, w);
-      if (i == 0) {
-#pragma unroll
-        for (int qq = 0; qq < 16; qq++) accw[qq] = w[qq];
-      } else if (i & 1) {
-#pragma unroll
-        for (int qq = 0; qq < 16; qq++) dblw[qq] = w[qq];
-      } else {
-        const int j = (i - 2) / 2;
-        const uint32_t bit = scalar_bit(L.sc, (int)(CH * c) + j);
-        stage[t][0] = bit & z;
-#pragma unroll
-        for (int qq = 0; qq < 16; qq++) {
-          const uint32_t nx = bit ? w[qq] : dblw[qq];
-          stage[t][1 + qq] = accw[qq] & z;
-          stage[t][17 + qq] = dblw[qq] & z;
-          stage[t][33 + qq] = w[qq] & z;
-          stage[t][49 + qq] = nx & z;
-          accw[qq] = nx;
-        }
-        coop_flush<TR_LADDER_ROW>(stage, s_base, s_live, (uint64_t)(CH * c + j) * TR_LADDER_ROW, out);
-      }
-    };
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const fe z3 = coord(c, start_bit, 4 * g + 3, 2), z2 = coord(c, start_bit, 4 * g + 2, 2), z1 = coord(c, start_bit, 4 * g + 1, 2),
-               z0 = coord(c, start_bit, 4 * g, 2);
-      const fe s3 = fe_mul(z3, ck[g]), s2 = fe_mul(z2, s3), s1 = fe_mul(z1, s2);
-      emit_point(4 * g, fe_mul(inv, s1)); inv = fe_mul(inv, z0);
-      emit_point(4 * g + 1, fe_mul(inv, s2)); inv = fe_mul(inv, z1);
-      emit_point(4 * g + 2, fe_mul(inv, s3)); inv = fe_mul(inv, z2);
-      emit_point(4 * g + 3, fe_mul(inv, ck[g])); inv = fe_mul(inv, z3);
-    }
-    emit_point(16, last ? inv : fe_mul(inv, behind));
-    if (!last) inv = fe_mul(inv, coord(c, start_bit, 16, 2));
+    const uint32_t bit = scalar_bit(L.sc, r);
+    stage[t][TR_ST_BIT] = bit_above & z;  // (an undecodable lane stores zero bits too)
+    // the span of this flush, in elements of the unit: [k_lo, k_hi)
+    const uint64_t U = base + (uint64_t)r * TR_LADDER_ROW + 17u;
+    const uint32_t a = ((uint32_t)U + out_align) & 7u, c = (8u - ((a + 1u) & 7u)) & 7u;
+    const bool top = r == r_end - 1, last = r + 1 == (int)TR_LADDER_ROWS;
+    const uint32_t k_lo = r == r_first ? 0u : (8u - a) & 7u, k_hi = last ? 48u : (top ? 65u : 65u + c);
+    ladder_flush(stage, lut, U + k_lo, (bit & z & 1u) | (uint32_t)(r & 1) << 1 | (live ? 4u : 0u) | k_lo << 3 | (k_hi - k_lo) << 6, out);
+    bit_above = bit;
   }
 }
 
@@ -587,7 +630,7 @@ uint64_t trace_elems(uint32_t kind, uint32_t n) {
   return trace_off_tree(kind, n) + ((kind == 0 ? 2ull : 1ull) * tree_slots(n) + (kind == 0 ? 4ull : 5ull) * 5) * TR_SHA256_2;
 }
 
-size_t trace_tmp_bytes(uint32_t n, uint32_t n_proofs) { return (size_t)((2ull * n_proofs * n + 63) / 64) * 64 * TR_LADDER_ROWS * TR_PT_WORDS * 4; }
+size_t trace_tmp_bytes(uint32_t n, uint32_t n_proofs) { return (size_t)((2ull * n_proofs * n + 63) / 64) * TR_LADDER_ROWS * TR_ROW_WORDS * 4; }
 
 // rows [row0, row1) of every ladder: the chain (pass 1) and, once it is done, the affine rows (pass 2); row0 / row1 multiples of eight
 int launch_trace_ladder_pass1(uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_ed, uint32_t ed_stride, void* d_tmp, uint32_t row0,
@@ -601,19 +644,17 @@ int launch_trace_ladder_pass1(uint32_t n, uint32_t n_proofs, const void* d_targe
 int launch_trace_ladder_pass2(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_ed, uint32_t ed_stride, const void* d_tmp,
                               void* d_out, uint32_t row0, uint32_t row1, void* stream) {
   if (n_proofs == 0) return 0;
-  const uint32_t lanes = n_proofs * n, chunks = (row1 - row0) / CH;
-  // batches per inversion.  Measured per 256-proof batch (ladders): 1 -> 6.80 ms, 2 -> 6.58, 4 -> 8.25, 8 -> 7.47: the inversion is 35 % of the
-  // pass's instructions, but the pass is latency-bound at two waves per SIMD -- a thread that does four batches in a row loses more to the
-  // longer chain and the thinner launch than it saves.  TMX_TRACE_GCH overrides.
-#define TMX_TRACE_P2(G)                                                                                                                        \
-  hipLaunchKernelGGL((k_trace_ladder_pass2<G>), dim3((2 * lanes + 63) / 64, chunks / G), dim3(64), 0, S_(stream), lanes, n,                       \
+  const uint32_t lanes = n_proofs * n, rows = row1 - row0;
+  // rows per inversion (= per thread): the inversion is ~13 k instructions, a row ~3 k; fewer rows = more, shorter threads.  TMX_TRACE_ROWS overrides.
+#define TMX_TRACE_P2(RR)                                                                                                                       \
+  hipLaunchKernelGGL((k_trace_ladder_pass2<RR>), dim3((2 * lanes + 63) / 64, rows / RR), dim3(64), 0, S_(stream), lanes, n,                      \
                      reinterpret_cast<const uint8_t*>(d_target), reinterpret_cast<const uint8_t*>(d_ed), ed_stride,                             \
-                     reinterpret_cast<const int32_t*>(d_tmp), reinterpret_cast<uint64_t*>(d_out), trace_elems(kind, n), row0 / CH)
-  static const int g_env = std::getenv("TMX_TRACE_GCH") ? std::atoi(std::getenv("TMX_TRACE_GCH")) : 2;
-  if (g_env >= 8 && chunks % 8 == 0) TMX_TRACE_P2(8);
-  else if (g_env >= 4 && chunks % 4 == 0) TMX_TRACE_P2(4);
-  else if (g_env >= 2 && chunks % 2 == 0) TMX_TRACE_P2(2);
-  else TMX_TRACE_P2(1);
+                     reinterpret_cast<const int32_t*>(d_tmp), reinterpret_cast<uint64_t*>(d_out), trace_elems(kind, n), row0)
+  static const int r_env = std::getenv("TMX_TRACE_ROWS") ? std::atoi(std::getenv("TMX_TRACE_ROWS")) : 16;
+  if (r_env >= 64 && rows % 64 == 0) TMX_TRACE_P2(64);
+  else if (r_env >= 32 && rows % 32 == 0) TMX_TRACE_P2(32);
+  else if (r_env >= 16 && rows % 16 == 0) TMX_TRACE_P2(16);
+  else TMX_TRACE_P2(8);
 #undef TMX_TRACE_P2
   return (int)hipGetLastError();
 }

@@ -29,7 +29,10 @@ while sz > 1:
     tn += sz
 secs = {"ladders": (1, n * 2 * 256 * 65), "sha512": (2, n * 2880), "sha256": (4, n * 2 * 576), "match": (8, n * n), "tree": (16, 2 * tn * 1152),
         "header": (32, 20 * 1152), "all": (63, te)}
+only = os.environ.get("SECTIONS")
 for name, (mask, elems) in secs.items():
+    if only and name not in only.split(","):
+        continue
     for _ in range(2):
         ctx.trace_rows_device(KIND_SKIP, P, d[1].data_ptr(), d[2].data_ptr(), tr.data_ptr(), mask, s.cuda_stream)
     torch.cuda.synchronize()
