@@ -105,7 +105,7 @@ __device__ __forceinline__ fe tiny_base(const uint8_t* __restrict__ rec, const i
 #pragma unroll
   for (int k = 0; k < PERP; k++) {
     const int i = i0 + k;
-    const int d = i < i1 ? key_digit<W>(e, i) : 0;
+    const int d = i < i1 ? key_digit_v<W>(e, i) : 0;
     dg[k] = d;
     const int m = d == 0 ? 0 : (d < 0 ? -d : d) - 1;
     const int32_t* src = qtable + ((size_t)((i < C::NW ? i : C::NW - 1) * C::HALF + m) * 4 + cached_component(q, d < 0)) * 10;
@@ -141,7 +141,7 @@ __device__ __forceinline__ fe tiny_walk(const uint32_t* h_lds, const int32_t* __
 #pragma unroll
   for (int k = 0; k < PERP; k++) {
     const int i = i0 + k;
-    const int d = i < i1 ? key_digit<KW>(e, i) : 0;
+    const int d = i < i1 ? key_digit_v<KW>(e, i) : 0;
     dg[k] = d;
     const int m = d == 0 ? 0 : (d < 0 ? -d : d) - 1;
     const int32_t* src = tab + (size_t)((i < C::NW ? i : C::NW - 1) * C::HALF + m) * 40 + 10 * cached_component(q, d < 0);
@@ -410,6 +410,7 @@ __device__ __forceinline__ void tiny_lane(const TinyEd& A, uint32_t lane, TinyLa
 #pragma unroll
     for (int w = 0; w < 8; w++) h[w] = L.h[w];
     recode_signed16(h, e);
+    const u32x8 ev = vec8_of(e);
     const uint32_t Ak = f16::from_limbs10(reinterpret_cast<const int32_t*>(L.key + KEY_OFF_A / 4 + 10 * c.row), c);
     uint32_t tab[8], Q;
     tab[0] = f16::to_cached(Ak, c);
@@ -420,6 +421,7 @@ __device__ __forceinline__ void tiny_lane(const TinyEd& A, uint32_t lane, TinyLa
       Q = f16::add_cached(Q, tab[0], c);
       tab[j] = f16::to_cached(Q, c);
     }
+    const u32x8 tabv = vec8_of(tab);
     uint32_t acc = (c.k == 0 && (c.row == 1 || c.row == 2)) ? 1u : 0u;
 #pragma unroll 1
     for (int i = 63; i >= 0; i--) {
@@ -427,12 +429,10 @@ __device__ __forceinline__ void tiny_lane(const TinyEd& A, uint32_t lane, TinyLa
         uint32_t V = f16::with_xy(acc, c);
         V = f16::dbl(V, acc, c); V = f16::dbl(V, acc, c); V = f16::dbl(V, acc, c); f16::dbl(V, acc, c);
       }
-      const int d = __builtin_amdgcn_readfirstlane(digit_at(e, i));
+      const int d = __builtin_amdgcn_readfirstlane(digit_at(ev, i));
       if (d != 0) {
         const int m = (d < 0 ? -d : d) - 1;
-        uint32_t qq = tab[0];
-#pragma unroll
-        for (int j = 1; j < 8; j++) qq = m == j ? tab[j] : qq;
+        uint32_t qq = tabv[m & 7];
         if (d < 0) qq = f16::neg_cached(qq, c);
         acc = f16::add_cached(acc, qq, c);
       }

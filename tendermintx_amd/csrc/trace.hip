@@ -247,12 +247,13 @@ __global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t n_lanes, uin
   fe inv = fe_invert_safegcd(pt_load(pt_at(blk, r_end - 1, TR_PA), t));  // 1 / P(add of the last row)
   uint32_t bit_above = r_end < (int)TR_LADDER_ROWS ? scalar_bit(L.sc, r_end) : 0u;
   const uint32_t out_align = (uint32_t)(reinterpret_cast<uintptr_t>(out) >> 3);  // (lines are 64 bytes of the ADDRESS, not of the element index)
+  // A point's four elements are requested together (the first form loaded each where it used it: six exposed memory latencies per row), and
+  // those of the NEXT row's first point before this row's stores go out: vmcnt counts loads and stores in order, so a load issued behind the
+  // 65 stores of a flush cannot be waited for without waiting for the stores -- the first point of a row is made affine while they drain.
+  fe pd = pt_load(pt_at(blk, r_end - 1, TR_PD), t), az = pt_load(pt_at(blk, r_end - 1, TR_AZ), t), ax = pt_load(pt_at(blk, r_end - 1, TR_AX), t),
+     ay = pt_load(pt_at(blk, r_end - 1, TR_AY), t);
 #pragma unroll 1
   for (int r = r_end - 1; r >= r_first; r--) {
-    // a point's four elements are requested together, the second point's while the first is being made affine (the first form loaded each
-    // element where it used it: six exposed memory latencies per row)
-    const fe pd = pt_load(pt_at(blk, r, TR_PD), t), az = pt_load(pt_at(blk, r, TR_AZ), t), ax = pt_load(pt_at(blk, r, TR_AX), t),
-             ay = pt_load(pt_at(blk, r, TR_AY), t);
     {  // add_r: 1 / Z = inv(P_add) P_dbl, then inv(P_dbl) = inv(P_add) Z
       uint32_t o[16];
       const fe zinv = fe_mul(inv, pd);
@@ -272,6 +273,10 @@ __global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t n_lanes, uin
       for (int q = 0; q < 16; q++) stage[t][q] = o[q] & z;
 #pragma unroll
       for (int q = 0; q < 7; q++) stage[t][TR_ST_CARRY + ((r & 1) ? 0 : 7) + q] = o[q] & z;  // (for the flush of the row below)
+    }
+    if (r > r_first) {
+      pd = pt_load(pt_at(blk, r - 1, TR_PD), t); az = pt_load(pt_at(blk, r - 1, TR_AZ), t); ax = pt_load(pt_at(blk, r - 1, TR_AX), t);
+      ay = pt_load(pt_at(blk, r - 1, TR_AY), t);
     }
     const uint32_t bit = scalar_bit(L.sc, r);
     stage[t][TR_ST_BIT] = bit_above & z;  // (an undecodable lane stores zero bits too)
