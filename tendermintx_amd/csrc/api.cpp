@@ -327,6 +327,7 @@ struct tmx_ctx {
   void *d_in_proofs = nullptr, *d_in_targets = nullptr, *d_in_trusteds = nullptr, *d_out = nullptr;
   uint64_t d_out_elems = 0;
   hipEvent_t ev_trace[17] = {};  // ladder segments done (up to 16) + [16] the side stream's pass 2 done
+  hipEvent_t ev_trace_rest[2] = {};  // the other sections beside the ladders: fork, join
   void* d_trace_tmp = nullptr;  // projective ladder points between the two passes of the Level-2 ladder kernels (allocated on first use)
   void* d_pack = nullptr;  // dense / narrowed rows for tmx_witness_batch_opts (allocated on first use)
   uint64_t d_pack_bytes = 0;
@@ -984,6 +985,8 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   if (c->ev_leaves) (void)hipEventDestroy(c->ev_leaves);
   if (c->ev_hash_clean) (void)hipEventDestroy(c->ev_hash_clean);
   if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
+  for (hipEvent_t e : c->ev_trace_rest)
+    if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_trace)
     if (e) (void)hipEventDestroy(e);
   if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
@@ -1249,6 +1252,19 @@ int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const
   const uint8_t* edr = reinterpret_cast<const uint8_t*>(c->d_tl) + TL_OFF_ED;
   const uint32_t n = c->cfg.n_max;
   int rc = 0;
+  // The other sections (0.6 ms of short, memory-bound kernels per 256-proof batch) beside the ladders, whose first segment is one
+  // latency-bound wave per SIMD with nothing else on the chip: on the low-priority side stream, joined at the end (all sections 5.6 -> 5.3 ms)
+  const bool rest_aside = (sections & TMX_TRACE_LADDERS) && (sections & ~(uint32_t)TMX_TRACE_LADDERS);
+  if (rest_aside) {
+    for (auto& e : c->ev_trace_rest)
+      if (!e) HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCK(c, hipEventRecord(c->ev_trace_rest[0], s));
+    HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_trace_rest[0], 0));
+    const TraceLevel1 L1 = {reinterpret_cast<const uint8_t*>(c->d_tl) + TL_OFF_LT, c->d_lr, c->d_nodes_t, c->d_nodes_r, c->d_pf, TL_STRIDE};
+    rc = launch_trace_rest((uint32_t)kind, n, n_proofs, d_targets, d_trusteds, L1, d_trace_out, sections, c->side3);
+    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_trace launch: ") + hipGetErrorString((hipError_t)rc));
+    HIPCK(c, hipEventRecord(c->ev_trace_rest[1], c->side3));
+  }
   if (sections & TMX_TRACE_LADDERS) {
     // The chain (pass 1: 1024 latency-bound waves per 256 proofs) in segments on the caller's stream; the affine rows of a segment (pass 2)
     // follow on the side stream while the next segment is being doubled.  Measured per 256-proof batch at N = 128 (round 4 kernels): two
@@ -1272,7 +1288,8 @@ int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const
       HIPCK(c, hipEventRecord(c->ev_trace[16], c->side));
     }
   }
-  if (!rc && (sections & ~(uint32_t)TMX_TRACE_LADDERS)) {
+  if (!rc && rest_aside) HIPCK(c, hipStreamWaitEvent(s, c->ev_trace_rest[1], 0));
+  if (!rc && (sections & ~(uint32_t)TMX_TRACE_LADDERS) && !rest_aside) {
     const TraceLevel1 L1 = {reinterpret_cast<const uint8_t*>(c->d_tl) + TL_OFF_LT, c->d_lr, c->d_nodes_t, c->d_nodes_r, c->d_pf, TL_STRIDE};
     rc = launch_trace_rest((uint32_t)kind, n, n_proofs, d_targets, d_trusteds, L1, d_trace_out, sections, s);
   }

@@ -35,16 +35,27 @@ __device__ __constant__ const uint32_t T_BX[8] = {0x8f25d51au, 0xc9562d60u, 0x95
 __device__ __constant__ const uint32_t T_BY[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u};
 
 
-// flush `nv` staged values of every thread's current row group: value e of thread j goes to out[base[j] + off + e]
+// flush NV (even) staged values of every thread's current row group: value e of thread j goes to out[base[j] + off + e].  One thread's group
+// per store instruction, 16 bytes per lane (lanes 0 .. NV / 2 - 1; a group starts at any multiple of 8 bytes: wide global stores need dword
+// alignment only); the group's address and whether it exists come from the owning lane's registers as SGPRs (v_readlane with a constant
+// lane) -- the first form read both from LDS in front of every store and needed two store instructions per group of 72.
+typedef uint64_t tr_u64x2 __attribute__((ext_vector_type(2)));
+typedef tr_u64x2 __attribute__((aligned(8))) tr_u64x2_a8;
 template <int NV>
 __device__ __forceinline__ void coop_flush(const uint32_t (*stage)[NV + 1], const uint64_t* s_base, const uint8_t* s_live, uint64_t off, uint64_t* __restrict__ out) {
+  static_assert(NV % 2 == 0 && NV <= 128, "two values per lane");
   __syncthreads();
   const uint32_t tid = threadIdx.x;
-#pragma unroll 1
+  const uint64_t my_dst = s_base[tid] + off;
+  const uint32_t dst_lo = (uint32_t)my_dst, dst_hi = (uint32_t)(my_dst >> 32), live = s_live[tid];
+  const uint32_t e = 2u * tid < (uint32_t)NV ? 2u * tid : 0u;  // (lanes beyond the group read its first pair and store nothing)
+#pragma unroll 8
   for (int j = 0; j < 64; j++) {
-    if (!s_live[j]) continue;
-    uint64_t* dst = out + s_base[j] + off;
-    for (uint32_t e = tid; e < (uint32_t)NV; e += 64) __builtin_nontemporal_store((uint64_t)stage[j][e], dst + e);
+    if (!__builtin_amdgcn_readlane((int)live, j)) continue;
+    uint64_t* dst = out + ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dst_lo, j) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dst_hi, j) << 32));
+    tr_u64x2 v;
+    v.x = stage[j][e]; v.y = stage[j][e + 1];
+    if (2u * tid < (uint32_t)NV) __builtin_nontemporal_store(v, reinterpret_cast<tr_u64x2_a8*>(dst + e));
   }
   __syncthreads();
 }
@@ -331,13 +342,16 @@ __global__ __launch_bounds__(64) void k_trace_sha512(uint32_t n_lanes, uint32_t 
 #pragma unroll
     for (int q = 0; q < 8; q++) v[q] = st[q];
     const bool used = blk < nblk;
+    // (sixteen rounds = four flushes per trip: the schedule index i mod 16 is then a constant and the select chains below fold away)
 #pragma unroll 1
-    for (int g = 0; g < 80 / RPF; g++) {
+    for (int g4 = 0; g4 < 80 / RPF; g4 += 16 / RPF) {
+#pragma unroll
+     for (int g = g4; g < g4 + 16 / RPF; g++) {
 #pragma unroll
       for (int u = 0; u < RPF; u++) {
         const int i = g * RPF + u;
         uint64_t wt;
-        {  // rolling schedule; the index is dynamic (the loop over g is not unrolled), so go through a select chain
+        {  // rolling schedule, written for any i: a select chain that is constant-folded with i mod 16 known
           uint64_t w16 = w[0], w15 = w[0], w7 = w[0], w2 = w[0];
 #pragma unroll
           for (int q = 0; q < 16; q++) {
@@ -360,6 +374,7 @@ __global__ __launch_bounds__(64) void k_trace_sha512(uint32_t n_lanes, uint32_t 
         for (int q = 0; q < 8; q++) { o[2 + 2 * q] = used ? (uint32_t)v[q] : 0u; o[3 + 2 * q] = used ? (uint32_t)(v[q] >> 32) : 0u; }
       }
       coop_flush<NV>(stage, s_base, s_live, (uint64_t)(blk * 80u + g * RPF) * TR_SHA512_ROW, out);
+     }
     }
 #pragma unroll
     for (int q = 0; q < 8; q++) st[q] += v[q];
