@@ -248,6 +248,7 @@ struct Knobs {
   int warm_schedule = -1;    // TMX_SCHEDULE=warm|cold: the EdDSA schedule for resident / new keys (default: by what the last launch saw)
   int phase1_max = -1;       // TMX_PHASE1_MAX=<lanes>: up to that many lanes the warm schedule runs s*B as a role of the hash launch (default 16384: 128 proofs at N = 128)
   bool proof_roles = true;   // TMX_PROOF_ROLES=0: k_proof as one workgroup per proof (the round-3 kernel) instead of four role workgroups
+  int hash_first = -1;       // TMX_HASH_FIRST=0|1: warm schedule with the hash role in front of the dedup (which moves to side2); default: see run_eddsa
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
 static Knobs read_knobs() {
@@ -264,6 +265,7 @@ static Knobs read_knobs() {
   k.tiny = (v = std::getenv("TMX_TINY")) ? (v[0] != '0' ? 1 : 0) : -1;
   k.proof_roles = !((v = std::getenv("TMX_PROOF_ROLES")) && v[0] == '0');
   if ((v = std::getenv("TMX_PHASE1_MAX"))) k.phase1_max = std::atoi(v);
+  k.hash_first = (v = std::getenv("TMX_HASH_FIRST")) ? (v[0] != '0' ? 1 : 0) : -1;
   return k;
 }
 
@@ -675,6 +677,9 @@ static int32_t check_batch_args(tmx_ctx* c, int32_t kind, uint32_t n_proofs, con
 //                              needs) fills the machine beside the 512 latency-bound waves of the hash role
 //   tiny (<= 512 lanes):       s: dedup -> phase 1 -> walk of the resident keys -> [table-free lanes + their finish, on side2] -> finish;
 //                              never waits for tables: the tables of new keys are built on side2 for the next call
+#ifndef TMX_HASH_FIRST_MAX
+#define TMX_HASH_FIRST_MAX 16384u  // measured: 64 / 128 proofs at N = 128 -3 %, 256 +2 %, 1024 +6 % (the dedup beside the hash role on a full chip)
+#endif
 static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_ed, uint32_t ed_stride, hipStream_t s) {
   const Knobs& K = c->knobs;
   EdQuad Q;
@@ -697,14 +702,31 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   hipError_t e;
   // (the launch's hash table was cleared, and the cache committed, on side2 by the previous launch.  Skipping this wait when s has
   // already waited for side2's tail was measured: k_proof 0.45 -> 0.52 ms beside it and the step +2 % at 256 proofs -- the packet stays.)
-  if ((e = hipStreamWaitEvent(s, c->ev_hash_clean, 0)) != hipSuccess) return (int)e;
+  // Hash first (warm schedule, not tiny): SHA-512 mod l reads the lane records only, so it opens the chain on s while the dedup (cache
+  // probe) and the key pipeline run on side2 -- the walk waits for side2's ev_part[0] either way.  s then carries no wait for
+  // ev_hash_clean either (side2 is in order behind its own tail of the previous launch).
+  const bool hash_first = warm && !tiny && n_lanes != 0 && (K.hash_first >= 0 ? K.hash_first != 0 : n_lanes <= TMX_HASH_FIRST_MAX);
   // Events that mark the end of one kernel ride on its dispatch (completion signal) instead of a record packet behind it: on the
   // chain every packet is latency.  `x` = that is on and the kernel really is launched.
   const bool x = K.ext_events && n_lanes != 0, xt = x && Q.mode != 0 && Q.kc.cap != 0;
-  int rc = launch_ed_dedup(Q, s, x ? c->ev_fork2 : nullptr);
-  if (rc) return rc;
-  if (!x && (e = hipEventRecord(c->ev_fork2, s)) != hipSuccess) return (int)e;
-  if ((e = hipStreamWaitEvent(c->side2, c->ev_fork2, 0)) != hipSuccess) return (int)e;
+  int rc = 0;
+  const bool sb_with_hash_hf = K.phase1_max >= 0 ? n_lanes <= (uint32_t)K.phase1_max : n_lanes <= 16384;
+  if (hash_first) {
+    if ((e = hipEventRecord(c->ev_fork2, s)) != hipSuccess) return (int)e;
+    rc = sb_with_hash_hf ? launch_ed_phase1(Q, s, x ? c->ev_hash : nullptr) : launch_ed_hash(Q, s, x ? c->ev_hash : nullptr);
+    if (rc) return rc;
+    if (!x && (e = hipEventRecord(c->ev_hash, s)) != hipSuccess) return (int)e;
+    c->ev_hash_recorded = true;
+    if ((e = hipStreamWaitEvent(c->side2, c->ev_fork2, 0)) != hipSuccess) return (int)e;
+    rc = launch_ed_dedup(Q, c->side2, nullptr);
+    if (rc) return rc;
+  } else {
+    if ((e = hipStreamWaitEvent(s, c->ev_hash_clean, 0)) != hipSuccess) return (int)e;
+    rc = launch_ed_dedup(Q, s, x ? c->ev_fork2 : nullptr);
+    if (rc) return rc;
+    if (!x && (e = hipEventRecord(c->ev_fork2, s)) != hipSuccess) return (int)e;
+    if ((e = hipStreamWaitEvent(c->side2, c->ev_fork2, 0)) != hipSuccess) return (int)e;
+  }
   rc = launch_ed_keys(Q, c->side2, x ? c->ev_keys : nullptr);
   if (rc) return rc;
   if (!x && (e = hipEventRecord(c->ev_keys, c->side2)) != hipSuccess) return (int)e;
@@ -733,10 +755,12 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     // (a few thousand lanes: s*B as a role of the same launch as the hash, as in a tiny launch -- on side2 it started behind three empty
     // launches, ran into the walk and held the finish back by ~50 us: profiles/r04_p32_timeline.txt)
     const bool sb_with_hash = tiny || (K.phase1_max >= 0 ? n_lanes <= (uint32_t)K.phase1_max : n_lanes <= 16384);
-    rc = sb_with_hash ? launch_ed_phase1(Q, s, x ? c->ev_hash : nullptr) : launch_ed_hash(Q, s, x ? c->ev_hash : nullptr);
-    if (rc) return rc;
-    if (!x && (e = hipEventRecord(c->ev_hash, s)) != hipSuccess) return (int)e;
-    c->ev_hash_recorded = true;
+    if (!hash_first) {
+      rc = sb_with_hash ? launch_ed_phase1(Q, s, x ? c->ev_hash : nullptr) : launch_ed_hash(Q, s, x ? c->ev_hash : nullptr);
+      if (rc) return rc;
+      if (!x && (e = hipEventRecord(c->ev_hash, s)) != hipSuccess) return (int)e;
+      c->ev_hash_recorded = true;
+    }
     // (up to 256 lanes the finish of the table-free lanes is fused into their kernel: at 512 the 512 waves of the fused kernel slow
     // k_proof, the longer of the two there, by more than they save)
     const bool fuse = tiny && n_lanes <= 256;

@@ -37,19 +37,24 @@ __device__ __forceinline__ uint64_t gl_sub_lazy(uint64_t a, uint64_t b) {  // an
   return d - (borrow ? GL_EPS : 0ull);  // after a borrow d >= 2^64 - (p - 1) > EPS: cannot wrap again
 }
 __device__ __forceinline__ uint64_t gl_mul_lazy(uint64_t a, uint64_t b) {  // any a, b -> any
-  // 128-bit product from four 32 x 32 -> 64 multiply-adds (v_mad_u64_u32), no addend can overflow:
-  //   p00 = a0 b0;  p01 = a0 b1 + hi(p00);  p10 = a1 b0 + lo(p01);  p11 = a1 b1 + hi(p01) + hi(p10)
+  // 128-bit product: four independent 32 x 32 -> 64 products (v_mad_u64_u32, no addend) summed by 32-bit carry chains.  (Chaining the
+  // products through the multiply-add's 64-bit addend -- p01 = a0 b1 + hi(p00) ... -- costs two v_mov per addend: a high half has to
+  // move to the even register of an aligned pair whose odd register is zero; this form has no move at all: 22 instead of 25 VALU
+  // instructions per product, profiles/r04_poseidon_isa.txt.)
   const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
-  const uint64_t p00 = (uint64_t)a0 * b0;
-  const uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);
-  const uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
-  const uint64_t hi = (uint64_t)a1 * b1 + ((p01 >> 32) + (p10 >> 32));
-  const uint64_t lo = (p10 << 32) | (uint32_t)p00;
-  const uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;  // x = lo + 2^64 hi_lo + 2^96 hi_hi = lo + (2^32 - 1) hi_lo - hi_hi
+  const uint64_t p00 = (uint64_t)a0 * b0, p01 = (uint64_t)a0 * b1, p10 = (uint64_t)a1 * b0, p11 = (uint64_t)a1 * b1;
+  unsigned c1, c2, c3, c4, c5;
+  const uint32_t mid_lo = __builtin_addc((uint32_t)p01, (uint32_t)p10, 0u, &c1);
+  const uint32_t mid_hi = __builtin_addc((uint32_t)(p01 >> 32), (uint32_t)(p10 >> 32), c1, &c2);  // p01 + p10 = mid_lo + 2^32 mid_hi + 2^64 c2
+  const uint32_t l_hi = __builtin_addc((uint32_t)(p00 >> 32), mid_lo, 0u, &c3);
+  const uint32_t hi_lo = __builtin_addc((uint32_t)p11, mid_hi, c3, &c4);
+  const uint32_t hi_hi = __builtin_addc((uint32_t)(p11 >> 32), c2, c4, &c5);  // (the product is < 2^128: c5 = 0)
+  const uint64_t lo = ((uint64_t)l_hi << 32) | (uint32_t)p00;
+  // x = lo + 2^64 hi_lo + 2^96 hi_hi = lo + (2^32 - 1) hi_lo - hi_hi
   unsigned long long t0, r;
   const bool borrow = __builtin_usubll_overflow(lo, hi_hi, &t0);
   t0 -= borrow ? GL_EPS : 0ull;  // the wrap added 2^64 = p + EPS
-  const uint64_t t1 = (hi_lo << 32) - hi_lo;
+  const uint64_t t1 = (uint64_t)hi_lo * 0xffffffffu;
   const bool carry = __builtin_uaddll_overflow(t0, t1, &r);
   r += carry ? GL_EPS : 0ull;
   return r;

@@ -49,14 +49,17 @@ constexpr uint32_t HDR_SIZE = 1136, PR_STRIDE = 2336, PR_OFF_BLOCK_A = 0, PR_OFF
 // look-up tables with one u32 per element (lut_field below); every section reads ONE source buffer
 enum : uint32_t { SRC_TARGET = 0, SRC_TRUSTED = 1, SRC_TL = 2, SRC_LR = 3, SRC_PF = 4, SRC_COUNT = 5 };
 // One entry describes a bit-field of a 4-byte-aligned dword of the source record (every multi-byte field of the records is 4-aligned):
-//   width [31:27] (1, 8, 16; 0 = the whole dword) | first bit [26:22] | aligned byte offset [21:0]
-// so the kernel is one aligned dword load + one v_bfe_u32 per element (its offset / width operands only look at their low five bits,
-// so both come from the entry by a plain shift), with no branch on the field type.
+//   left shift [31:24] | right shift [23:16] | aligned byte offset within the record [15:0]      field = (dword << lsh) >> rsh
+// (a field of `width` bits at bit `pos`: lsh = 32 - pos - width, rsh = 32 - width; the whole dword: 0, 0).  Byte-aligned sub-fields of the
+// entry are operand selects (SDWA) of the two shifts and of the address add, so an element is one aligned dword load + two shifts with no
+// instruction spent on decoding the entry and no branch on the field type.  (Rounds 1-3: width | first bit | 22-bit offset and a
+// v_bfe_u32: two shifts for its operands and a select for the whole-dword case -- five instructions per element instead of two.)
 enum : uint32_t { W_BIT = 1, W_U8 = 8, W_U16 = 16, W_U32 = 0 };
-constexpr uint32_t LUT_OFF_MASK = 0x3fffffu;
+constexpr uint32_t LUT_OFF_MASK = 0xffffu;
 constexpr uint32_t lut_field(uint32_t width, uint32_t byte_off, uint32_t bit_in_byte) {
-  return (width << 27) | ((8 * (byte_off & 3u) + bit_in_byte) << 22) | (byte_off & ~3u);
+  return ((32u - (8u * (byte_off & 3u) + bit_in_byte) - (width ? width : 32u)) << 24) | ((32u - (width ? width : 32u)) << 16) | (byte_off & ~3u);
 }
+static_assert(TL_STRIDE <= LUT_OFF_MASK && PF_STRIDE <= LUT_OFF_MASK && VR_STRIDE <= LUT_OFF_MASK && PR_STRIDE <= LUT_OFF_MASK, "record offsets are 16-bit in the LUT");
 
 enum : uint32_t { SEC_LUT = 0, SEC_LINEAR_T = 1, SEC_LINEAR_R = 2 };
 struct Section {

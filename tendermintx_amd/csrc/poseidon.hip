@@ -31,14 +31,22 @@ __device__ __forceinline__ uint64_t pos_sbox(uint64_t x) {
   const uint64_t x2 = gl_mul_lazy(x, x), x3 = gl_mul_lazy(x2, x), x4 = gl_mul_lazy(x2, x2);
   return gl_mul_lazy(x3, x4);
 }
-// lo + 2^32 hi for lo, hi < 2^63: any representative
+// lo + 2^32 hi for lo, hi < 2^54: any representative.  2^32 hi = 2^32 h_lo + 2^64 h_hi = 2^32 h_lo + (2^32 - 1) h_hi: the second term
+// rides on ONE v_mad_u64_u32 with lo as its addend (< 2^22 2^32 + 2^54: no carry), the first is an add into the high word whose carry
+// (2^64 = 2^32 - 1) is folded back once -- after a carry the sum is < 2^55, so it cannot wrap again.
 __device__ __forceinline__ uint64_t pos_fold(uint64_t lo, uint64_t hi) {
-  const uint64_t h_lo = hi & GL_EPS, h_hi = hi >> 32;
-  const uint64_t t = gl_add_lazy(lo, gl_canon(h_lo << 32));     // (h_lo << 32 may be >= p by at most 2^32 - 1... canonical second operand)
-  return gl_add_lazy(t, (h_hi << 32) - h_hi);                    // h_hi < 2^31: (2^32 - 1) h_hi < p
+  const uint32_t h_lo = (uint32_t)hi, h_hi = (uint32_t)(hi >> 32);
+  const uint64_t t = (uint64_t)h_hi * 0xffffffffu + lo;
+  uint32_t n_hi;
+  const bool carry = __builtin_uadd_overflow((uint32_t)(t >> 32), h_lo, &n_hi);
+  const uint64_t s = ((uint64_t)n_hi << 32) | (uint32_t)t;
+  return s + (carry ? GL_EPS : 0ull);
 }
+// MDS layer.  SMALL (every entry < 2^16): the diagonal entry joins the circulant's entry 0 on the scalar unit, and the NEXT round's
+// constants enter as one more multiply-add per accumulator (rc_lo * inj, rc_hi * inj with inj = 1 in a VGPR; 0 behind the last round) --
+// two instructions per element instead of a 64-bit modular add (five).  Bounds: 13 products < 2^17 2^32 and one < 2^32: < 2^53.
 template <bool SMALL>
-__device__ __forceinline__ void pos_mds(uint64_t (&s)[12], const PosConsts& K) {
+__device__ __forceinline__ void pos_mds(uint64_t (&s)[12], const PosConsts& K, const uint64_t* __restrict__ rc_next, bool more, uint32_t inj) {
   uint64_t o[12];
   if (SMALL) {
     uint32_t lo[12], hi[12];
@@ -46,11 +54,11 @@ __device__ __forceinline__ void pos_mds(uint64_t (&s)[12], const PosConsts& K) {
     for (int i = 0; i < 12; i++) { lo[i] = (uint32_t)s[i]; hi[i] = (uint32_t)(s[i] >> 32); }
 #pragma unroll
     for (int r = 0; r < 12; r++) {
-      const uint32_t d = (uint32_t)K.diag[r];
-      uint64_t al = (uint64_t)d * lo[r], ah = (uint64_t)d * hi[r];
+      const uint64_t rcn = rc_next[r];
+      uint64_t al = (uint64_t)(uint32_t)rcn * inj, ah = (uint64_t)(uint32_t)(rcn >> 32) * inj;
 #pragma unroll
       for (int i = 0; i < 12; i++) {
-        const uint32_t c = (uint32_t)K.circ[i];  // < 2^16: twelve products of 48 bits + one more fit 64 bits with room
+        const uint32_t c = (uint32_t)K.circ[i] + (i == 0 ? (uint32_t)K.diag[r] : 0u);
         al += (uint64_t)c * lo[(i + r) % 12];
         ah += (uint64_t)c * hi[(i + r) % 12];
       }
@@ -62,7 +70,7 @@ __device__ __forceinline__ void pos_mds(uint64_t (&s)[12], const PosConsts& K) {
       uint64_t acc = gl_mul(s[r], K.diag[r]);
 #pragma unroll
       for (int i = 0; i < 12; i++) acc = gl_add(acc, gl_mul(s[(i + r) % 12], K.circ[i]));
-      o[r] = acc;
+      o[r] = more ? gl_add_lazy(acc, rc_next[r]) : acc;  // (uniform)
     }
   }
 #pragma unroll
@@ -70,18 +78,20 @@ __device__ __forceinline__ void pos_mds(uint64_t (&s)[12], const PosConsts& K) {
 }
 template <bool SMALL>
 __device__ __forceinline__ void pos_permute(uint64_t (&s)[12], const PosConsts& K) {
+  uint32_t vone;
+  asm volatile("v_mov_b32 %0, 1" : "=v"(vone));  // (opaque to the optimizer: rc * 1 has to stay a multiply-add)
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_add_lazy(s[i], K.rc[i]);
 #pragma unroll 1
   for (int r = 0; r < (int)POS_ROUNDS; r++) {
-    const uint64_t* rc = K.rc + r * 12;
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add_lazy(s[i], rc[i]);
     if (r < (int)POS_RF / 2 || r >= (int)(POS_RF / 2 + POS_RP)) {  // (uniform: a scalar branch)
 #pragma unroll
       for (int i = 0; i < 12; i++) s[i] = pos_sbox(s[i]);
     } else {
       s[0] = pos_sbox(s[0]);
     }
-    pos_mds<SMALL>(s, K);
+    const bool more = r + 1 < (int)POS_ROUNDS;
+    pos_mds<SMALL>(s, K, K.rc + (more ? r + 1 : r) * 12, more, more ? vone : 0u);
   }
 }
 
