@@ -589,7 +589,11 @@ KNOBS = [
     # round 4: the small path (two launches for <= 2048 lanes) and k_proof as role workgroups, off / forced / combined with the others
     {"TMX_TINY": "0"}, {"TMX_PROOF_ROLES": "0"}, {"TMX_TINY": "0", "TMX_PROOF_ROLES": "0"}, {"TMX_TINY": "1", "TMX_SCHEDULE": "cold"},
     {"TMX_TINY": "1", "TMX_KEY_CACHE": "0"}, {"TMX_TINY": "1", "TMX_EXT_EVENTS": "0"}, {"TMX_TINY": "1", "TMX_KEY_CACHE_KEYS": "40"},
-    {"TMX_PHASE1_MAX": "0"}, {"TMX_PHASE1_MAX": "1000000", "TMX_TINY": "0"}]
+    {"TMX_PHASE1_MAX": "0"}, {"TMX_PHASE1_MAX": "1000000", "TMX_TINY": "0"},
+    # the warm schedule opening with the hash role (dedup + key pipeline on side2): off, forced onto a launch with new keys, with the
+    # hash role as a kernel of its own, with record packets instead of completion signals
+    {"TMX_HASH_FIRST": "0"}, {"TMX_HASH_FIRST": "1", "TMX_SCHEDULE": "warm"}, {"TMX_HASH_FIRST": "1", "TMX_PHASE1_MAX": "0"},
+    {"TMX_HASH_FIRST": "1", "TMX_EXT_EVENTS": "0", "TMX_TINY": "0"}]
 
 
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
