@@ -248,6 +248,7 @@ struct Knobs {
   int warm_schedule = -1;    // TMX_SCHEDULE=warm|cold: the EdDSA schedule for resident / new keys (default: by what the last launch saw)
   int phase1_max = -1;       // TMX_PHASE1_MAX=<lanes>: up to that many lanes the warm schedule runs s*B as a role of the hash launch (default 16384: 128 proofs at N = 128)
   bool proof_roles = true;   // TMX_PROOF_ROLES=0: k_proof as one workgroup per proof (the round-3 kernel) instead of four role workgroups
+  int p1_early = -1;         // TMX_P1_EARLY=0|1|2: D.1a behind k_proof's sections on the side stream (1: on a capped grid, 2: full grid) instead of behind k_ed_fin (default: capped, from 131072 lanes)
   int hash_first = -1;       // TMX_HASH_FIRST=0|1: warm schedule with the hash role in front of the dedup (which moves to side2); default: see run_eddsa
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
@@ -266,6 +267,7 @@ static Knobs read_knobs() {
   k.proof_roles = !((v = std::getenv("TMX_PROOF_ROLES")) && v[0] == '0');
   if ((v = std::getenv("TMX_PHASE1_MAX"))) k.phase1_max = std::atoi(v);
   k.hash_first = (v = std::getenv("TMX_HASH_FIRST")) ? (v[0] != '0' ? 1 : 0) : -1;
+  k.p1_early = (v = std::getenv("TMX_P1_EARLY")) && v[0] >= '0' && v[0] <= '2' ? v[0] - '0' : -1;
   return k;
 }
 
@@ -486,10 +488,11 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // D.1a (the byte fields of the per-target-lane derived values: a quarter of the row) needs k_proof and phase 1, not k_ed_fin: behind
   // k_proof's sections on the side stream, i.e. while the table walk and the finish run.  Measured (round 2): -6.3 % step at 1024
   // proofs x 128; +-0.5 % at 256 and 64, +1 ... +2 % at 512 proofs (and +7 % at 256 with a warm key cache): on from 131072 lanes
-  const bool p1_early = leaves_first || small_tail || (K.ser_split && c->ev_hash_recorded && (uint64_t)n_proofs * n >= 131072);
+  const bool p1_early = leaves_first || small_tail ||
+                        (K.ser_split && c->ev_hash_recorded && (K.p1_early >= 0 ? K.p1_early != 0 : (uint64_t)n_proofs * n >= 131072));
   if (p1_early && !leaves_first && !small_tail) {
     HIPCK(c, hipStreamWaitEvent(c->side, c->ev_hash, 0));
-    if ((st0 = serialize(prog.mask_p1, c->side, beside_chain_wgs))) return st0;
+    if ((st0 = serialize(prog.mask_p1, c->side, K.p1_early == 2 ? 0u : beside_chain_wgs))) return st0;
   }
   HIPCK(c, hipStreamWaitEvent(c->side, c->ev_join3, 0));  // ev_join = both low-priority streams done
   HIPCK(c, hipEventRecord(c->ev_join, c->side));
