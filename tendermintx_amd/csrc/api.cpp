@@ -1614,7 +1614,8 @@ static int32_t ntt_run(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const void* 
     return TMX_OK;
   }
   // N = N1 N2, N1 = 2^a (pass A, strided), N2 = 2^b (pass B, contiguous).  (Round 3 re-measured the split and the tile sizes at 2^16 / 2^20 /
-  // 2^22: a = ceil(log_n / 2) -1 / -2 / +1 and tiles of 2^12 / 2^13 / 2^14 elements everywhere -- the balanced split with the tile rule below wins each.)
+  // 2^22: a = ceil(log_n / 2) -1 / -2 / +1 and tiles of 2^12 / 2^13 / 2^14 elements everywhere -- the balanced split with the tile rule below wins each; round 4 re-measured pass A's tile alone at
+  // 2^16 / 2^20 / 2^22: 0.161 / 4.53 / 2.11 ms with 2^12, 0.169 / 3.29 / 1.71 with 2^13, 0.191 / 3.32 / 1.24 with 2^14 -- the rule's choices.)
   const uint32_t a = (log_n + 1) / 2, b = log_n - a;
   const uint64_t N = (uint64_t)1 << log_n, N1 = (uint64_t)1 << a, N2 = (uint64_t)1 << b;
   // tiles of the two strided passes: T >= 8 sub-transforms side by side (runs of >= 64 B along the unit-stride dimension; with T = 4 at

@@ -79,6 +79,29 @@ def test_injected_constants_and_general_mds(tmx, oracle):
                 oracle.poseidon_set_constants(pm.grain_constants(), pm.MDS_CIRC, pm.MDS_DIAG)
 
 
+def test_small_mds_path_at_its_bounds(tmx, oracle):
+    """the 32-bit-limb MDS layer (every entry < 2^16) with every entry at 2^16 - 1, the diagonal too (it joins the circulant's entry 0:
+    2^17 - 2), every round constant p - 1 (they enter as multiply-adds of the row accumulators) and all-ones states: the largest
+    accumulators the layer can see (< 2^54, poseidon.hip: pos_fold) -- against the Python model and the C oracle"""
+    import poseidon_model as pm
+    rc, circ, diag = [P - 1] * 360, [65535] * 12, [65535] * 12
+    s = _states(5, 200)
+    s[5] = 2**64 - 1
+    s[6] = 2**32 - 1
+    s[7] = (2**64 - 1) ^ (2**32 - 1)
+    with tmx.Context(4, b"celestia") as c:
+        c.poseidon_set_constants(rc, circ, diag)
+        got = c.poseidon_permute(s)
+        model = pm.Poseidon(rc, circ, diag)
+        for i in (0, 1, 2, 5, 6, 7, 199):
+            assert [int(x) for x in got[i]] == model.permute([int(x) % P for x in s[i]]), i
+        try:
+            oracle.poseidon_set_constants(rc, circ, diag)
+            assert np.array_equal(got, oracle.poseidon_permute(s))
+        finally:
+            oracle.poseidon_set_constants(pm.grain_constants(), pm.MDS_CIRC, pm.MDS_DIAG)
+
+
 @pytest.mark.parametrize("log_n,n_cols,cap", [(3, 3, 0), (4, 4, 2), (6, 5, 1), (8, 8, 4), (10, 9, 0), (9, 20, 3), (12, 135, 4), (5, 300, 5)])
 def test_merkle_vs_oracle(ctx, oracle, log_n, n_cols, cap):
     import torch
