@@ -347,7 +347,8 @@ struct tmx_ctx {
   // Poseidon: round constants | MDS circulant | MDS diagonal, host copy and device copy (uploaded on first use / on change)
   std::vector<uint64_t> pos_consts;
   void* d_pos_consts = nullptr;
-  bool pos_dirty = true, pos_mds_small = true;
+  bool pos_dirty = true;
+  int pos_mode = POS_MODE_SMALL;  // poseidon.h POS_MODE_*: chosen from the MDS entries when the tables are uploaded
   bool pos_rc_injected = false;  // round constants came from tmx_poseidon_set_constants (the defaults are NOT plonky2's table)
 };
 
@@ -1762,20 +1763,73 @@ static void poseidon_default_constants(std::vector<uint64_t>& k) {
   static const uint64_t circ[POS_T] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
   for (uint32_t i = 0; i < POS_T; i++) { k[POS_ROUNDS * POS_T + i] = circ[i]; k[POS_ROUNDS * POS_T + POS_T + i] = i == 0 ? 8 : 0; }
 }
+// The device buffer behind the caller-visible constants: the tables of the merged partial rounds (poseidon.h), from the MDS matrix over
+// the integers.  Returns the mode the kernels can run in.
+static int poseidon_tables(const std::vector<uint64_t>& k, std::vector<uint64_t>& dev) {
+  const unsigned __int128 P = 0xffffffff00000001ull;
+  dev.assign(POS_CONST_WORDS_EXT, 0);
+  std::copy(k.begin(), k.begin() + POS_CONST_WORDS, dev.begin());
+  const uint64_t* circ = &k[POS_ROUNDS * POS_T];
+  const uint64_t* diag = circ + POS_T;
+  for (uint32_t i = 0; i < 2 * POS_T; i++)
+    if (circ[i] >> 16) return POS_MODE_GENERAL;
+  // M[r][j] = circ[(j - r) mod 12] + (j == r) diag[r]   (out[r] = sum_i circ[i] s[(i + r) mod 12] + diag[r] s[r], poseidon.hip: pos_mds)
+  unsigned __int128 M[3][POS_T][POS_T];
+  const unsigned __int128 LIM = (unsigned __int128)1 << 26;
+  for (uint32_t r = 0; r < POS_T; r++)
+    for (uint32_t j = 0; j < POS_T; j++) M[0][r][j] = circ[(j + POS_T - r) % POS_T] + (j == r ? diag[r] : 0);
+  for (int e = 1; e < 3; e++)
+    for (uint32_t r = 0; r < POS_T; r++)
+      for (uint32_t j = 0; j < POS_T; j++) {
+        unsigned __int128 a = 0;
+        for (uint32_t t = 0; t < POS_T; t++) a += M[e - 1][r][t] * M[0][t][j];
+        if (a >= LIM) return POS_MODE_SMALL;  // (entries only grow: M^3 decides)
+        M[e][r][j] = a;
+      }
+  for (uint32_t r = 0; r < POS_T; r++)
+    for (uint32_t j = 0; j < POS_T; j++)
+      if (M[0][r][j] >= LIM) return POS_MODE_SMALL;
+  uint32_t* U = reinterpret_cast<uint32_t*>(&dev[POS_X_U32]);
+  for (uint32_t i = 0; i < POS_T; i++) {
+    U[POS_U_R1 + i] = (uint32_t)M[0][0][i]; U[POS_U_R2 + i] = (uint32_t)M[1][0][i];
+    U[POS_U_C2 + i] = (uint32_t)M[1][i][0]; U[POS_U_C1 + i] = (uint32_t)M[0][i][0];
+    for (uint32_t j = 0; j < POS_T; j++) U[POS_U_M3 + POS_T * i + j] = (uint32_t)M[2][i][j];
+  }
+  auto mat_vec = [&](int e, const uint64_t* v, uint64_t* out) {  // out = M^(e+1) v mod p
+    for (uint32_t r = 0; r < POS_T; r++) {
+      unsigned __int128 a = 0;
+      for (uint32_t j = 0; j < POS_T; j++) a = (a + M[e][r][j] * v[j]) % P;
+      out[r] = (uint64_t)a;
+    }
+  };
+  for (uint32_t g = 0; g < POS_MERGE_GROUPS; g++) {
+    const uint32_t r = POS_MERGE_FIRST + 3 * g;
+    const uint64_t *rc1 = &k[(r + 1) * POS_T], *rc2 = &k[(r + 2) * POS_T], *rc3 = &k[(r + 3) * POS_T];
+    uint64_t m_rc1[POS_T], m2_rc1[POS_T], m_rc2[POS_T];
+    mat_vec(0, rc1, m_rc1); mat_vec(1, rc1, m2_rc1); mat_vec(0, rc2, m_rc2);
+    uint64_t* G = &dev[POS_X_GROUPS + g * POS_X_GROUP_WORDS];
+    G[0] = rc1[0];
+    G[1] = (uint64_t)(((unsigned __int128)m_rc1[0] + rc2[0]) % P);
+    for (uint32_t i = 0; i < POS_T; i++) G[2 + i] = (uint64_t)(((unsigned __int128)m2_rc1[i] + m_rc2[i] + rc3[i]) % P);
+  }
+  return POS_MODE_MERGE3;
+}
 static int32_t poseidon_ready(tmx_ctx* c, hipStream_t s) {
   if (c->pos_consts.empty()) poseidon_default_constants(c->pos_consts);
   if (!c->d_pos_consts) {
     HIPCK(c, hipSetDevice(c->cfg.device));
-    HIPCK(c, hipMalloc(&c->d_pos_consts, POS_CONST_WORDS * 8));
+    HIPCK(c, hipMalloc(&c->d_pos_consts, POS_CONST_WORDS_EXT * 8));
     c->pos_dirty = true;
   }
   if (c->pos_dirty) {
-    HIPCK(c, hipMemcpyAsync(c->d_pos_consts, c->pos_consts.data(), POS_CONST_WORDS * 8, hipMemcpyHostToDevice, s));
-    HIPCK(c, hipStreamSynchronize(s));  // once per change of the tables: later calls may come on another stream
+    std::vector<uint64_t> dev;
+    int mode = poseidon_tables(c->pos_consts, dev);
+    if (const char* v = std::getenv("TMX_POSEIDON_MERGE"))  // TMX_POSEIDON_MERGE=0: one dense layer per partial round (times the merged form against it)
+      if (v[0] == '0' && mode == POS_MODE_MERGE3) mode = POS_MODE_SMALL;
+    HIPCK(c, hipMemcpyAsync(c->d_pos_consts, dev.data(), POS_CONST_WORDS_EXT * 8, hipMemcpyHostToDevice, s));
+    HIPCK(c, hipStreamSynchronize(s));  // once per change of the tables: later calls may come on another stream (and `dev` is a local)
     c->pos_dirty = false;
-    c->pos_mds_small = true;
-    for (uint32_t i = POS_ROUNDS * POS_T; i < POS_CONST_WORDS; i++)
-      if (c->pos_consts[i] >> 16) c->pos_mds_small = false;
+    c->pos_mode = mode;
   }
   return TMX_OK;
 }
@@ -1816,11 +1870,11 @@ int32_t tmx_poseidon_merkle_device(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, 
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
   int32_t st = poseidon_ready(c, s);
   if (st) return st;
-  int rc = launch_poseidon_leaves(c->d_pos_consts, c->pos_mds_small, log_n, n_cols, d_cols, d_levels, s);
+  int rc = launch_poseidon_leaves(c->d_pos_consts, c->pos_mode, log_n, n_cols, d_cols, d_levels, s);
   uint64_t* cur = d_levels;
   for (uint32_t k = 0; !rc && k + cap_height < log_n; k++) {
     const uint64_t cnt = 1ull << (log_n - k);
-    rc = launch_poseidon_level(c->d_pos_consts, c->pos_mds_small, cnt / 2, cur, cur + 4 * cnt, s);
+    rc = launch_poseidon_level(c->d_pos_consts, c->pos_mode, cnt / 2, cur, cur + 4 * cnt, s);
     cur += 4 * cnt;
   }
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_poseidon launch: ") + hipGetErrorString((hipError_t)rc));
@@ -1837,7 +1891,7 @@ int32_t tmx_poseidon_permute(tmx_ctx* c, uint32_t n, const uint64_t* in, uint64_
   hipError_t e = hipMalloc(&d_in, (size_t)n * 96);
   if (e == hipSuccess) e = hipMalloc(&d_out, (size_t)n * 96);
   if (e == hipSuccess) e = hipMemcpy(d_in, in, (size_t)n * 96, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = (hipError_t)launch_poseidon_permute(c->d_pos_consts, c->pos_mds_small, n, d_in, d_out, c->side2);
+  if (e == hipSuccess) e = (hipError_t)launch_poseidon_permute(c->d_pos_consts, c->pos_mode, n, d_in, d_out, c->side2);
   if (e == hipSuccess) e = hipStreamSynchronize(c->side2);
   if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * 96, hipMemcpyDeviceToHost);
   if (d_in) (void)hipFree(d_in);
