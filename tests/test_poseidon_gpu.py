@@ -102,6 +102,31 @@ def test_small_mds_path_at_its_bounds(tmx, oracle):
             oracle.poseidon_set_constants(pm.grain_constants(), pm.MDS_CIRC, pm.MDS_DIAG)
 
 
+def test_field_product_rare_borrow_path(tmx, oracle):
+    """gl_mul_lazy corrects `lo - hi_hi` behind a wave-wide branch (lo < hi_hi happens once in 2^32 random products, so random states
+    never take it).  With zero round constants the first S-box squares the state elements themselves: 2^48, 3 * 2^48, 2^63 and friends
+    square to lo = 0 with hi_hi != 0 -- lanes that borrow beside lanes that do not, in one wave and in a wave where every lane borrows."""
+    import poseidon_model as pm
+    rc = [0] * 360
+    s = _states(6, 192)
+    special = [2**48, 3 * 2**48, 2**63, 2**56 + 2**48, P - 2**48, 2**48 + 1, 2**62, 5 * 2**52]
+    for k, v in enumerate(special):
+        s[8 + k] = v                      # wave 0: a few borrowing lanes among random ones
+    s[128:192] = 2**48                    # wave 2: every lane borrows
+    s[128:192, 3] = np.arange(64, dtype=np.uint64) * np.uint64(2**48)
+    with tmx.Context(4, b"celestia") as c:
+        c.poseidon_set_constants(rc, pm.MDS_CIRC, pm.MDS_DIAG)
+        got = c.poseidon_permute(s)
+        model = pm.Poseidon(rc, pm.MDS_CIRC, pm.MDS_DIAG)
+        for i in (0, 8, 9, 10, 11, 12, 13, 14, 15, 128, 150, 191):
+            assert [int(x) for x in got[i]] == model.permute([int(x) % P for x in s[i]]), i
+        try:
+            oracle.poseidon_set_constants(rc, pm.MDS_CIRC, pm.MDS_DIAG)
+            assert np.array_equal(got, oracle.poseidon_permute(s))
+        finally:
+            oracle.poseidon_set_constants(pm.grain_constants(), pm.MDS_CIRC, pm.MDS_DIAG)
+
+
 @pytest.mark.parametrize("log_n,n_cols,cap", [(3, 3, 0), (4, 4, 2), (6, 5, 1), (8, 8, 4), (10, 9, 0), (9, 20, 3), (12, 135, 4), (5, 300, 5)])
 def test_merkle_vs_oracle(ctx, oracle, log_n, n_cols, cap):
     import torch
