@@ -339,6 +339,7 @@ struct tmx_ctx {
   // Goldilocks NTT: twiddle tables per transform size (built on first use), scratch for the four-step split / LDE
   void* d_ntt_w[TMX_NTT_MAX_LOG + 1] = {};
   void* d_ntt_m[2][TMX_NTT_MAX_LOG + 1] = {};  // four-step twiddle matrices omega_N^(+- n2 k1) (forward, inverse), built on first use
+  void* d_lde_s[TMX_NTT_MAX_LOG + 1] = {};  // coset-LDE scale vectors S[i] = shift^i / N per column length (built on first use, dropped with the domain)
   void* d_ntt_tmp = nullptr;
   size_t ntt_tmp_bytes = 0;
   // NTT domain: primitive 2^32-th root of unity and coset shift.  Default: the constants recalled from plonky2's GoldilocksField
@@ -994,6 +995,8 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   for (auto& dir : c->d_ntt_m)
     for (void* m : dir)
       if (m) (void)hipFree(m);
+  for (void* v : c->d_lde_s)
+    if (v) (void)hipFree(v);
   if (c->d_ntt_tmp) (void)hipFree(c->d_ntt_tmp);
   if (c->d_pos_consts) (void)hipFree(c->d_pos_consts);
   for (auto& set : c->ev)
@@ -1582,8 +1585,10 @@ static uint64_t gl_pow_host(uint64_t b, uint64_t e) {
   return (uint64_t)r;
 }
 // columns of 2^log_n elements, column c at element c * col_stride; `tmp` (n_cols << log_n elements) only for log_n > 11
+// post_vec (or null): the outputs are multiplied by post_vec[k] INSTEAD of the inverse transform's 1 / N (a vector that carries it);
+// nonzero (or 0): only the first `nonzero` inputs of every column are non-zero and read (a multiple of N2 for a two-pass transform).
 static int32_t ntt_run(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const void* d_in, uint64_t in_stride, void* d_out, uint64_t out_stride,
-                       void* tmp, bool inverse, hipStream_t s) {
+                       void* tmp, bool inverse, hipStream_t s, const void* post_vec = nullptr, uint64_t nonzero = 0) {
   void* w = nullptr;
   int32_t st = ntt_table(c, log_n, s, &w);
   if (st) return st;
@@ -1609,8 +1614,8 @@ static int32_t ntt_run(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const void* 
     P.tiles_per_col = (n_cols + T - 1) / T; P.n_sub = n_cols;
     P.col_stride_in = 0; P.t_stride_in = in_stride; P.j_stride_in = 1;
     P.col_stride_out = 0; P.t_stride_out = out_stride; P.j_stride_out = 1;
-    P.scale = n_inv;
-    rc = launch_ntt_pass(P, 1, d_in, d_out, w, nullptr, s);
+    P.scale = post_vec ? 1 : n_inv; P.post_twiddle = post_vec ? 1 : 0; P.tm_t_stride = 0; P.j_nonzero = (uint32_t)nonzero;
+    rc = launch_ntt_pass(P, 1, d_in, d_out, w, post_vec, s);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_ntt_tile launch: ") + hipGetErrorString((hipError_t)rc));
     return TMX_OK;
   }
@@ -1626,7 +1631,8 @@ static int32_t ntt_run(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const void* 
   P.log_l = a; P.log_t = std::min(tile_log_of(a) - a, b); P.n_sub = N2; P.tiles_per_col = (uint32_t)(N2 >> P.log_t);
   P.col_stride_in = in_stride; P.t_stride_in = 1; P.j_stride_in = N2;
   P.col_stride_out = N; P.t_stride_out = 1; P.j_stride_out = N2;
-  P.post_twiddle = 1; P.scale = 1;
+  P.post_twiddle = 1; P.scale = 1; P.tm_t_stride = P.t_stride_out;
+  P.j_nonzero = nonzero ? (uint32_t)(nonzero >> b) : 0u;  // input n1 N2 + n2 is zero from n1 = nonzero / N2 on
   void* m = nullptr;
   st = ntt_matrix(c, log_n, b, inverse, w, s, &m);
   if (st) return st;
@@ -1635,8 +1641,8 @@ static int32_t ntt_run(tmx_ctx* c, uint32_t log_n, uint32_t n_cols, const void* 
   P.log_l = b; P.log_t = std::min(tile_log_of(b) - b, a); P.n_sub = N1; P.tiles_per_col = (uint32_t)(N1 >> P.log_t);
   P.col_stride_in = N; P.t_stride_in = N2; P.j_stride_in = 1;
   P.col_stride_out = out_stride; P.t_stride_out = 1; P.j_stride_out = N1;
-  P.post_twiddle = 0; P.scale = n_inv;
-  rc = launch_ntt_pass(P, n_cols, tmp, d_out, w, nullptr, s);
+  P.post_twiddle = post_vec ? 1 : 0; P.scale = post_vec ? 1 : n_inv; P.tm_t_stride = P.t_stride_out; P.j_nonzero = 0;
+  rc = launch_ntt_pass(P, n_cols, tmp, d_out, w, post_vec, s);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_ntt_tile launch: ") + hipGetErrorString((hipError_t)rc));
   return TMX_OK;
 }
@@ -1646,9 +1652,13 @@ int32_t tmx_ntt_set_domain(tmx_ctx* c, uint64_t root_2_32, uint64_t coset_shift)
   const uint64_t P = 0xffffffff00000001ull;
   if (root_2_32 >= P || coset_shift == 0 || coset_shift >= P || gl_pow_host(root_2_32, 1ull << 31) != P - 1)
     return fail(c, TMX_ERR_BAD_ARG, "root_2_32 must be a primitive 2^32-th root of unity of the Goldilocks field, coset_shift a non-zero element");
-  if (root_2_32 != c->ntt_root) {  // the twiddle tables belong to the old root
+  if (root_2_32 != c->ntt_root || coset_shift != c->ntt_shift) {  // the tables belong to the old domain
     HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, hipDeviceSynchronize());
+    for (auto& v : c->d_lde_s)
+      if (v) { (void)hipFree(v); v = nullptr; }
+  }
+  if (root_2_32 != c->ntt_root) {
     for (auto& w : c->d_ntt_w)
       if (w) { (void)hipFree(w); w = nullptr; }
     for (auto& dir : c->d_ntt_m)
@@ -1686,6 +1696,24 @@ int32_t tmx_lde_goldilocks_device(tmx_ctx* c, uint32_t log_n, uint32_t log_blowu
   if (st) return st;
   uint64_t* coef = reinterpret_cast<uint64_t*>(c->d_ntt_tmp);
   uint64_t* tmp = coef + (size_t)n_cols * M;
+  // Fused form: the inverse transform's last pass multiplies coefficient i by S[i] = shift^i / N (one vector per column length, built
+  // once), and the forward transform does not read the zero padding -- its pass A loads the first N / N2 inputs of every strided
+  // sub-transform only.  (Before: k_lde_expand rewrote all M slots, a gl_pow per coefficient, and pass A read them back: 17 of the ~55 GB
+  // an 8x LDE of 2^15-row columns moved.)  A split whose N2 exceeds N keeps the padded form.
+  const uint32_t b_fwd = log_m > 11 ? log_m - (log_m + 1) / 2 : 0;
+  const bool fused = !(std::getenv("TMX_LDE_FUSED") && std::getenv("TMX_LDE_FUSED")[0] == '0') && log_n >= b_fwd;
+  if (fused) {
+    if (!c->d_lde_s[log_n]) {
+      HIPCK(c, hipSetDevice(c->cfg.device));
+      HIPCK(c, hipMalloc(&c->d_lde_s[log_n], (size_t)8 << log_n));
+      int rc = launch_lde_scale_table(c->d_lde_s[log_n], log_n, c->ntt_shift, gl_pow_host(N, 0xffffffff00000001ull - 2), s);
+      if (rc) return fail(c, TMX_ERR_HIP, std::string("k_lde_scale_table launch: ") + hipGetErrorString((hipError_t)rc));
+      HIPCK(c, hipStreamSynchronize(s));  // once per size: later calls may come on another stream
+    }
+    st = ntt_run(c, log_n, n_cols, d_in, N, coef, M, tmp, true, s, c->d_lde_s[log_n]);  // scaled coefficients into the first N slots of every M-slot column
+    if (st) return st;
+    return ntt_run(c, log_m, n_cols, coef, M, d_out, M, tmp, false, s, nullptr, N);
+  }
   st = ntt_run(c, log_n, n_cols, d_in, N, coef, M, tmp, true, s);  // coefficients into the first N slots of every M-slot column
   if (st) return st;
   int rc = launch_lde_expand(coef, log_n, log_m, n_cols, c->ntt_shift, s);  // c_i shift^i, zero padding

@@ -190,7 +190,7 @@ constexpr uint32_t brev_bits(uint32_t v, int bits) {
 
 template <int LOG_L, int LOG_T, bool CONTIG, bool FULL>
 __device__ __forceinline__ void tile_load(uint64_t* __restrict__ s, const uint64_t* __restrict__ src, uint32_t t0, uint32_t n_sub, uint32_t ts,
-                                          uint32_t js) {
+                                          uint32_t js, uint32_t j_nz) {
   using M = TileMap<LOG_L, LOG_T, CONTIG>;
   constexpr uint32_t SS = sub_stride<LOG_L, LOG_T>();
   const uint32_t tl = M::t_of(threadIdx.x), j0 = M::j_of(threadIdx.x);
@@ -199,7 +199,7 @@ __device__ __forceinline__ void tile_load(uint64_t* __restrict__ s, const uint64
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     const uint64_t step = (uint64_t)M::dt(i) * ts + (uint64_t)M::dj(i) * js;  // wave-uniform
-    v[i] = (FULL || t0 + tl + M::dt(i) < n_sub) ? p[step] : 0;
+    v[i] = ((FULL || t0 + tl + M::dt(i) < n_sub) && j0 + M::dj(i) < j_nz) ? p[step] : 0;  // (j_nz = 2^32 - 1 when every input is read)
   }
   uint64_t* q = s + tl * SS + lds_pad(j0);
 #pragma unroll
@@ -221,7 +221,8 @@ __device__ __forceinline__ void tile_store(const uint64_t* __restrict__ s, uint6
   const uint64_t* q = s + tl * SS + (CONTIG ? lds_pad(kr0) : 17u * r0);
   // the four-step twiddles omega_N^(n2 k1) come from a matrix in the layout of this pass's output column: same offsets, same coalescing
   const uint64_t in_col = (uint64_t)(t0 + tl) * ts + (uint64_t)k0 * js;
-  const uint64_t* tm = TM + in_col;
+  const uint64_t tts = P.tm_t_stride;  // (the four-step matrix: = ts, same offsets as the output; a vector indexed by k alone: 0)
+  const uint64_t* tm = TM + ((uint64_t)(t0 + tl) * tts + (uint64_t)k0 * js);
   uint64_t v[16], w[16];
   uint32_t dk[16];
 #pragma unroll
@@ -229,7 +230,7 @@ __device__ __forceinline__ void tile_store(const uint64_t* __restrict__ s, uint6
     dk[i] = CONTIG ? M::dj(i) : (brev_bits(i, 4) << (LOG_L - 4));
     const uint64_t step = (uint64_t)M::dt(i) * ts + (uint64_t)dk[i] * js;
     v[i] = q[CONTIG ? M::dt(i) * SS + pad_off(brev_bits(M::dj(i), LOG_L)) : (uint32_t)i];
-    w[i] = (post && (FULL || t0 + tl + M::dt(i) < n_sub)) ? tm[step] : 1;
+    w[i] = (post && (FULL || t0 + tl + M::dt(i) < n_sub)) ? tm[(uint64_t)M::dt(i) * tts + (uint64_t)dk[i] * js] : 1;
   }
   uint64_t* o = dst + in_col;
 #pragma unroll
@@ -269,10 +270,11 @@ __global__ __launch_bounds__(1024) void k_ntt_tile(NttPass P, const uint64_t* __
   {
     const uint32_t ts = (uint32_t)P.t_stride_in, js = (uint32_t)P.j_stride_in;
     const bool contiguous = js == 1;
+    const uint32_t j_nz = P.j_nonzero ? P.j_nonzero : 0xffffffffu;
     if constexpr (FIXED) {
       constexpr int LT = FIXED ? LOG_T : 0;
-      if (contiguous) { if (full) tile_load<LOG_L, LT, true, true>(s, src, t0, n_sub, ts, js); else tile_load<LOG_L, LT, true, false>(s, src, t0, n_sub, ts, js); }
-      else { if (full) tile_load<LOG_L, LT, false, true>(s, src, t0, n_sub, ts, js); else tile_load<LOG_L, LT, false, false>(s, src, t0, n_sub, ts, js); }
+      if (contiguous) { if (full) tile_load<LOG_L, LT, true, true>(s, src, t0, n_sub, ts, js, j_nz); else tile_load<LOG_L, LT, true, false>(s, src, t0, n_sub, ts, js, j_nz); }
+      else { if (full) tile_load<LOG_L, LT, false, true>(s, src, t0, n_sub, ts, js, j_nz); else tile_load<LOG_L, LT, false, false>(s, src, t0, n_sub, ts, js, j_nz); }
     } else {
       uint64_t v[16];
 #pragma unroll
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(1024) void k_ntt_tile(NttPass P, const uint64_t* __
         const uint32_t e = threadIdx.x + i * blockDim.x;
         uint32_t t, j;
         if (contiguous) { j = e & (L - 1); t = e >> LOG_L; } else { t = e & (T - 1); j = e >> log_t; }
-        const bool live = e < tile && t0 + t < n_sub;
+        const bool live = e < tile && t0 + t < n_sub && j < j_nz;
         const uint64_t off = (uint64_t)(t0 + t) * ts + (uint64_t)j * js;
         v[i] = live ? src[off] : 0;
       }
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(1024) void k_ntt_tile(NttPass P, const uint64_t* __
         const bool live = e < tile && t0 + t < n_sub;
         const uint32_t kr = LOG_L ? (__brev(k) >> (32 - (LOG_L ? LOG_L : 1))) : 0u;
         v[i] = live ? s[lds_pad(t * L + kr)] : 0;
-        w[i] = (post && live) ? M[(uint64_t)(t0 + t) * ts + (uint64_t)k * js] : 1;  // omega_N^(n2 k1), in the layout of the output column
+        w[i] = (post && live) ? M[(uint64_t)(t0 + t) * P.tm_t_stride + (uint64_t)k * js] : 1;  // omega_N^(n2 k1), in the layout of the output column
       }
 #pragma unroll
       for (int i = 0; i < 16; i++) {
@@ -347,6 +349,18 @@ __global__ __launch_bounds__(256) void k_lde_expand(uint64_t* __restrict__ buf, 
   buf[e] = gl_mul(buf[e], gl_pow(shift, i));
 }
 
+// S[i] = scale * shift^i: what the last pass of the inverse transform of a coset LDE multiplies coefficient i by
+__global__ __launch_bounds__(256) void k_lde_scale_table(uint64_t* __restrict__ S, uint32_t log_n, uint64_t shift, uint64_t scale) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >> log_n) return;
+  S[i] = gl_mul(scale, gl_pow(shift, i));
+}
+int launch_lde_scale_table(void* d_s, uint32_t log_n, uint64_t shift, uint64_t scale, void* stream) {
+  const uint64_t n = 1ull << log_n;
+  hipLaunchKernelGGL(k_lde_scale_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<uint64_t*>(d_s), log_n, shift, scale);
+  return (int)hipGetLastError();
+}
 int launch_ntt_table(void* d_w, uint32_t log_n, uint64_t root_2_32, void* stream) {
   const uint64_t half = log_n ? (1ull << (log_n - 1)) : 1ull;
   hipLaunchKernelGGL(k_ntt_table, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),

@@ -127,7 +127,10 @@ def test_ntt_every_size_and_odd_column_counts(env, log_n):
             assert np.array_equal(_to_host(out), oc.ntt(x, inverse=inverse)), (log_n, cols, inverse)
 
 
-@pytest.mark.parametrize("log_n,log_blowup,cols", [(0, 1, 2), (3, 3, 3), (8, 2, 5), (10, 3, 2), (12, 1, 3), (13, 3, 1)])
+# (round 4: the scale vector rides on the inverse transform's last pass and the forward transform skips the zero padding -- one-pass and
+# two-pass shapes of either transform, many columns (the fixed-shape tile kernels), and a split whose N2 exceeds N: the padded form)
+@pytest.mark.parametrize("log_n,log_blowup,cols", [(0, 1, 2), (3, 3, 3), (8, 2, 5), (10, 3, 2), (12, 1, 3), (13, 3, 1), (11, 3, 70), (15, 3, 9),
+                                                   (4, 8, 3), (6, 6, 17), (9, 2, 33), (12, 3, 16)])
 def test_lde_matches_oracle(env, log_n, log_blowup, cols):
     torch, ctx, oc = env
     rng = np.random.default_rng(50 * log_n + log_blowup)
