@@ -10,6 +10,15 @@ namespace tmx {
 constexpr uint64_t GL_P = 0xffffffff00000001ull, GL_EPS = 0xffffffffull;
 
 __device__ __forceinline__ uint64_t gl_canon(uint64_t x) { return x >= GL_P ? x - GL_P : x; }
+// The same for a value that is "any representative" out of the lazy forms below: x >= p needs the high word to be all ones, once in 2^32
+// values -- one compare and a wave-wide branch instead of a compare, two selects and a 64-bit subtract in every butterfly.
+__device__ __forceinline__ uint64_t gl_canon_rare(uint64_t x) {
+  if (__builtin_amdgcn_ballot_w64(x >= GL_P)) {
+    asm volatile("; gl_canon_rare: x >= p");  // (keeps the block a branch target: if-converted, it is the plain form again)
+    x = gl_canon(x);
+  }
+  return x;
+}
 __device__ __forceinline__ uint64_t gl_add(uint64_t a, uint64_t b) {  // a, b < p
   unsigned long long s;
   const bool carry = __builtin_uaddll_overflow(a, b, &s);

@@ -82,7 +82,7 @@ __device__ __forceinline__ void dft_stage(uint64_t (&x)[1 << R]) {
     if constexpr ((K & (1 << hb)) == 0) {
       constexpr int k2 = K | (1 << hb), pos = K & ((1 << hb) - 1);
       constexpr int S = (96 * pos) >> hb;  // omega_(2 h)^pos = 2^(96 pos / h), h = 2^hb
-      const uint64_t a = x[K], c = gl_canon(x[k2]);
+      const uint64_t a = x[K], c = gl_canon_rare(x[k2]);
       x[K] = gl_add_lazy(a, c);
       x[k2] = gl_mul_pow2_or_id<S>(gl_sub_lazy(a, c));
     }
@@ -238,7 +238,7 @@ __device__ __forceinline__ void tile_store(const uint64_t* __restrict__ s, uint6
     uint64_t r = v[i];
     if (post) r = gl_mul_lazy(r, w[i]);
     if (scaled) r = gl_mul_lazy(r, P.scale);
-    r = gl_canon(r);
+    r = gl_canon_rare(r);
     const uint64_t step = (uint64_t)M::dt(i) * ts + (uint64_t)dk[i] * js;
     if (FULL || t0 + tl + M::dt(i) < n_sub) o[step] = r;
   }
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(1024) void k_ntt_tile(NttPass P, const uint64_t* __
         uint64_t r = v[i];
         if (post) r = gl_mul_lazy(r, w[i]);
         if (scaled) r = gl_mul_lazy(r, P.scale);
-        r = gl_canon(r);
+        r = gl_canon_rare(r);
         if (live) dst[(uint64_t)(t0 + t) * ts + (uint64_t)k * js] = r;
       }
     }
