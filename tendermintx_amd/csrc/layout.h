@@ -59,7 +59,9 @@ constexpr uint32_t LUT_OFF_MASK = 0xffffu;
 constexpr uint32_t lut_field(uint32_t width, uint32_t byte_off, uint32_t bit_in_byte) {
   return ((32u - (8u * (byte_off & 3u) + bit_in_byte) - (width ? width : 32u)) << 24) | ((32u - (width ? width : 32u)) << 16) | (byte_off & ~3u);
 }
-static_assert(TL_STRIDE <= LUT_OFF_MASK && PF_STRIDE <= LUT_OFF_MASK && VR_STRIDE <= LUT_OFF_MASK && PR_STRIDE <= LUT_OFF_MASK, "record offsets are 16-bit in the LUT");
+static_assert(TL_STRIDE <= LUT_OFF_MASK && PF_STRIDE <= LUT_OFF_MASK && VR_STRIDE <= LUT_OFF_MASK && PR_STRIDE <= LUT_OFF_MASK && HR_STRIDE <= LUT_OFF_MASK &&
+                  LANE_STRIDE <= LUT_OFF_MASK,
+              "record offsets are 16-bit in the LUT (and record strides 24-bit multiplicands in serialize_pair)");
 
 enum : uint32_t { SEC_LUT = 0, SEC_LINEAR_T = 1, SEC_LINEAR_R = 2 };
 struct Section {
