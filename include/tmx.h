@@ -177,6 +177,150 @@ int32_t tmx_witness_batch_opts(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, co
                                const tmx_validator_rec* targets, const tmx_hashfield_rec* trusteds /*NULL for step*/, uint32_t sections,
                                uint32_t format, void* out, uint64_t cap_bytes, tmx_report* reports);
 
+/* ---- the TYPED VALUE of the hint: what the reference's hint bodies actually hold before plonky2x expands it into field elements.
+ * SkipOffchainInputs::hint builds a `VerifySkipStruct` literal from a `SkipInputs<F>` (reference circuits/skip.rs:85-98, circuits/input/mod.rs:60-74)
+ * and hands it to `write_value` (skip.rs:100), which does the bit / limb expansion itself; StepOffchainInputs::hint the same with `StepInputs<F>`
+ * (step.rs:75-87, input/mod.rs:45-58).  These structs mirror those two types FIELD BY FIELD -- bytes as bytes, u64 as u64 -- so a hint body
+ * assigns them by name (rust-shim/skip_hint.rs.example) and no knowledge of the element order inside plonky2x's variable types is needed:
+ * 38 KB per N = 128 skip proof instead of the 1.86 MB of u64 elements (0.93 MB as u32) of the expanded row.
+ * One proof's value = fixed part | tmx_validator_value[n_max] | tmx_hashfield_value[n_max] (skip only)
+ *                     [| derived values, with TMX_SEC_DERIVED: see tmx_value_layout], every part 16-byte aligned, little-endian. */
+typedef struct {             /* ValidatorType<F>: the value type of ValidatorVariable, reference circuits/variables.rs:69-79; built by
+                                get_validator_data_from_block, circuits/input/conversion.rs:59-137 */
+  uint8_t pubkey[32];        /* CompressedEdwardsY */
+  uint8_t sig_r[32];         /* EDDSASignatureVariableValue.r (compressed point) */
+  uint8_t sig_s[32];         /* EDDSASignatureVariableValue.s: U256, little-endian */
+  uint8_t message[TMX_VALIDATOR_MESSAGE_BYTES_LENGTH_MAX];
+  uint32_t message_byte_length;
+  uint64_t voting_power;
+  uint32_t validator_byte_length;
+  uint32_t signed_;          /* bool `signed` */
+} tmx_validator_value;       /* 240 B */
+typedef struct {             /* ValidatorHashField<F>: variables.rs:82-88; validator_hash_field_from_block, conversion.rs:139-178 */
+  uint8_t pubkey[32];
+  uint64_t voting_power;
+  uint32_t validator_byte_length;
+  uint32_t pad;
+} tmx_hashfield_value;       /* 48 B */
+typedef struct {             /* ChainIdProofValueType<F>: variables.rs:35-41; input/mod.rs:471-482 */
+  uint8_t proof[TMX_HEADER_PROOF_DEPTH][32];
+  uint32_t enc_chain_id_byte_length;
+  uint8_t chain_id[TMX_PROTOBUF_CHAIN_ID_SIZE_BYTES]; /* the encoded field resized to 52 bytes */
+  uint8_t pad[8];
+} tmx_chain_id_proof_value;  /* 192 B */
+typedef struct {             /* HeightProofValueType<F>: variables.rs:49-55; input/mod.rs:484-493 */
+  uint8_t proof[TMX_HEADER_PROOF_DEPTH][32];
+  uint32_t enc_height_byte_length;
+  uint32_t pad;
+  uint64_t height;
+} tmx_height_proof_value;    /* 144 B */
+typedef struct {             /* InclusionProof<HEADER_PROOF_DEPTH, PROTOBUF_HASH_SIZE_BYTES, F>: input/mod.rs:303-314 */
+  uint8_t proof[TMX_HEADER_PROOF_DEPTH][32];
+  uint8_t leaf[34];
+  uint8_t pad[14];
+} tmx_hash_inclusion_proof_value;     /* 176 B */
+typedef struct {             /* InclusionProof<HEADER_PROOF_DEPTH, PROTOBUF_BLOCK_ID_SIZE_BYTES, F> */
+  uint8_t proof[TMX_HEADER_PROOF_DEPTH][32];
+  uint8_t leaf[72];
+  uint8_t pad[8];
+} tmx_block_id_inclusion_proof_value; /* 208 B */
+typedef struct {             /* SkipInputs<F> (input/mod.rs:60-74) without its two Vecs, which follow as arrays; + the verdicts */
+  uint8_t target_header[32];
+  uint8_t trusted_header[32];
+  uint64_t round;
+  uint32_t nb_target_validators;
+  uint32_t nb_trusted_validators;
+  tmx_chain_id_proof_value target_block_chain_id_proof;
+  tmx_height_proof_value target_block_height_proof;
+  tmx_hash_inclusion_proof_value target_block_validators_hash_proof;
+  tmx_hash_inclusion_proof_value trusted_block_validators_hash_proof;
+  tmx_report report;
+} tmx_skip_inputs_fixed;     /* 832 B */
+typedef struct {             /* StepInputs<F> (input/mod.rs:45-58) without its Vec; + the verdicts */
+  uint8_t next_header[32];
+  uint64_t round;
+  uint32_t nb_validators;
+  uint32_t pad;
+  tmx_chain_id_proof_value next_block_chain_id_proof;
+  tmx_height_proof_value next_block_height_proof;
+  tmx_hash_inclusion_proof_value next_block_validators_hash_proof;
+  tmx_block_id_inclusion_proof_value next_block_last_block_id_proof;
+  tmx_hash_inclusion_proof_value prev_block_next_validators_hash_proof;
+  tmx_report report;
+} tmx_step_inputs_fixed;     /* 1008 B */
+/* Derived Level-1 values (section D of the row, DESIGN.md "Witness layout") in packed form -- optional (TMX_SEC_DERIVED): what a
+ * replacement for Curta's result hints would consume.  Pad bytes are written as zeros. */
+typedef struct {             /* D.1a + D.1b of one target lane */
+  uint8_t sha512_digest[64]; /* SHA-512(R | A | M) of the lane's effective triple */
+  uint8_t h[32];             /* digest mod l, little-endian */
+  uint8_t points[10][32];    /* A.x A.y R.x R.y sB.x sB.y hA.x hA.y (R+hA).x (R+hA).y: canonical, little-endian */
+  uint32_t eddsa_ok;
+  uint32_t decode_ok;
+  uint8_t pad0[24];
+  uint8_t marshalled[TMX_VALIDATOR_BYTE_LENGTH_MAX];
+  uint8_t pad1[2];
+  uint8_t leaf_hash[32];
+  uint8_t flags[6];          /* enabled, hash_in_msg, is_precommit, height_ok, round_ok, sigdata_ok */
+  uint8_t pad2[2];
+  uint64_t total_prefix;     /* running sum of enabled powers (voting.rs:31-63) */
+  uint64_t signed_prefix;    /* running sum of signed powers (voting.rs:79-89) */
+  uint8_t pad3[8];
+} tmx_target_lane_derived;   /* 560 B */
+typedef struct {             /* D.2a + D.2b of one trusted lane (skip) */
+  uint8_t marshalled[TMX_VALIDATOR_BYTE_LENGTH_MAX];
+  uint8_t pad1[2];
+  uint8_t leaf_hash[32];
+  uint8_t flags[2];          /* enabled, matched (verify.rs:398-418) */
+  uint8_t pad2[6];
+  uint64_t total_prefix;
+  uint64_t matched_prefix;
+  uint8_t pad3[8];
+} tmx_trusted_lane_derived;  /* 112 B */
+typedef struct {             /* D.5 / D.6 of one proof */
+  uint8_t proofs[5][5][32];  /* chain id, height, validators hash, X, Y (step only): leaf hash then the four path nodes */
+  uint8_t height_leaf[11];   /* 00 08 varint9(height) */
+  uint8_t pad0[5];
+  uint64_t tally_target[4];  /* total, acc, acc * 3, total * 2 */
+  uint64_t tally_trusted[4]; /* skip only */
+  uint32_t verdicts[4];      /* gt_target, gt_trusted, dist_gt, dist_le (the last three: skip only) */
+  uint32_t checks[16];       /* 13 (skip) / 15 (step) check words, tmx_report.fail_mask bit order */
+  uint32_t all_ok;
+  uint32_t pad1;
+  uint64_t height;
+} tmx_proof_derived;         /* 976 B */
+typedef struct {
+  uint64_t bytes;              /* of one proof's value: proof p of a batch starts at p * bytes */
+  uint32_t fixed_bytes;        /* sizeof(tmx_skip_inputs_fixed) / sizeof(tmx_step_inputs_fixed), at offset 0 */
+  uint32_t off_validators;     /* tmx_validator_value[n_max] */
+  uint32_t off_hashfields;     /* tmx_hashfield_value[n_max]; 0 for step */
+  uint32_t off_target_lanes;   /* tmx_target_lane_derived[n_max]; this and the following: 0 without TMX_SEC_DERIVED */
+  uint32_t off_trusted_lanes;  /* tmx_trusted_lane_derived[n_max]; 0 for step */
+  uint32_t off_nodes_target;   /* [tree_nodes][32]: every node of the fixed-shape validator tree, layer by layer (D.3) */
+  uint32_t off_nodes_trusted;  /* (D.4) 0 for step */
+  uint32_t off_proof_derived;  /* tmx_proof_derived */
+  uint32_t tree_nodes;
+  uint32_t reserved;
+} tmx_value_layout;
+/* sections: TMX_SEC_HINT (the reference's hint value) or TMX_SEC_ALL (+ the derived values); TMX_ERR_BAD_ARG otherwise */
+int32_t tmx_value_layout_of(int32_t kind, uint32_t n_max, uint32_t sections, tmx_value_layout* out);
+/* Host buffers in, host buffer out: `out` receives n_proofs values of layout.bytes each.  No element row is produced on the device at all
+ * (the serializer does not run).  Fastest with page-locked buffers (tmx_host_alloc): the copies are then direct DMA, and a page-locked
+ * `out` is written by the GPU itself. */
+int32_t tmx_inputs_value_batch(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const tmx_proof_rec* proofs, const tmx_validator_rec* targets,
+                               const tmx_hashfield_rec* trusteds /*NULL for step*/, uint32_t sections, void* out, uint64_t cap_bytes);
+/* the single-proof forms a hint body binds (reference circuits/skip.rs:64-102, circuits/step.rs:56-89) */
+int32_t tmx_skip_inputs_value(tmx_ctx* ctx, const tmx_proof_rec* proof, const tmx_validator_rec* target /*[n_max]*/,
+                              const tmx_hashfield_rec* trusted /*[n_max]*/, uint32_t sections, void* out, uint64_t cap_bytes);
+int32_t tmx_step_inputs_value(tmx_ctx* ctx, const tmx_proof_rec* proof, const tmx_validator_rec* target /*[n_max]*/, uint32_t sections,
+                              void* out, uint64_t cap_bytes);
+/* Device pointers in and out, asynchronous on hip_stream like tmx_witness_batch_device (d_out may also be the device address of mapped
+ * page-locked host memory). */
+int32_t tmx_inputs_value_batch_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
+                                      const void* d_trusteds, uint32_t sections, void* d_out, void* hip_stream);
+/* page-locked host memory for the host entry points (hipHostMalloc: mapped, portable).  NULL on failure. */
+void* tmx_host_alloc(tmx_ctx* ctx, uint64_t bytes);
+void tmx_host_free(tmx_ctx* ctx, void* p);
+
 /* ---- device-resident entry point: inputs already in HBM, outputs stay in HBM.  All pointers are device
  * pointers of the context's device; `hip_stream` is the hipStream_t to enqueue on, used exactly as passed (NULL = the HIP
  * default stream; tmx_ctx_stream() = the context's own stream).  Asynchronous: returns after enqueueing. */

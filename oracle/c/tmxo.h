@@ -71,6 +71,44 @@ int tmxo_tally(const uint64_t* powers, size_t n, size_t nb, const uint8_t* in_gr
 int tmxo_is_valid_skip(const uint8_t* start, uint32_t n_start, const uint8_t* target, uint32_t n_target, const uint8_t* sigs, uint32_t n_sigs,
                        uint64_t* shared, uint64_t* total);
 
+/* ---- the typed value of the hint: SkipInputs<F> / StepInputs<F> of the reference (circuits/input/mod.rs:45-74) field by field, as the
+ * hint bodies hold it before `write_value` expands it (circuits/skip.rs:85-100, circuits/step.rs:75-87), + the derived Level-1 values in
+ * packed form.  The oracle's own statement of the layout the product declares in include/tmx.h (tests compare the two byte for byte, and
+ * expand this value back into the H elements of tmxo_witness).  All little-endian, pad bytes zero. */
+typedef struct { uint8_t pubkey[32], sig_r[32], sig_s[32], message[124]; uint32_t message_byte_length; uint64_t voting_power; uint32_t validator_byte_length, signed_; } tmxo_validator_value;   /* variables.rs:69-79 */
+typedef struct { uint8_t pubkey[32]; uint64_t voting_power; uint32_t validator_byte_length, pad; } tmxo_hashfield_value;                                                             /* variables.rs:82-88 */
+typedef struct { uint8_t proof[4][32]; uint32_t enc_chain_id_byte_length; uint8_t chain_id[52]; uint8_t pad[8]; } tmxo_chain_id_proof_value;                                         /* variables.rs:35-41 */
+typedef struct { uint8_t proof[4][32]; uint32_t enc_height_byte_length, pad; uint64_t height; } tmxo_height_proof_value;                                                             /* variables.rs:49-55 */
+typedef struct { uint8_t proof[4][32]; uint8_t leaf[34]; uint8_t pad[14]; } tmxo_hash_inclusion_proof_value;                                                                         /* input/mod.rs:303-314 */
+typedef struct { uint8_t proof[4][32]; uint8_t leaf[72]; uint8_t pad[8]; } tmxo_block_id_inclusion_proof_value;
+typedef struct {   /* input/mod.rs:60-74 */
+  uint8_t target_header[32], trusted_header[32]; uint64_t round; uint32_t nb_target_validators, nb_trusted_validators;
+  tmxo_chain_id_proof_value target_block_chain_id_proof; tmxo_height_proof_value target_block_height_proof;
+  tmxo_hash_inclusion_proof_value target_block_validators_hash_proof, trusted_block_validators_hash_proof;
+  tmxo_report report;
+} tmxo_skip_inputs_fixed;
+typedef struct {   /* input/mod.rs:45-58 */
+  uint8_t next_header[32]; uint64_t round; uint32_t nb_validators, pad;
+  tmxo_chain_id_proof_value next_block_chain_id_proof; tmxo_height_proof_value next_block_height_proof;
+  tmxo_hash_inclusion_proof_value next_block_validators_hash_proof; tmxo_block_id_inclusion_proof_value next_block_last_block_id_proof;
+  tmxo_hash_inclusion_proof_value prev_block_next_validators_hash_proof;
+  tmxo_report report;
+} tmxo_step_inputs_fixed;
+typedef struct {
+  uint8_t sha512_digest[64], h[32], points[10][32]; uint32_t eddsa_ok, decode_ok; uint8_t pad0[24];
+  uint8_t marshalled[46], pad1[2], leaf_hash[32], flags[6], pad2[2]; uint64_t total_prefix, signed_prefix; uint8_t pad3[8];
+} tmxo_target_lane_derived;
+typedef struct { uint8_t marshalled[46], pad1[2], leaf_hash[32], flags[2], pad2[6]; uint64_t total_prefix, matched_prefix; uint8_t pad3[8]; } tmxo_trusted_lane_derived;
+typedef struct {
+  uint8_t proofs[5][5][32], height_leaf[11], pad0[5]; uint64_t tally_target[4], tally_trusted[4]; uint32_t verdicts[4], checks[16], all_ok, pad1; uint64_t height;
+} tmxo_proof_derived;
+/* bytes of one proof's value: fixed | validators[n] | hashfields[n] (skip) [| target lanes | trusted lanes (skip) | target nodes | trusted
+ * nodes (skip) | proof derived, when with_derived] */
+size_t tmxo_value_bytes(int kind, size_t n, int with_derived);
+/* tmxo_witness with the typed value as a second output (either output may be NULL) */
+int tmxo_witness_value(int kind, const uint8_t* proof_rec, const uint8_t* target_recs, const uint8_t* trusted_recs, uint32_t n,
+                       const uint8_t* chain_id, uint32_t chain_id_len, uint64_t skip_max, uint64_t* out, tmxo_report* rep, uint8_t* value, int with_derived);
+
 size_t tmxo_elem_count(int kind, size_t n);
 /* one proof; out must hold tmxo_elem_count(kind, n) elements.  trusted_recs ignored for step. returns 0 / <0 */
 int tmxo_witness(int kind, const uint8_t* proof_rec, const uint8_t* target_recs, const uint8_t* trusted_recs, uint32_t n,

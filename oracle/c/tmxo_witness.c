@@ -164,9 +164,41 @@ size_t tmxo_elem_count(int kind, size_t n) {
   return 1517 * n + 6919 + n * DT + tmxo_tree_nodes(n) * 256 + (5 * PROOF_D + 88) + 25;
 }
 
+/* where the parts of a proof's typed value start (tmxo.h) */
+typedef struct { size_t fixed, validators, hashfields, lane_t, lane_r, nodes_t, nodes_r, proof_d, bytes; } vlay;
+static vlay value_lay(int kind, size_t n, int with_derived) {
+  vlay L; size_t o = 0; const int skip = kind == TMXO_KIND_SKIP; const size_t tn = tmxo_tree_nodes(n);
+  L.fixed = o; o += skip ? sizeof(tmxo_skip_inputs_fixed) : sizeof(tmxo_step_inputs_fixed);
+  L.validators = o; o += n * sizeof(tmxo_validator_value);
+  L.hashfields = o; o += skip ? n * sizeof(tmxo_hashfield_value) : 0;
+  L.lane_t = o; o += with_derived ? n * sizeof(tmxo_target_lane_derived) : 0;
+  L.lane_r = o; o += with_derived && skip ? n * sizeof(tmxo_trusted_lane_derived) : 0;
+  L.nodes_t = o; o += with_derived ? 32 * tn : 0;
+  L.nodes_r = o; o += with_derived && skip ? 32 * tn : 0;
+  L.proof_d = o; o += with_derived ? sizeof(tmxo_proof_derived) : 0;
+  L.bytes = o;
+  return L;
+}
+size_t tmxo_value_bytes(int kind, size_t n, int with_derived) { return value_lay(kind, n, with_derived).bytes; }
+static void put_proof(uint8_t dst[4][32], uint8_t aunts[4][32]) { memcpy(dst, aunts, 128); }
+
 int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8_t* rrec, uint32_t n,
                  const uint8_t* chain_id, uint32_t chain_id_len, uint64_t skip_max, uint64_t* out, tmxo_report* rep) {
+  return tmxo_witness_value(kind, prec, trec, rrec, n, chain_id, chain_id_len, skip_max, out, rep, NULL, 0);
+}
+
+int tmxo_witness_value(int kind, const uint8_t* prec, const uint8_t* trec, const uint8_t* rrec, uint32_t n,
+                       const uint8_t* chain_id, uint32_t chain_id_len, uint64_t skip_max, uint64_t* out, tmxo_report* rep_out, uint8_t* value, int with_derived) {
   if (n == 0 || n > 4096) return -1;
+  tmxo_report rep_local;
+  tmxo_report* rep = rep_out ? rep_out : &rep_local;   /* (the typed value carries the report too) */
+  const vlay VL = value_lay(kind, n, with_derived);
+  if (value) memset(value, 0, VL.bytes);
+  tmxo_skip_inputs_fixed* vsk = value && kind == TMXO_KIND_SKIP ? (tmxo_skip_inputs_fixed*)(value + VL.fixed) : NULL;
+  tmxo_step_inputs_fixed* vst = value && kind == TMXO_KIND_STEP ? (tmxo_step_inputs_fixed*)(value + VL.fixed) : NULL;
+  tmxo_target_lane_derived* vlt = value && with_derived ? (tmxo_target_lane_derived*)(value + VL.lane_t) : NULL;
+  tmxo_trusted_lane_derived* vlr = value && with_derived && kind == TMXO_KIND_SKIP ? (tmxo_trusted_lane_derived*)(value + VL.lane_r) : NULL;
+  tmxo_proof_derived* vpd = value && with_derived ? (tmxo_proof_derived*)(value + VL.proof_d) : NULL;
   es E = {out, 0};
   uint64_t block_a = rd64(prec), block_b = rd64(prec + 8), round = rd64(prec + 48);
   const uint8_t* pub_hash = prec + 16;
@@ -181,6 +213,19 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
   uint8_t a_cid[4][32], a_h[4][32], a_v[4][32], a_tv[4][32], a_lb[4][32], a_nv[4][32];
   rfc6962_aunts(&ha.lh[0][0], 14, 1, a_cid); rfc6962_aunts(&ha.lh[0][0], 14, 2, a_h); rfc6962_aunts(&ha.lh[0][0], 14, 7, a_v);
   uint8_t leaf34[34], leaf72[72], leafb[34];
+  if (value) {   /* the two Vecs of SkipInputs / StepInputs: conversion.rs:59-178 */
+    tmxo_validator_value* vv = (tmxo_validator_value*)(value + VL.validators);
+    for (uint32_t i = 0; i < n; i++) {
+      const uint8_t* v = trec + (size_t)TMXO_REC_VALIDATOR * i;
+      memcpy(vv[i].pubkey, v, 32); memcpy(vv[i].sig_r, v + 32, 32); memcpy(vv[i].sig_s, v + 64, 32); memcpy(vv[i].message, v + 96, 124);
+      vv[i].message_byte_length = (uint32_t)v[220] | ((uint32_t)v[221] << 8); vv[i].voting_power = rd64(v + 224);
+      vv[i].validator_byte_length = v[222]; vv[i].signed_ = v[223] & TMXO_FLAG_SIGNED;
+    }
+    if (kind == TMXO_KIND_SKIP) {
+      tmxo_hashfield_value* hv = (tmxo_hashfield_value*)(value + VL.hashfields);
+      for (uint32_t j = 0; j < n; j++) { const uint8_t* t = rrec + (size_t)TMXO_REC_HASHFIELD * j; memcpy(hv[j].pubkey, t, 32); hv[j].voting_power = rd64(t + 32); hv[j].validator_byte_length = t[40]; }
+    }
+  }
 
   /* ---------------- H */
   e_bytes(&E, header, 32);
@@ -198,12 +243,23 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
   memset(leaf34, 0, 34); memcpy(leaf34, ha.leaf[7], ha.len[7] < 34 ? ha.len[7] : 34);
   for (int k = 0; k < 4; k++) e_bytes(&E, a_v[k], 32);
   e_bytes(&E, leaf34, 34);
+  if (value) {   /* input/mod.rs:471-499 (skip), 370-398 (step): the three proofs both kinds carry */
+    tmxo_chain_id_proof_value* cp = vsk ? &vsk->target_block_chain_id_proof : &vst->next_block_chain_id_proof;
+    tmxo_height_proof_value* hp = vsk ? &vsk->target_block_height_proof : &vst->next_block_height_proof;
+    tmxo_hash_inclusion_proof_value* vp = vsk ? &vsk->target_block_validators_hash_proof : &vst->next_block_validators_hash_proof;
+    put_proof(cp->proof, a_cid); cp->enc_chain_id_byte_length = ha.len[1]; memcpy(cp->chain_id, ha.leaf[1], ha.len[1] < 52 ? ha.len[1] : 52);
+    put_proof(hp->proof, a_h); hp->enc_height_byte_length = ha.len[2]; hp->height = height_a;
+    put_proof(vp->proof, a_v); memcpy(vp->leaf, leaf34, 34);
+    if (vsk) { memcpy(vsk->target_header, header, 32); memcpy(vsk->trusted_header, pub_hash, 32); vsk->round = round; vsk->nb_target_validators = nb; vsk->nb_trusted_validators = nbt; }
+    else { memcpy(vst->next_header, header, 32); vst->round = round; vst->nb_validators = nb; }
+  }
   if (kind == TMXO_KIND_SKIP) {
     rfc6962_aunts(&hb.lh[0][0], 14, 7, a_tv);
     memset(leafb, 0, 34); memcpy(leafb, hb.leaf[7], hb.len[7] < 34 ? hb.len[7] : 34);
     e_u32(&E, nbt);
     for (int k = 0; k < 4; k++) e_bytes(&E, a_tv[k], 32);
     e_bytes(&E, leafb, 34);
+    if (vsk) { put_proof(vsk->trusted_block_validators_hash_proof.proof, a_tv); memcpy(vsk->trusted_block_validators_hash_proof.leaf, leafb, 34); }
     for (uint32_t j = 0; j < n; j++) { const uint8_t* t = rrec + (size_t)TMXO_REC_HASHFIELD * j; e_bytes(&E, t, 32); e_u64(&E, rd64(t + 32)); e_u32(&E, t[40]); }
   } else {
     rfc6962_aunts(&ha.lh[0][0], 14, 4, a_lb); rfc6962_aunts(&hb.lh[0][0], 14, 8, a_nv);
@@ -213,6 +269,10 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
     e_bytes(&E, leaf72, 72);
     for (int k = 0; k < 4; k++) e_bytes(&E, a_nv[k], 32);
     e_bytes(&E, leafb, 34);
+    if (vst) {
+      put_proof(vst->next_block_last_block_id_proof.proof, a_lb); memcpy(vst->next_block_last_block_id_proof.leaf, leaf72, 72);
+      put_proof(vst->prev_block_next_validators_hash_proof.proof, a_nv); memcpy(vst->prev_block_next_validators_hash_proof.leaf, leafb, 34);
+    }
   }
 
   /* ---------------- D */
@@ -255,6 +315,11 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
     uint8_t* f = lflags + 6 * i;
     f[0] = (uint8_t)enabled; f[1] = (uint8_t)hash_in_msg; f[2] = (uint8_t)is_precommit; f[3] = (uint8_t)height_ok; f[4] = (uint8_t)round_ok; f[5] = (uint8_t)sigdata_ok;
     e_bytes(&E, m, 46); e_bytes(&E, lh, 32); e_bytes(&E, tr->digest, 64);
+    if (vlt) {
+      tmxo_target_lane_derived* d = &vlt[i];
+      memcpy(d->sha512_digest, tr->digest, 64); memcpy(d->h, tr->h, 32); memcpy(d->points, tr->pt, 320); d->eddsa_ok = tr->ok; d->decode_ok = tr->decode_ok;
+      memcpy(d->marshalled, m, 46); memcpy(d->leaf_hash, lh, 32); memcpy(d->flags, f, 6); d->total_prefix = totp[i]; d->signed_prefix = accp[i];
+    }
     if (!tr->ok) { all_eddsa = 0; if (first_bad < 0) first_bad = (int32_t)i; }
     if (!sigdata_ok) all_sigdata = 0;
   }
@@ -288,11 +353,17 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
     gt_r = tmxo_tally(rp, n, nbt, matched, 1, 3, totp, accp, scal_r, &no_overflow);
     for (uint32_t j = 0; j < n; j++) { e_bytes(&E, rm + 46 * j, 46); e_bytes(&E, rleaves + 32 * j, 32); }                    /* D.2a: byte fields */
     for (uint32_t j = 0; j < n; j++) { e_bool(&E, j < nbt); e_bool(&E, matched[j]); e_u64(&E, totp[j]); e_u64(&E, accp[j]); }  /* D.2b: word fields */
+    if (vlr)
+      for (uint32_t j = 0; j < n; j++) {
+        memcpy(vlr[j].marshalled, rm + 46 * j, 46); memcpy(vlr[j].leaf_hash, rleaves + 32 * j, 32);
+        vlr[j].flags[0] = j < nbt; vlr[j].flags[1] = matched[j]; vlr[j].total_prefix = totp[j]; vlr[j].matched_prefix = accp[j];
+      }
     tmxo_fixed_shape_tree(rleaves, n, nbt, nodes_r, root_r);
     free(matched); free(rp); free(rleaves); free(rm);
   }
   e_bytes(&E, nodes, 32 * tn);
   if (kind == TMXO_KIND_SKIP) e_bytes(&E, nodes_r, 32 * tn);
+  if (value && with_derived) { memcpy(value + VL.nodes_t, nodes, 32 * tn); if (kind == TMXO_KIND_SKIP) memcpy(value + VL.nodes_r, nodes_r, 32 * tn); }
 
   uint8_t n_cid[4][32], n_h[4][32], n_v[4][32], n_x[4][32], n_y[4][32], hl[96] = {0}, hlh[32], vlh[32], xlh[32], ylh[32];
   /* verify.rs:189-202: SHA-256 over 1 + enc_len bytes of 00 | chain_id[52] | zeros, where chain_id is the encoded field resized to
@@ -358,7 +429,7 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
     e_bool(&E, all_ok);
     if (rep) rep->dist_ok = 0;
   }
-  if (rep) {
+  {
     memcpy(rep->header, header, 32);
     rep->all_ok = (uint32_t)all_ok; rep->fail_mask = 0;
     for (int k = 0; k < nchk; k++) if (!checks[k]) rep->fail_mask |= 1u << k;
@@ -366,6 +437,19 @@ int tmxo_witness(int kind, const uint8_t* prec, const uint8_t* trec, const uint8
     rep->reserved[0] = (nb > n ? 1u : 0u) | (kind == TMXO_KIND_SKIP && nbt > n ? 2u : 0u);   /* precond: input/mod.rs:439-444, 338-342 */
     rep->reserved[1] = 0;
   }
+  if (vpd) {
+    uint8_t (*nd[5])[32] = {n_cid, n_h, n_v, n_x, n_y};
+    const uint8_t* lhs[5] = {cid_lh, hlh, vlh, xlh, ylh};
+    for (int q = 0; q < (kind == TMXO_KIND_SKIP ? 4 : 5); q++) { memcpy(vpd->proofs[q][0], lhs[q], 32); memcpy(vpd->proofs[q][1], nd[q], 128); }
+    memcpy(vpd->height_leaf, hl, 11);
+    for (int k = 0; k < 4; k++) { vpd->tally_target[k] = scal_t[k]; vpd->tally_trusted[k] = scal_r[k]; }
+    vpd->verdicts[0] = (uint32_t)gt_t;
+    if (kind == TMXO_KIND_SKIP) { vpd->verdicts[1] = (uint32_t)gt_r; vpd->verdicts[2] = block_b > block_a + 1; vpd->verdicts[3] = block_b <= block_a + skip_max; }
+    for (int k = 0; k < nchk; k++) vpd->checks[k] = (uint32_t)checks[k];
+    vpd->all_ok = (uint32_t)all_ok; vpd->height = height_a;
+  }
+  if (vsk) vsk->report = *rep;
+  if (vst) vst->report = *rep;
   free(powers); free(signedv); free(totp); free(accp); free(leaves); free(nodes); free(nodes_r);
   return E.n == tmxo_elem_count(kind, n) ? 0 : -2;
 }

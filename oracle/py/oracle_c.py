@@ -150,6 +150,25 @@ def witness(kind, proof_rec, target_recs, trusted_recs, chain_id, skip_max):
     return out, _rep(rep)
 
 
+def value_bytes(kind, n, with_derived):
+    L = lib()
+    L.tmxo_value_bytes.restype = C.c_size_t
+    return int(L.tmxo_value_bytes(kind, C.c_size_t(n), 1 if with_derived else 0))
+
+
+def witness_value(kind, proof_rec, target_recs, trusted_recs, chain_id, skip_max, with_derived=False):
+    """One proof: the typed value of the hint (tmxo.h tmxo_*_value structs) as a np.uint8 array, and the report."""
+    n = len(target_recs) // 256
+    val = np.zeros(value_bytes(kind, n, with_derived) // 8, dtype=np.uint64)   # (8-byte aligned: the C side writes through struct pointers)
+    rep = Report()
+    rc = lib().tmxo_witness_value(kind, bytes(proof_rec), bytes(target_recs), bytes(trusted_recs) if trusted_recs else None,
+                                  C.c_uint32(n), bytes(chain_id), C.c_uint32(len(chain_id)), C.c_uint64(skip_max), None, C.byref(rep),
+                                  val.ctypes.data_as(C.c_void_p), 1 if with_derived else 0)
+    if rc:
+        raise RuntimeError(f"tmxo_witness_value rc={rc}")
+    return val.view(np.uint8), _rep(rep)
+
+
 def witness_batch(kind, n_proofs, proof_recs, target_recs, trusted_recs, n, chain_id, skip_max, n_threads=1, want_out=True):
     ec = elem_count(kind, n)
     out = np.zeros(ec * n_proofs, dtype=np.uint64) if want_out else None

@@ -68,6 +68,73 @@ class Config(C.Structure):
                 ("skip_max", C.c_uint64), ("device", C.c_int32), ("max_batch", C.c_uint32)]
 
 
+# ---- the typed value of the hint (include/tmx.h "TYPED VALUE"): SkipInputs<F> / StepInputs<F> field by field
+class ValidatorValue(C.Structure):
+    _fields_ = [("pubkey", C.c_uint8 * 32), ("sig_r", C.c_uint8 * 32), ("sig_s", C.c_uint8 * 32), ("message", C.c_uint8 * 124),
+                ("message_byte_length", C.c_uint32), ("voting_power", C.c_uint64), ("validator_byte_length", C.c_uint32), ("signed_", C.c_uint32)]
+
+
+class HashFieldValue(C.Structure):
+    _fields_ = [("pubkey", C.c_uint8 * 32), ("voting_power", C.c_uint64), ("validator_byte_length", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class ChainIdProofValue(C.Structure):
+    _fields_ = [("proof", (C.c_uint8 * 32) * 4), ("enc_chain_id_byte_length", C.c_uint32), ("chain_id", C.c_uint8 * 52), ("pad", C.c_uint8 * 8)]
+
+
+class HeightProofValue(C.Structure):
+    _fields_ = [("proof", (C.c_uint8 * 32) * 4), ("enc_height_byte_length", C.c_uint32), ("pad", C.c_uint32), ("height", C.c_uint64)]
+
+
+class HashInclusionProofValue(C.Structure):
+    _fields_ = [("proof", (C.c_uint8 * 32) * 4), ("leaf", C.c_uint8 * 34), ("pad", C.c_uint8 * 14)]
+
+
+class BlockIdInclusionProofValue(C.Structure):
+    _fields_ = [("proof", (C.c_uint8 * 32) * 4), ("leaf", C.c_uint8 * 72), ("pad", C.c_uint8 * 8)]
+
+
+class SkipInputsFixed(C.Structure):
+    _fields_ = [("target_header", C.c_uint8 * 32), ("trusted_header", C.c_uint8 * 32), ("round", C.c_uint64),
+                ("nb_target_validators", C.c_uint32), ("nb_trusted_validators", C.c_uint32),
+                ("target_block_chain_id_proof", ChainIdProofValue), ("target_block_height_proof", HeightProofValue),
+                ("target_block_validators_hash_proof", HashInclusionProofValue), ("trusted_block_validators_hash_proof", HashInclusionProofValue),
+                ("report", Report)]
+
+
+class StepInputsFixed(C.Structure):
+    _fields_ = [("next_header", C.c_uint8 * 32), ("round", C.c_uint64), ("nb_validators", C.c_uint32), ("pad", C.c_uint32),
+                ("next_block_chain_id_proof", ChainIdProofValue), ("next_block_height_proof", HeightProofValue),
+                ("next_block_validators_hash_proof", HashInclusionProofValue), ("next_block_last_block_id_proof", BlockIdInclusionProofValue),
+                ("prev_block_next_validators_hash_proof", HashInclusionProofValue), ("report", Report)]
+
+
+class TargetLaneDerived(C.Structure):
+    _fields_ = [("sha512_digest", C.c_uint8 * 64), ("h", C.c_uint8 * 32), ("points", (C.c_uint8 * 32) * 10), ("eddsa_ok", C.c_uint32),
+                ("decode_ok", C.c_uint32), ("pad0", C.c_uint8 * 24), ("marshalled", C.c_uint8 * 46), ("pad1", C.c_uint8 * 2),
+                ("leaf_hash", C.c_uint8 * 32), ("flags", C.c_uint8 * 6), ("pad2", C.c_uint8 * 2), ("total_prefix", C.c_uint64),
+                ("signed_prefix", C.c_uint64), ("pad3", C.c_uint8 * 8)]
+
+
+class TrustedLaneDerived(C.Structure):
+    _fields_ = [("marshalled", C.c_uint8 * 46), ("pad1", C.c_uint8 * 2), ("leaf_hash", C.c_uint8 * 32), ("flags", C.c_uint8 * 2),
+                ("pad2", C.c_uint8 * 6), ("total_prefix", C.c_uint64), ("matched_prefix", C.c_uint64), ("pad3", C.c_uint8 * 8)]
+
+
+class ProofDerived(C.Structure):
+    _fields_ = [("proofs", ((C.c_uint8 * 32) * 5) * 5), ("height_leaf", C.c_uint8 * 11), ("pad0", C.c_uint8 * 5), ("tally_target", C.c_uint64 * 4),
+                ("tally_trusted", C.c_uint64 * 4), ("verdicts", C.c_uint32 * 4), ("checks", C.c_uint32 * 16), ("all_ok", C.c_uint32),
+                ("pad1", C.c_uint32), ("height", C.c_uint64)]
+
+
+class ValueLayout(C.Structure):
+    _fields_ = [("bytes", C.c_uint64), ("fixed_bytes", C.c_uint32), ("off_validators", C.c_uint32), ("off_hashfields", C.c_uint32),
+                ("off_target_lanes", C.c_uint32), ("off_trusted_lanes", C.c_uint32), ("off_nodes_target", C.c_uint32),
+                ("off_nodes_trusted", C.c_uint32), ("off_proof_derived", C.c_uint32), ("tree_nodes", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+assert (C.sizeof(ValidatorValue), C.sizeof(HashFieldValue), C.sizeof(SkipInputsFixed), C.sizeof(StepInputsFixed)) == (240, 48, 832, 1008)
+assert (C.sizeof(TargetLaneDerived), C.sizeof(TrustedLaneDerived), C.sizeof(ProofDerived)) == (560, 112, 976)
 assert C.sizeof(ValidatorRec) == 256 and C.sizeof(HashFieldRec) == 48 and C.sizeof(ProofRec) == 2336
 assert C.sizeof(Report) == 64 and C.sizeof(AddrRec) == 32
 
@@ -138,6 +205,13 @@ def lib():
     L.tmx_out_row_elems.argtypes = [C.c_int32, C.c_uint32, C.c_uint32]
     L.tmx_witness_batch_opts.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                          C.c_void_p, C.c_uint64, C.c_void_p]
+    L.tmx_value_layout_of.argtypes = [C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(ValueLayout)]
+    L.tmx_inputs_value_batch.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
+    L.tmx_inputs_value_batch_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.tmx_host_alloc.restype = C.c_void_p
+    L.tmx_host_alloc.argtypes = [C.c_void_p, C.c_uint64]
+    L.tmx_host_free.restype = None
+    L.tmx_host_free.argtypes = [C.c_void_p, C.c_void_p]
     L.tmx_witness_batch_device_sections.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_uint32]
     L.tmx_trace_elem_count.restype = C.c_uint64

@@ -106,6 +106,50 @@ class Context:
         """Only the hint section H of every row (what the reference's hint writes to its output stream), narrowed to u32 by default."""
         return self.witness_batch_opts(kind, proofs, targets, trusteds, _lib.SEC_HINT, fmt, out)
 
+    # ---- the typed value of the hint: SkipInputs<F> / StepInputs<F> field by field (include/tmx.h "TYPED VALUE")
+    def value_layout(self, kind, sections=_lib.SEC_HINT):
+        lay = _lib.ValueLayout()
+        check(self._L.tmx_value_layout_of(kind, self.n_max, sections, C.byref(lay)), self._h)
+        return lay
+
+    def host_alloc(self, nbytes):
+        """Page-locked host memory (tmx_host_alloc) as a np.uint8 array; release with host_free(array)."""
+        p = self._L.tmx_host_alloc(self._h, nbytes)
+        if not p:
+            raise MemoryError(f"tmx_host_alloc({nbytes})")
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p
+        return a
+
+    def host_free(self, a):
+        p = getattr(self, "_pinned", {}).pop(a.ctypes.data, None)
+        if p:
+            self._L.tmx_host_free(self._h, p)
+
+    def inputs_value_batch(self, kind, proofs, targets, trusteds=None, sections=_lib.SEC_HINT, out=None):
+        """tmx_inputs_value_batch: n proofs -> np.uint8 [n, layout.bytes] (one typed value per row) + the layout.  proofs / targets /
+        trusteds: bytes, or np.uint8 arrays (e.g. views of host_alloc memory: nothing is copied on the way in)."""
+        ptr = lambda b: b.ctypes.data if isinstance(b, np.ndarray) else bytes(b)
+        size = lambda b: b.nbytes if isinstance(b, np.ndarray) else len(b)
+        n = size(proofs) // 2336
+        assert size(proofs) == n * 2336 and size(targets) == n * self.n_max * 256
+        if kind == KIND_SKIP:
+            assert trusteds is not None and size(trusteds) == n * self.n_max * 48
+        lay = self.value_layout(kind, sections)
+        if out is None:
+            out = np.zeros(n * lay.bytes, dtype=np.uint8)
+        else:
+            assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and out.size >= n * lay.bytes
+            out = out.reshape(-1)[:n * lay.bytes]
+        st = self._L.tmx_inputs_value_batch(self._h, kind, n, ptr(proofs), ptr(targets), ptr(trusteds) if trusteds is not None else None, sections,
+                                            out.ctypes.data, out.nbytes)
+        check(st, self._h)
+        return out.reshape(n, lay.bytes), lay
+
+    def inputs_value_batch_device(self, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, sections=_lib.SEC_HINT, stream=None):
+        check(self._L.tmx_inputs_value_batch_device(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, sections, d_out, self._stream(stream)), self._h)
+
     def witness_batch_device_sections(self, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports, sections, stream=None):
         check(self._L.tmx_witness_batch_device_sections(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports,
                                                         self._stream(stream), sections), self._h)

@@ -6,6 +6,7 @@
 // on one HIP stream.  No CPU compute path exists here: without a usable HIP device every call fails.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,8 +19,12 @@
 #include "poseidon.h"
 #include "trace.h"
 #include "tmx.h"
+#include "value.h"
 
 using namespace tmx;
+
+// why the last context-less call of this thread failed (tmx_comm_unique_id has no context to carry the text): tmx_last_error(NULL)
+static thread_local std::string g_tls_err;
 
 static_assert(sizeof(tmx_validator_rec) == VR_STRIDE, "validator record layout");
 static_assert(sizeof(tmx_hashfield_rec) == HR_STRIDE, "hash-field record layout");
@@ -31,6 +36,23 @@ static_assert(offsetof(tmx_validator_rec, voting_power) == VR_OFF_POWER, "power 
 static_assert(offsetof(tmx_hashfield_rec, validator_byte_length) == HR_OFF_VLEN, "vlen offset");
 static_assert(offsetof(tmx_proof_rec, header_b) == PR_OFF_HDR_B, "header_b offset");
 static_assert(TMX_N_MAX_LIMIT == TMX_N_LIMIT, "n_max limit");
+static_assert(sizeof(tmx_validator_value) == VAL_VALIDATOR && sizeof(tmx_hashfield_value) == VAL_HASHFIELD, "typed value: lane structs");
+static_assert(sizeof(tmx_skip_inputs_fixed) == VAL_FIXED_SKIP && sizeof(tmx_step_inputs_fixed) == VAL_FIXED_STEP, "typed value: fixed parts");
+static_assert(sizeof(tmx_target_lane_derived) == VAL_LANE_T && sizeof(tmx_trusted_lane_derived) == VAL_LANE_R && sizeof(tmx_proof_derived) == VAL_PROOF_D,
+              "typed value: derived structs");
+static_assert(offsetof(tmx_validator_value, message_byte_length) == 220 && offsetof(tmx_validator_value, voting_power) == 224 &&
+                  offsetof(tmx_validator_value, validator_byte_length) == 232 && offsetof(tmx_validator_value, signed_) == 236,
+              "tmx_validator_value: k_pack_value writes these offsets");
+static_assert(offsetof(tmx_target_lane_derived, eddsa_ok) == ED_OFF_OK && offsetof(tmx_target_lane_derived, marshalled) == TL_OFF_LT + LN_OFF_MARSHAL &&
+                  offsetof(tmx_target_lane_derived, leaf_hash) == TL_OFF_LT + LN_OFF_LEAF && offsetof(tmx_target_lane_derived, flags) == TL_OFF_LT + LN_OFF_FLAGS &&
+                  offsetof(tmx_target_lane_derived, total_prefix) == TL_OFF_LT + LN_OFF_TOT && offsetof(tmx_target_lane_derived, signed_prefix) == TL_OFF_LT + LN_OFF_ACC,
+              "tmx_target_lane_derived mirrors the context's lane record");
+static_assert(offsetof(tmx_trusted_lane_derived, flags) == LN_OFF_FLAGS && offsetof(tmx_trusted_lane_derived, matched_prefix) == LN_OFF_ACC, "tmx_trusted_lane_derived");
+static_assert(offsetof(tmx_proof_derived, height_leaf) == PF_OFF_HLEAF - PF_OFF_PROOFD && offsetof(tmx_proof_derived, tally_target) == PF_OFF_TALLY_T - PF_OFF_PROOFD &&
+                  offsetof(tmx_proof_derived, tally_trusted) == PF_OFF_TALLY_R - PF_OFF_PROOFD && offsetof(tmx_proof_derived, verdicts) == PF_OFF_VERDICTS - PF_OFF_PROOFD &&
+                  offsetof(tmx_proof_derived, checks) == PF_OFF_CHECKS - PF_OFF_PROOFD && offsetof(tmx_proof_derived, all_ok) == PF_OFF_ALLOK - PF_OFF_PROOFD &&
+                  offsetof(tmx_proof_derived, height) == PF_OFF_HEIGHT - PF_OFF_PROOFD,
+              "tmx_proof_derived mirrors the context's per-proof record");
 
 // ------------------------------------------------------------------------------------------------ element layout
 // Declarative description of the witness row: hint section H in the field order of VerifySkipVariable<N> /
@@ -298,6 +320,7 @@ struct tmx_ctx {
   hipStream_t last_stream = nullptr;  // stream and end event of the previous batch (cross-stream callers are ordered behind it)
   bool last_stream_valid = false;
   hipEvent_t ev_done = nullptr;
+  hipEvent_t ev_value = nullptr;  // end of the last typed-value batch (its k_pack_value launch)
   int32_t last_kind = -1;       // kind and size of the last Level-1 batch (tmx_trace_rows_device reads its lane records)
   uint32_t last_n_proofs = 0;
   Program prog[2];
@@ -334,6 +357,9 @@ struct tmx_ctx {
   hipEvent_t ev_trace_rest[2] = {};  // the other sections beside the ladders: fork, join
   void* d_trace_tmp = nullptr;  // projective ladder points between the two passes of the Level-2 ladder kernels (allocated on first use)
   void* d_pack = nullptr;  // dense / narrowed rows for tmx_witness_batch_opts (allocated on first use)
+  void* d_val_lut[2] = {nullptr, nullptr};  // fixed-part gather tables of the typed value (value.h), per kind
+  void* d_value = nullptr;  // device staging of tmx_inputs_value_batch when `out` is not page-locked (allocated on first use)
+  uint64_t d_value_bytes = 0;
   uint64_t d_pack_bytes = 0;
   uint32_t sections = 3;  // TMX_SEC_* of the batch being enqueued
   // Goldilocks NTT: twiddle tables per transform size (built on first use), scratch for the four-step split / LDE
@@ -866,7 +892,7 @@ uint64_t tmx_hint_elem_count(int32_t kind, uint32_t n) {
   return kind == TMX_KIND_SKIP ? 1776ull * n + 5320 : 1517ull * n + 6919;
 }
 
-const char* tmx_last_error(const tmx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char* tmx_last_error(const tmx_ctx* ctx) { return ctx ? ctx->err.c_str() : (g_tls_err.empty() ? "null context" : g_tls_err.c_str()); }
 
 }  // extern "C"
 
@@ -987,7 +1013,8 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   }
   void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_owner_of, c->d_slot_of_owner, c->d_slot_of_uid, c->d_owners, c->d_keyrec,
                   c->d_anchors, c->d_keytab, c->kc.d_hash, c->kc.d_pk, c->kc.d_used, c->kc.d_free, c->kc.d_state, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
-                  c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out, c->d_pack, c->d_trace_tmp, c->d_tiny, c->d_shadow, c->d_commit};
+                  c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out, c->d_pack, c->d_trace_tmp, c->d_tiny, c->d_shadow, c->d_commit,
+                  c->d_val_lut[0], c->d_val_lut[1], c->d_value};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (void* w : c->d_ntt_w)
@@ -1016,6 +1043,7 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   if (c->ev_leaves) (void)hipEventDestroy(c->ev_leaves);
   if (c->ev_hash_clean) (void)hipEventDestroy(c->ev_hash_clean);
   if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
+  if (c->ev_value) (void)hipEventDestroy(c->ev_value);
   for (hipEvent_t e : c->ev_trace_rest)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_trace)
@@ -1045,6 +1073,7 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   c->side = ds->side; c->side2 = ds->side2; c->side3 = ds->side3;
   c->have_streams = true;
   HIPCK(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_value, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming));
   for (auto& ev : c->ev_part) HIPCK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1339,11 +1368,13 @@ int32_t tmx_kernel_ms_mean(tmx_ctx* c, uint32_t last_k, float ms[TMX_N_KERNELS])
     hipEvent_t* ev = c->ev[(c->n_calls - 1 - j) % tmx_ctx::EV_RING];
     HIPCK(c, hipEventSynchronize(ev[3]));
     if (c->slot_tiny[(c->n_calls - 1 - j) % tmx_ctx::EV_RING]) {
-      // a small launch: ev[0] .. ev[1] = k_tiny (the EdDSA lanes and the proof roles side by side), ev[2] .. ev[3] = k_tiny_tail
+      // a small launch: ev[0] .. ev[1] = k_tiny (the EdDSA lanes and the proof roles side by side: attributed ONCE, to the EdDSA slot),
+      // ev[1] .. ev[2] = the gap between the two launches (the serializer slot), ev[2] .. ev[3] = k_tiny_tail (the verdict slot) -- the four
+      // figures are disjoint intervals, so their sum is the small launch's length as it is for a classic one
       float t = 0;
-      HIPCK(c, hipEventElapsedTime(&t, ev[0], ev[1])); acc[TMX_K_EDDSA] += t; acc[TMX_K_PROOF] += t;
+      HIPCK(c, hipEventElapsedTime(&t, ev[0], ev[1])); acc[TMX_K_EDDSA] += t;
       HIPCK(c, hipEventElapsedTime(&t, ev[2], ev[3])); acc[TMX_K_VERDICT] += t;
-      HIPCK(c, hipEventElapsedTime(&t, ev[1], ev[3])); acc[TMX_K_SERIALIZE] += t;
+      HIPCK(c, hipEventElapsedTime(&t, ev[1], ev[2])); acc[TMX_K_SERIALIZE] += t;
       continue;
     }
     hipEvent_t* evs = c->ev_side[(c->n_calls - 1 - j) % tmx_ctx::EV_RING];
@@ -1359,7 +1390,7 @@ int32_t tmx_kernel_ms_mean(tmx_ctx* c, uint32_t last_k, float ms[TMX_N_KERNELS])
 }
 int32_t tmx_last_kernel_ms(tmx_ctx* c, float ms[TMX_N_KERNELS]) { return tmx_kernel_ms_mean(c, 1, ms); }
 
-static int32_t ensure_staging(tmx_ctx* c) {
+static int32_t ensure_staging_inputs(tmx_ctx* c) {
   int32_t hs = ensure_host_stream(c);
   if (hs) return hs;
   if (c->d_in_proofs) return TMX_OK;
@@ -1368,6 +1399,13 @@ static int32_t ensure_staging(tmx_ctx* c) {
   HIPCK(c, hipMalloc(&c->d_in_proofs, B * sizeof(tmx_proof_rec)));
   HIPCK(c, hipMalloc(&c->d_in_targets, lanes * sizeof(tmx_validator_rec)));
   HIPCK(c, hipMalloc(&c->d_in_trusteds, lanes * sizeof(tmx_hashfield_rec)));
+  return TMX_OK;
+}
+static int32_t ensure_staging(tmx_ctx* c) {  // + the row buffer of the element-producing host entry points (the typed-value calls never need it)
+  int32_t st = ensure_staging_inputs(c);
+  if (st) return st;
+  if (c->d_out) return TMX_OK;
+  const size_t B = c->cfg.max_batch;
   uint64_t stride = tmx_elem_stride(TMX_KIND_SKIP, c->cfg.n_max), st2 = tmx_elem_stride(TMX_KIND_STEP, c->cfg.n_max);
   c->d_out_elems = (stride > st2 ? stride : st2) * B;
   HIPCK(c, hipMalloc(&c->d_out, c->d_out_elems * 8));
@@ -1466,11 +1504,185 @@ int32_t tmx_step_witness(tmx_ctx* c, const tmx_proof_rec* proof, const tmx_valid
   return tmx_witness_batch(c, TMX_KIND_STEP, 1, proof, target, nullptr, out_elems, cap_elems, report);
 }
 
+}  // extern "C"
+
+// ---- the typed value of the hint (include/tmx.h "TYPED VALUE"; value.h / value.hip) ----------------------------------------------------
+static ValueLayout value_layout_for(int32_t kind, uint32_t n, uint32_t sections) { return value_layout((uint32_t)kind, n, tree_nodes(n), sections); }
+
+// fixed-part gather table of one kind, straight from the public structs' offsetof: whatever include/tmx.h declares is what the device writes
+static std::vector<uint16_t> value_fixed_lut(int32_t kind) {
+  std::vector<uint16_t> lut(VAL_FIXED_MAX, VAL_LUT_ZERO);
+  auto put = [&](size_t dst, size_t len, uint32_t src, uint32_t off) {
+    for (size_t i = 0; i < len; i++) lut[dst + i] = (uint16_t)((src << 12) | (off + (uint32_t)i));
+  };
+  auto chain_id_proof = [&](size_t at) {
+    put(at + offsetof(tmx_chain_id_proof_value, proof), 128, VSRC_PF, PF_OFF_AUNTS + 128 * 0);
+    put(at + offsetof(tmx_chain_id_proof_value, enc_chain_id_byte_length), 4, VSRC_PF, PF_OFF_CIDLEN);
+    put(at + offsetof(tmx_chain_id_proof_value, chain_id), 52, VSRC_PF, PF_OFF_CID52);
+  };
+  auto height_proof = [&](size_t at) {
+    put(at + offsetof(tmx_height_proof_value, proof), 128, VSRC_PF, PF_OFF_AUNTS + 128 * 1);
+    put(at + offsetof(tmx_height_proof_value, enc_height_byte_length), 4, VSRC_PF, PF_OFF_HLEN);
+    put(at + offsetof(tmx_height_proof_value, height), 8, VSRC_PF, PF_OFF_HEIGHT);
+  };
+  auto hash_proof = [&](size_t at, int q, uint32_t leaf_off) {
+    put(at + offsetof(tmx_hash_inclusion_proof_value, proof), 128, VSRC_PF, PF_OFF_AUNTS + 128 * (uint32_t)q);
+    put(at + offsetof(tmx_hash_inclusion_proof_value, leaf), 34, VSRC_PF, leaf_off);
+  };
+  if (kind == TMX_KIND_SKIP) {
+    put(offsetof(tmx_skip_inputs_fixed, target_header), 32, VSRC_PF, PF_OFF_HEADER);
+    put(offsetof(tmx_skip_inputs_fixed, trusted_header), 32, VSRC_PROOF, PR_OFF_HASH);
+    put(offsetof(tmx_skip_inputs_fixed, round), 8, VSRC_PROOF, PR_OFF_ROUND);
+    put(offsetof(tmx_skip_inputs_fixed, nb_target_validators), 4, VSRC_PROOF, PR_OFF_NB_A);
+    put(offsetof(tmx_skip_inputs_fixed, nb_trusted_validators), 4, VSRC_PROOF, PR_OFF_NB_B);
+    chain_id_proof(offsetof(tmx_skip_inputs_fixed, target_block_chain_id_proof));
+    height_proof(offsetof(tmx_skip_inputs_fixed, target_block_height_proof));
+    hash_proof(offsetof(tmx_skip_inputs_fixed, target_block_validators_hash_proof), 2, PF_OFF_LEAFV);
+    hash_proof(offsetof(tmx_skip_inputs_fixed, trusted_block_validators_hash_proof), 3, PF_OFF_LEAFX);
+    put(offsetof(tmx_skip_inputs_fixed, report), sizeof(tmx_report), VSRC_REPORT, 0);
+  } else {
+    put(offsetof(tmx_step_inputs_fixed, next_header), 32, VSRC_PF, PF_OFF_HEADER);
+    put(offsetof(tmx_step_inputs_fixed, round), 8, VSRC_PROOF, PR_OFF_ROUND);
+    put(offsetof(tmx_step_inputs_fixed, nb_validators), 4, VSRC_PROOF, PR_OFF_NB_A);
+    chain_id_proof(offsetof(tmx_step_inputs_fixed, next_block_chain_id_proof));
+    height_proof(offsetof(tmx_step_inputs_fixed, next_block_height_proof));
+    hash_proof(offsetof(tmx_step_inputs_fixed, next_block_validators_hash_proof), 2, PF_OFF_LEAFV);
+    const size_t lb = offsetof(tmx_step_inputs_fixed, next_block_last_block_id_proof);
+    put(lb + offsetof(tmx_block_id_inclusion_proof_value, proof), 128, VSRC_PF, PF_OFF_AUNTS + 128 * 3);
+    put(lb + offsetof(tmx_block_id_inclusion_proof_value, leaf), 72, VSRC_PF, PF_OFF_LEAFX);
+    hash_proof(offsetof(tmx_step_inputs_fixed, prev_block_next_validators_hash_proof), 4, PF_OFF_LEAFY);
+    put(offsetof(tmx_step_inputs_fixed, report), sizeof(tmx_report), VSRC_REPORT, 0);
+  }
+  return lut;
+}
+
+extern "C" {
+
+int32_t tmx_value_layout_of(int32_t kind, uint32_t n, uint32_t sections, tmx_value_layout* out) {
+  if (!out || (kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP) || n == 0 || n > TMX_N_MAX_LIMIT || (sections != TMX_SEC_HINT && sections != TMX_SEC_ALL))
+    return TMX_ERR_BAD_ARG;
+  const ValueLayout L = value_layout_for(kind, n, sections);
+  std::memset(out, 0, sizeof *out);
+  auto at = [&](uint32_t p) { return L.off[p + 1] > L.off[p] ? L.off[p] : 0u; };
+  out->bytes = L.off[VP_COUNT];
+  out->fixed_bytes = L.off[VP_FIXED + 1] - L.off[VP_FIXED];
+  out->off_validators = at(VP_VALIDATORS); out->off_hashfields = at(VP_HASHFIELDS);
+  out->off_target_lanes = at(VP_LANE_T); out->off_trusted_lanes = at(VP_LANE_R);
+  out->off_nodes_target = at(VP_NODES_T); out->off_nodes_trusted = at(VP_NODES_R); out->off_proof_derived = at(VP_PROOF_D);
+  out->tree_nodes = L.tree_nodes;
+  return TMX_OK;
+}
+
+int32_t tmx_inputs_value_batch_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets, const void* d_trusteds,
+                                      uint32_t sections, void* d_out, void* hip_stream) {
+  int32_t st = check_batch_args(c, kind, n_proofs, d_proofs, d_targets, d_trusteds);
+  if (st) return st;
+  if (!d_out || (sections != TMX_SEC_HINT && sections != TMX_SEC_ALL)) return fail(c, TMX_ERR_BAD_ARG, "d_out must be set and sections TMX_SEC_HINT or TMX_SEC_ALL");
+  if (n_proofs == 0) return TMX_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  if (!c->d_val_lut[kind]) {  // once per kind (blocking: the table is a local)
+    const std::vector<uint16_t> lut = value_fixed_lut(kind);
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipMalloc(&c->d_val_lut[kind], lut.size() * 2));
+    HIPCK(c, hipMemcpy(c->d_val_lut[kind], lut.data(), lut.size() * 2, hipMemcpyHostToDevice));
+  }
+  // the Level-1 kernels without a single element row: no serializer launch, only the lane / proof records and the reports
+  st = tmx_witness_batch_device(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, nullptr, c->d_reports, hip_stream);
+  if (st) return st;
+  const ValueLayout L = value_layout_for(kind, c->cfg.n_max, sections);
+  ValueSources V;
+  V.proofs = (const uint8_t*)d_proofs; V.targets = (const uint8_t*)d_targets; V.trusteds = (const uint8_t*)d_trusteds;
+  V.tl = (const uint8_t*)c->d_tl; V.lr = (const uint8_t*)c->d_lr; V.pf = (const uint8_t*)c->d_pf;
+  V.nodes_t = (const uint8_t*)c->d_nodes_t; V.nodes_r = (const uint8_t*)c->d_nodes_r; V.reports = (const uint8_t*)c->d_reports;
+  int rc = launch_pack_value(L, V, c->d_val_lut[kind], n_proofs, d_out, s);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_pack_value launch: ") + hipGetErrorString((hipError_t)rc));
+  // the batch now ends with this launch: a later call on another stream must start behind it, not behind the Level-1 kernels' end
+  HIPCK(c, hipEventRecord(c->ev_value, s));
+  c->ev_done = c->ev_value;
+  return TMX_OK;
+}
+
+// the device address of `p` if it is mapped page-locked host memory (hipHostMalloc / hipHostRegister with the mapped flag), else null
+static void* mapped_device_ptr(const void* p) {
+  hipPointerAttribute_t a;
+  std::memset(&a, 0, sizeof a);
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+  return a.devicePointer;
+}
+
+int32_t tmx_inputs_value_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const tmx_proof_rec* proofs, const tmx_validator_rec* targets,
+                               const tmx_hashfield_rec* trusteds, uint32_t sections, void* out, uint64_t cap_bytes) {
+  if (!c || !proofs || !targets || !out || (kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP)) return TMX_ERR_BAD_ARG;
+  if (kind == TMX_KIND_SKIP && !trusteds) return fail(c, TMX_ERR_BAD_ARG, "skip needs the trusted hash fields");
+  if (sections != TMX_SEC_HINT && sections != TMX_SEC_ALL) return fail(c, TMX_ERR_BAD_ARG, "sections must be TMX_SEC_HINT or TMX_SEC_ALL");
+  if (n_proofs == 0) return TMX_OK;
+  if (n_proofs > c->cfg.max_batch) return fail(c, TMX_ERR_CAPACITY, "n_proofs exceeds the context's max_batch");
+  const uint32_t n = c->cfg.n_max;
+  const ValueLayout L = value_layout_for(kind, n, sections);
+  const size_t bytes = (size_t)n_proofs * L.off[VP_COUNT];
+  if (cap_bytes < bytes) return fail(c, TMX_ERR_CAPACITY, "out buffer too small");
+  for (uint32_t p = 0; p < n_proofs; p++)  // reference input/mod.rs:439-444, 338-342
+    if (proofs[p].nb_a > n || (kind == TMX_KIND_SKIP && proofs[p].nb_b > n)) return fail(c, TMX_ERR_SET_TOO_LARGE, "validator set larger than VALIDATOR_SET_SIZE_MAX");
+  int32_t st = ensure_staging_inputs(c);
+  if (st) return st;
+  const size_t lanes = (size_t)n_proofs * n;
+  HIPCK(c, hipMemcpyAsync(c->d_in_proofs, proofs, (size_t)n_proofs * sizeof(tmx_proof_rec), hipMemcpyHostToDevice, c->stream));
+  HIPCK(c, hipMemcpyAsync(c->d_in_targets, targets, lanes * sizeof(tmx_validator_rec), hipMemcpyHostToDevice, c->stream));
+  if (kind == TMX_KIND_SKIP)
+    HIPCK(c, hipMemcpyAsync(c->d_in_trusteds, trusteds, lanes * sizeof(tmx_hashfield_rec), hipMemcpyHostToDevice, c->stream));
+  // A page-locked `out` is written by k_pack_value itself (posted writes over PCIe: no device-to-host copy to enqueue and wait for) up to
+  // TMX_VALUE_DIRECT_MAX bytes; larger transfers, and pageable buffers, go through device staging and one copy.
+  static const size_t direct_max = std::getenv("TMX_VALUE_DIRECT_MAX") ? (size_t)std::atoll(std::getenv("TMX_VALUE_DIRECT_MAX")) : ((size_t)1 << 20);
+  void* direct = bytes <= direct_max ? mapped_device_ptr(out) : nullptr;
+  void* dst = direct;
+  if (!dst) {
+    if (c->d_value_bytes < bytes) {
+      if (c->d_value) { HIPCK(c, hipStreamSynchronize(c->stream)); HIPCK(c, hipFree(c->d_value)); c->d_value = nullptr; c->d_value_bytes = 0; }
+      const size_t per = std::max<size_t>(value_layout_for(TMX_KIND_STEP, n, TMX_SEC_ALL).off[VP_COUNT], value_layout_for(TMX_KIND_SKIP, n, TMX_SEC_ALL).off[VP_COUNT]);
+      const size_t want = (size_t)c->cfg.max_batch * per;
+      HIPCK(c, hipMalloc(&c->d_value, want));
+      c->d_value_bytes = want;
+    }
+    dst = c->d_value;
+  }
+  st = tmx_inputs_value_batch_device(c, kind, n_proofs, c->d_in_proofs, c->d_in_targets, kind == TMX_KIND_SKIP ? c->d_in_trusteds : nullptr, sections, dst,
+                                     c->stream);
+  if (st) return st;
+  if (!direct) HIPCK(c, hipMemcpyAsync(out, c->d_value, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  return TMX_OK;
+}
+
+int32_t tmx_skip_inputs_value(tmx_ctx* c, const tmx_proof_rec* proof, const tmx_validator_rec* target, const tmx_hashfield_rec* trusted, uint32_t sections,
+                              void* out, uint64_t cap_bytes) {
+  return tmx_inputs_value_batch(c, TMX_KIND_SKIP, 1, proof, target, trusted, sections, out, cap_bytes);
+}
+int32_t tmx_step_inputs_value(tmx_ctx* c, const tmx_proof_rec* proof, const tmx_validator_rec* target, uint32_t sections, void* out, uint64_t cap_bytes) {
+  return tmx_inputs_value_batch(c, TMX_KIND_STEP, 1, proof, target, nullptr, sections, out, cap_bytes);
+}
+
+void* tmx_host_alloc(tmx_ctx* c, uint64_t bytes) {
+  if (!c || bytes == 0) return nullptr;
+  if (hipSetDevice(c->cfg.device) != hipSuccess) return nullptr;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void tmx_host_free(tmx_ctx* c, void* p) {
+  (void)c;
+  if (p) (void)hipHostFree(p);
+}
+
+}  // extern "C"
+
+extern "C" {
+
 int32_t tmx_eddsa_lanes(tmx_ctx* c, uint32_t n_lanes, const tmx_validator_rec* lanes, uint8_t* out) {
   if (!c || !lanes || !out) return TMX_ERR_BAD_ARG;
   if (n_lanes == 0) return TMX_OK;
   if ((uint64_t)n_lanes > (uint64_t)c->cfg.max_batch * c->cfg.n_max) return fail(c, TMX_ERR_CAPACITY, "n_lanes exceeds max_batch * n_max");
-  int32_t st = ensure_staging(c);
+  int32_t st = ensure_staging_inputs(c);
   if (st) return st;
   HIPCK(c, hipMemcpyAsync(c->d_in_targets, lanes, (size_t)n_lanes * sizeof(tmx_validator_rec), hipMemcpyHostToDevice, c->stream));
   if (use_tiny(c, n_lanes)) {
@@ -1946,6 +2158,7 @@ struct Rccl {
   int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
@@ -1959,46 +2172,68 @@ int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
   }
   return 0;
 }
-// null on success, else why not
-const char* rccl_load() {
+// empty on success, else why not (returned by value: the caller's copy cannot change under it)
+std::string rccl_load() {
   std::lock_guard<std::mutex> lk(g_rccl_mu);
   Rccl& R = g_rccl;
-  if (R.lib) return nullptr;
-  std::string loaded;
-  (void)dl_iterate_phdr(find_loaded_rccl, &loaded);  // the copy the process already runs on (PyTorch's), if any
+  if (R.lib) return std::string();
+  // an explicit TMX_RCCL_LIB wins (a host that names a library means it -- tests/fake_rccl runs two ranks on one GPU this way); then the
+  // copy the process already runs on (PyTorch's), then the loader's search path
   std::vector<std::string> names;
+  if (const char* v = std::getenv("TMX_RCCL_LIB"))
+    if (v[0]) names.push_back(v);
+  std::string loaded;
+  (void)dl_iterate_phdr(find_loaded_rccl, &loaded);
   if (!loaded.empty()) names.push_back(loaded);
-  if (const char* v = std::getenv("TMX_RCCL_LIB")) names.push_back(v);
   names.push_back("librccl.so.1");
   names.push_back("librccl.so");
   names.push_back("/opt/rocm/lib/librccl.so.1");
   void* h = nullptr;
-  for (const std::string& nm : names)
+  std::string why;
+  for (const std::string& nm : names) {
     if ((h = dlopen(nm.c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
-  if (!h) { R.err = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?"); return R.err.c_str(); }
-  auto sym = [&](const char* n) { return dlsym(h, n); };
-  R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(sym("ncclGetUniqueId"));
-  R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(sym("ncclCommInitRank"));
-  R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
-  R.Broadcast = reinterpret_cast<decltype(R.Broadcast)>(sym("ncclBroadcast"));
-  R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(sym("ncclGroupStart"));
-  R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(sym("ncclGroupEnd"));
-  R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
-  if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.Broadcast || !R.GroupStart || !R.GroupEnd || !R.GetErrorString) {
-    R.err = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclBroadcast / ncclGroupStart / ncclGroupEnd / ncclGetErrorString";
-    return R.err.c_str();
+    const char* e = dlerror();  // (one call: dlerror clears the message it returns)
+    if (why.empty()) why = e ? e : "?";
   }
-  R.lib = h;
-  return nullptr;
+  if (!h) return R.err = "librccl not loadable: " + why;
+  Rccl T;
+  auto sym = [&](const char* n) { return dlsym(h, n); };
+  T.GetUniqueId = reinterpret_cast<decltype(T.GetUniqueId)>(sym("ncclGetUniqueId"));
+  T.CommInitRank = reinterpret_cast<decltype(T.CommInitRank)>(sym("ncclCommInitRank"));
+  T.CommDestroy = reinterpret_cast<decltype(T.CommDestroy)>(sym("ncclCommDestroy"));
+  T.Broadcast = reinterpret_cast<decltype(T.Broadcast)>(sym("ncclBroadcast"));
+  T.AllGather = reinterpret_cast<decltype(T.AllGather)>(sym("ncclAllGather"));
+  T.GroupStart = reinterpret_cast<decltype(T.GroupStart)>(sym("ncclGroupStart"));
+  T.GroupEnd = reinterpret_cast<decltype(T.GroupEnd)>(sym("ncclGroupEnd"));
+  T.GetErrorString = reinterpret_cast<decltype(T.GetErrorString)>(sym("ncclGetErrorString"));
+  if (!T.GetUniqueId || !T.CommInitRank || !T.CommDestroy || !T.Broadcast || !T.AllGather || !T.GroupStart || !T.GroupEnd || !T.GetErrorString) {
+    (void)dlclose(h);  // nothing of a half-bound library stays: the next attempt starts from scratch
+    return R.err = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclBroadcast / ncclAllGather / ncclGroupStart / "
+                   "ncclGroupEnd / ncclGetErrorString";
+  }
+  T.lib = h;
+  R = T;
+  return std::string();
 }
 int32_t rccl_fail(tmx_ctx* c, const char* what, int rc) {
   return fail(c, TMX_ERR_RCCL, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
 }
 constexpr int RCCL_UINT8 = 1;  // ncclUint8
-// every rank's slice [lo_r, hi_r) of `n_items` records of `rec_bytes` becomes resident on every rank: one grouped exchange, in place
+// every rank's slice [lo_r, hi_r) of `n_items` records of `rec_bytes` becomes resident on every rank: one exchange, in place.
+// Equal slices (n_items a multiple of the world: 256 proofs or 512 lanes over 2 / 4 / 8 ranks, BASELINE configs[3] / [4]) are ONE
+// ncclAllGather -- the collective north_star names and the one RCCL schedules over all seven xGMI links at once -- in its in-place form
+// (sendbuff = recvbuff + rank * count); ragged slices fall back to a group of broadcasts, each rank the root of its own slice.
 int32_t exchange_slices(tmx_ctx* c, void* d_buf, uint64_t n_items, size_t rec_bytes, hipStream_t s) {
-  if (!c->comm) return TMX_OK;
-  int rc = g_rccl.GroupStart();
+  if (!c->comm || !d_buf || n_items == 0) return TMX_OK;
+  int rc;
+  if (n_items % c->comm_world == 0) {
+    const size_t per = (size_t)(n_items / c->comm_world) * rec_bytes;
+    uint8_t* base = reinterpret_cast<uint8_t*>(d_buf);
+    rc = g_rccl.AllGather(base + (size_t)c->comm_rank * per, base, per, RCCL_UINT8, c->comm, s);
+    if (rc) return rccl_fail(c, "ncclAllGather", rc);
+    return TMX_OK;
+  }
+  rc = g_rccl.GroupStart();
   if (rc) return rccl_fail(c, "ncclGroupStart", rc);
   for (uint32_t r = 0; r < c->comm_world; r++) {
     uint64_t lo, hi;
@@ -2027,7 +2262,7 @@ void tmx_shard_range(uint64_t n_items, uint32_t rank, uint32_t world, uint64_t* 
 
 int32_t tmx_comm_unique_id(uint8_t out[TMX_UNIQUE_ID_BYTES]) {
   if (!out) return TMX_ERR_BAD_ARG;
-  if (rccl_load()) return TMX_ERR_RCCL;
+  if (!(g_tls_err = rccl_load()).empty()) return TMX_ERR_RCCL;
   RcclId id;
   std::memset(&id, 0, sizeof id);
   if (g_rccl.GetUniqueId(&id)) return TMX_ERR_RCCL;
@@ -2043,7 +2278,10 @@ int32_t tmx_comm_create(tmx_ctx* c, const uint8_t* unique_id, uint32_t rank, uin
   if (world == 1 && !unique_id) { c->comm_rank = 0; c->comm_world = 1; return TMX_OK; }  // nothing to exchange, nothing to load
   // (world == 1 WITH an id makes a real one-rank communicator: the exchange then runs through RCCL -- a broadcast to itself -- which is
   // how the 1-GPU boxes exercise this path)
-  if (const char* why = rccl_load()) return fail(c, TMX_ERR_RCCL, why);
+  {
+    const std::string why = rccl_load();
+    if (!why.empty()) return fail(c, TMX_ERR_RCCL, why);
+  }
   HIPCK(c, hipSetDevice(c->cfg.device));
   RcclId id;
   std::memcpy(id.internal, unique_id, TMX_UNIQUE_ID_BYTES);
@@ -2078,7 +2316,8 @@ int32_t tmx_witness_batch_sharded_device(tmx_ctx* c, int32_t kind, uint32_t n_to
   int32_t st = check_batch_args(c, kind, 0, d_proofs, d_targets, d_trusteds);
   if (st) return st;
   if (n_total == 0) return TMX_OK;
-  if (gather && c->comm_world > 1 && (!d_out_elems || !d_reports)) return fail(c, TMX_ERR_BAD_ARG, "gather needs the row and report buffers");
+  // (a one-rank communicator made WITH an id exchanges through RCCL too: the guard is on the communicator, not on the world size)
+  if (gather && (c->comm || c->comm_world > 1) && (!d_out_elems || !d_reports)) return fail(c, TMX_ERR_BAD_ARG, "gather needs the row and report buffers");
   uint64_t lo, hi;
   tmx_shard_range(n_total, c->comm_rank, c->comm_world, &lo, &hi);
   if (hi - lo > c->cfg.max_batch) return fail(c, TMX_ERR_CAPACITY, "this rank's shard exceeds the context's max_batch");

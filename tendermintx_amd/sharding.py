@@ -52,6 +52,9 @@ def connect(ctx, group=None):
 def proof_sharded_batch(ctx, kind, n_total, d_proofs, d_targets, d_trusteds, d_out, d_reports, gather=False, stream=None):
     """All arguments are device tensors holding ALL n_total proofs / rows (identical inputs on every rank); this rank fills its rows,
     `gather` fills the others'."""
+    if stream is None:  # the buffers were produced on torch's current stream: enqueue behind it (the context's own stream would race their fill)
+        import torch
+        stream = int(torch.cuda.current_stream(d_targets.device).cuda_stream)
     ctx.witness_batch_sharded_device(kind, n_total, d_proofs.data_ptr(), d_targets.data_ptr(), d_trusteds.data_ptr() if d_trusteds is not None else None,
                                      d_out.data_ptr() if d_out is not None else None, d_reports.data_ptr(), gather, stream)
 
@@ -61,6 +64,8 @@ def validator_sharded_skip(ctx, kind, proof, target, trusted, n_proofs=1, stream
     (elements int64 [n_proofs, elem_stride], reports uint8 [n_proofs * 64]) on every rank; one proof: ([elem_count], [64]) as before."""
     import torch
     dev = target.device
+    if stream is None:  # out / rep are zero-filled on torch's current stream and handed back to it: the kernels must be ordered with both
+        stream = int(torch.cuda.current_stream(dev).cuda_stream)
     out = torch.zeros((n_proofs, ctx.elem_stride(kind)), dtype=torch.int64, device=dev)
     rep = torch.zeros(n_proofs * 64, dtype=torch.uint8, device=dev)
     ctx.witness_validator_sharded_device(kind, n_proofs, proof.data_ptr(), target.data_ptr(), trusted.data_ptr() if trusted is not None else None,
