@@ -6,6 +6,10 @@
  *   step    <fixtures> <n_max> <chain_id> <out.bin> <prev_block> <prev_hash_hex>                           tmx_step_witness, u64 row
  *   hint32  <fixtures> <n_max> <chain_id> <out.bin> <trusted_block> <trusted_hash_hex> <target_block>      tmx_witness_batch_opts(TMX_SEC_HINT,
  *                                                                                                           TMX_OUT_U32): the hint section as u32
+ *   value   <fixtures> <n_max> <chain_id> <out.bin> <trusted_block> <trusted_hash_hex> <target_block>      tmx_skip_inputs_value(TMX_SEC_ALL) into
+ *           page-locked memory from tmx_host_alloc: the typed SkipInputs value + derived values; prints fields READ BY NAME from the structs
+ *           (what a hint body assigns into VerifySkipStruct, reference circuits/skip.rs:85-98) and the host-to-host ms per call of 50 warm calls
+ *   stepvalue <fixtures> <n_max> <chain_id> <out.bin> <prev_block> <prev_hash_hex>                         tmx_step_inputs_value(TMX_SEC_ALL)
  *   threads <fixtures> <n_max> <chain_id> <out.bin> <trusted_block> <trusted_hash_hex> <target_block> <iters>
  *           two host threads, each with a context of its own, run the same skip witness `iters` times concurrently (the calling pattern of
  *           a tokio host with several hint workers, reference circuits/skip.rs:37-44: contexts of one device share the library's internal
@@ -123,6 +127,30 @@ int main(int argc, char** argv) {
   uint8_t hash[32];
   unhex32(argv[7], hash);
   tmx_report rep;
+  if (!strcmp(mode, "stepvalue")) {
+    tmx_ctx* ctx = make_ctx(n, chain);
+    tmx_proof_rec proof;
+    tmx_validator_rec* tg = (tmx_validator_rec*)calloc(n, sizeof *tg);
+    char *pc = slurp(dir, block, "commit.json"), *nc = slurp(dir, block + 1, "commit.json"), *nv = slurp(dir, block + 1, "validators_1.json");
+    int32_t st = tmx_step_inputs_from_json(pc, nc, nv, n, block, hash, &proof, tg);
+    if (st) { fprintf(stderr, "codec: %s\n", tmx_status_str(st)); return 1; }
+    tmx_value_layout lay;
+    if (tmx_value_layout_of(TMX_KIND_STEP, n, TMX_SEC_ALL, &lay)) return 1;
+    uint8_t* val = (uint8_t*)tmx_host_alloc(ctx, lay.bytes);
+    if (!val) { fprintf(stderr, "tmx_host_alloc failed\n"); return 1; }
+    st = tmx_step_inputs_value(ctx, &proof, tg, TMX_SEC_ALL, val, lay.bytes);
+    if (st) { fprintf(stderr, "tmx_step_inputs_value: %s -- %s\n", tmx_status_str(st), tmx_last_error(ctx)); return 1; }
+    const tmx_step_inputs_fixed* f = (const tmx_step_inputs_fixed*)val;
+    const tmx_validator_value* vals = (const tmx_validator_value*)(val + lay.off_validators);
+    print_report(&f->report, lay.bytes);
+    printf("nb_validators %u round %llu height %llu enc_height_len %u last_block_id_leaf0 %02x%02x signed0 %u power0 %llu\n", f->nb_validators,
+           (unsigned long long)f->round, (unsigned long long)f->next_block_height_proof.height, f->next_block_height_proof.enc_height_byte_length,
+           f->next_block_last_block_id_proof.leaf[0], f->next_block_last_block_id_proof.leaf[1], vals[0].signed_, (unsigned long long)vals[0].voting_power);
+    dump(out, val, lay.bytes);
+    tmx_host_free(ctx, val);
+    tmx_ctx_destroy(ctx);
+    return memcmp(f->next_header, f->report.header, 32) ? 1 : 0;
+  }
   if (!strcmp(mode, "step")) {
     tmx_ctx* ctx = make_ctx(n, chain);
     tmx_proof_rec proof;
@@ -158,6 +186,34 @@ int main(int argc, char** argv) {
            ki.last_hit_lanes);
     tmx_ctx_destroy(ctx);
     return 0;
+  }
+  if (!strcmp(mode, "value")) {
+    tmx_ctx* ctx = make_ctx(n, chain);
+    tmx_value_layout lay;
+    if (tmx_value_layout_of(TMX_KIND_SKIP, n, TMX_SEC_ALL, &lay)) return 1;
+    uint8_t* val = (uint8_t*)tmx_host_alloc(ctx, lay.bytes);
+    if (!val) { fprintf(stderr, "tmx_host_alloc failed\n"); return 1; }
+    int32_t st = tmx_skip_inputs_value(ctx, &in.proof, in.tg, in.tr, TMX_SEC_ALL, val, lay.bytes);   /* cold: also makes the keys resident */
+    if (st) { fprintf(stderr, "tmx_skip_inputs_value: %s -- %s\n", tmx_status_str(st), tmx_last_error(ctx)); return 1; }
+    const double t0 = now_ms();
+    for (int i = 0; i < 50 && !st; i++) st = tmx_skip_inputs_value(ctx, &in.proof, in.tg, in.tr, TMX_SEC_ALL, val, lay.bytes);
+    const double ms = (now_ms() - t0) / 50;
+    if (st) { fprintf(stderr, "tmx_skip_inputs_value: %s -- %s\n", tmx_status_str(st), tmx_last_error(ctx)); return 1; }
+    /* the fields a hint body assigns into VerifySkipStruct (circuits/skip.rs:85-98), read by name */
+    const tmx_skip_inputs_fixed* f = (const tmx_skip_inputs_fixed*)val;
+    const tmx_validator_value* vals = (const tmx_validator_value*)(val + lay.off_validators);
+    const tmx_hashfield_value* hfs = (const tmx_hashfield_value*)(val + lay.off_hashfields);
+    print_report(&f->report, lay.bytes);
+    printf("nb_target %u nb_trusted %u round %llu height %llu enc_chain_id_len %u chain_id %.*s signed0 %u power0 %llu trusted_power0 %llu ms_per_call %.4f\n",
+           f->nb_target_validators, f->nb_trusted_validators, (unsigned long long)f->round, (unsigned long long)f->target_block_height_proof.height,
+           f->target_block_chain_id_proof.enc_chain_id_byte_length, (int)f->target_block_chain_id_proof.enc_chain_id_byte_length - 2,
+           (const char*)f->target_block_chain_id_proof.chain_id + 2, vals[0].signed_, (unsigned long long)vals[0].voting_power,
+           (unsigned long long)hfs[0].voting_power, ms);
+    dump(out, val, lay.bytes);
+    const int same = memcmp(f->target_header, f->report.header, 32) == 0 && memcmp(f->trusted_header, hash, 32) == 0;
+    tmx_host_free(ctx, val);
+    tmx_ctx_destroy(ctx);
+    return same ? 0 : 1;
   }
   if (!strcmp(mode, "hint32")) {
     tmx_ctx* ctx = make_ctx(n, chain);

@@ -78,6 +78,51 @@ def test_hint_section_as_u32_from_c_host(host, oracle, cases, tmp_path, built_li
     assert hint == 1776 * 32 + 5320 and got.size == hint and np.array_equal(got.astype(np.uint64), want[:hint])
 
 
+@pytest.mark.parametrize("kind,a,b,n", [(0, 10000, 10500, 4), (0, 10000, 10500, 32), (0, 10500, 157001, 128), (0, 10500, 157001, 512),
+                                         (1, 10000, 0, 2), (1, 10500, 0, 4), (1, 10500, 0, 100), (1, 10500, 0, 512)])
+def test_typed_value_from_c_host(host, oracle, built_lib, tmp_path, kind, a, b, n):
+    """tmx_skip_inputs_value / tmx_step_inputs_value from compiled C into page-locked memory (tmx_host_alloc): the packed SkipInputs<F> /
+    StepInputs<F> value (reference circuits/input/mod.rs:45-74) equals the oracle's byte for byte, and -- expanded by THIS test by the
+    reference's element rules -- reproduces section H (and, through the derived part, the whole row) at N = 4 / 32 / 128 / 512 and for step"""
+    import ctypes as C
+    from tendermintx_amd import _lib
+    from tendermintx_amd.circuits import InputDataFetcher
+    from test_typed_value import expand_derived, expand_hint
+    f = InputDataFetcher(FX)
+    import tmx_model as m
+    pf = m.FixtureFetcher(FX)
+    if kind == 0:
+        pr, tg, tr = m.skip_inputs_from_fixtures(pf, a, b, n)
+        targets, trusteds = b"".join(tg), b"".join(tr)
+        h = m.unpack_proof(pr)["hash"].hex()
+        args = [host, "value", FX, str(n), "mocha-4", str(tmp_path / "v.bin"), str(a), h, str(b)]
+    else:
+        pr, tg = m.step_inputs_from_fixtures(pf, a, n)
+        targets, trusteds = b"".join(tg), None
+        h = m.unpack_proof(pr)["hash"].hex()
+        args = [host, "stepvalue", FX, str(n), "mocha-4", str(tmp_path / "v.bin"), str(a), h]
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.split("\n")
+    want, orep = oracle.witness_value(kind, pr, targets, trusteds, b"mocha-4", 100800, True)
+    got = np.fromfile(str(tmp_path / "v.bin"), dtype=np.uint8)
+    assert got.size == want.size and np.array_equal(got, want)
+    assert lines[0] == "header " + orep["header"].hex() and _fields(lines[1])["all_ok"] == str(int(orep["all_ok"]))   # (10500 -> 157001 is too far: dist_ok fails, as in the goldens)
+    named = _fields(lines[2])
+    row, _ = oracle.witness(kind, pr, targets, trusteds, b"mocha-4", 100800)
+    lay = _lib.ValueLayout()
+    assert built_lib.tmx_value_layout_of(kind, n, _lib.SEC_ALL, C.byref(lay)) == 0
+    hint = int(built_lib.tmx_hint_elem_count(kind, n))
+    assert np.array_equal(expand_hint(_lib, kind, n, got, lay), row[:hint])
+    assert np.array_equal(expand_derived(_lib, kind, n, got, lay), row[hint:])
+    # the fields the C program read by name are the record's
+    if kind == 0:
+        assert named["chain_id"] == "mocha-4" and int(named["height"]) == b and int(named["nb_target"]) == m.unpack_proof(pr)["nb_a"]
+        print("typed value from C host, N =", n, "host-to-host ms per call:", named["ms_per_call"])
+    else:
+        assert int(named["height"]) == a + 1 and int(named["nb_validators"]) == m.unpack_proof(pr)["nb_a"]
+
+
 def test_two_host_threads_two_contexts(host, oracle, cases, tmp_path):
     """Two threads, a context each, 40 skip witnesses each at the same time: every row equals the single-threaded one and the oracle's
     (the contexts share the device's three internal side streams; each owns its scratch, events and key cache)."""
