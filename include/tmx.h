@@ -349,15 +349,17 @@ int32_t tmx_last_dedup(tmx_ctx* ctx, uint32_t* n_unique, uint32_t* used_tables);
 
 /* ---- multi-GPU: one process per GPU, the exchange step behind this ABI so that the host the reference actually has -- the
  * Rust process of bin/skip.rs, reached only through SkipOffchainInputs::hint (reference circuits/skip.rs:64-102) -- can shard without
- * any Python.  RCCL is resolved at run time from the host process (no DT_NEEDED, like the HIP runtime): an already loaded librccl is
- * used, else $TMX_RCCL_LIB, else librccl.so.1 / librccl.so by the loader's search path.  Bootstrap as with NCCL: ONE rank calls
+ * any Python.  RCCL is resolved at run time from the host process (no DT_NEEDED, like the HIP runtime): $TMX_RCCL_LIB if set (then it is
+ * the only candidate), else an already loaded librccl, else librccl.so.1 / librccl.so by the loader's search path.  A context-less call
+ * (tmx_comm_unique_id) leaves its reason in tmx_last_error(NULL), per thread.  Bootstrap as with NCCL: ONE rank calls
  * tmx_comm_unique_id, hands the 128 bytes to the others by whatever channel the host has (a file, its RPC, MPI ...), then every rank calls
  * tmx_comm_create(ctx, id, rank, world) on a context of ITS device.  world = 1 needs no id and loads nothing.
  *   tmx_shard_range                       contiguous [lo, hi) of n_items for `rank` of `world`; sizes differ by at most one
  *   tmx_witness_batch_sharded_device      BASELINE configs[3]: n_total independent proofs, every rank holds all input records and an output
  *                                         buffer for all rows; rank r computes rows [lo_r, hi_r) in place; gather != 0 then makes every row
- *                                         (and report) resident on every rank -- one grouped RCCL exchange, each rank broadcasting its slice
- *                                         in place: no padding, no staging copy.  gather = 0: no data-path collective at all.
+ *                                         (and report) resident on every rank -- ONE exchange in place, no padding, no staging copy: an
+ *                                         ncclAllGather when n_total divides by the world (256 proofs over 2 / 4 / 8 ranks), else a group of
+ *                                         broadcasts, each rank the root of its own slice.  gather = 0: no data-path collective at all.
  *   tmx_witness_validator_sharded_device  BASELINE configs[4]: the n_proofs * n_max validator lanes split across the ranks for the EdDSA stage,
  *                                         ONE grouped exchange of the 448-byte lane records, then every rank finishes every proof
  *                                         (tmx_finish_batch_device on the reassembled records): full rows + reports on every rank.
@@ -372,6 +374,24 @@ int32_t tmx_witness_batch_sharded_device(tmx_ctx* ctx, int32_t kind, uint32_t n_
                                          const void* d_trusteds, void* d_out_elems, void* d_reports, uint32_t gather, void* hip_stream);
 int32_t tmx_witness_validator_sharded_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
                                              const void* d_trusteds, void* d_out_elems, void* d_reports, void* hip_stream);
+
+/* The Level-2 trace rows across the ranks (the one payload of this path big enough for xGMI to matter: 41 MB per proof at N = 128, 136 MB at
+ * N = 512).  Same conventions as above: d_trace_out holds the rows of ALL proofs (tmx_trace_elem_count() u64 each), asynchronous on hip_stream.
+ *   tmx_trace_rows_sharded_device            after tmx_witness_batch_sharded_device of the same n_total: rank r writes the rows of its proofs
+ *                                            [lo_r, hi_r) in place; gather != 0: one exchange (ncclAllGather when the shards are equal) leaves
+ *                                            every proof's rows on every rank.
+ *   tmx_trace_rows_validator_sharded_device  after tmx_witness_validator_sharded_device of the same n_proofs: the per-lane sections (ladders,
+ *                                            SHA-512 rounds: 93 % of the rows) are computed for this rank's lanes only and exchanged lane slab
+ *                                            by lane slab (one proof: one all-gather per section); the small per-proof sections (leaf / tree /
+ *                                            header SHA-256, N x N) are computed on every rank.  All rows on every rank afterwards.
+ *   tmx_trace_commit_sharded_device          tmx_trace_commit_device over this rank's own proofs (no row crosses a link), its cap into slot
+ *                                            `rank` of d_caps[world][4 << cap_height], then ONE all-gather of the caps. */
+int32_t tmx_trace_rows_sharded_device(tmx_ctx* ctx, int32_t kind, uint32_t n_total, const void* d_targets, const void* d_trusteds, void* d_trace_out,
+                                      uint32_t sections, uint32_t gather, void* hip_stream);
+int32_t tmx_trace_rows_validator_sharded_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const void* d_targets, const void* d_trusteds,
+                                                void* d_trace_out, uint32_t sections, void* hip_stream);
+int32_t tmx_trace_commit_sharded_device(tmx_ctx* ctx, int32_t kind, uint32_t n_total, uint32_t section, uint32_t log_blowup, uint32_t cap_height,
+                                        const void* d_trace_rows, uint64_t* d_caps /*[world][4 << cap_height]*/, void* hip_stream);
 
 /* ---- persistent per-key table cache.  h*A of a lane is 32 additions from a 655-KB window table of its public key instead of 252
  * doublings + 64 additions; the context keeps those tables in a content-addressed cache in HBM (key = the 32 public-key bytes, all 32

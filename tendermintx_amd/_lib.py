@@ -246,6 +246,9 @@ def lib():
                                                    C.c_uint32, C.c_void_p]
     L.tmx_witness_validator_sharded_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                        C.c_void_p]
+    L.tmx_trace_rows_sharded_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.tmx_trace_rows_validator_sharded_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.tmx_trace_commit_sharded_device.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tmx_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.tmx_kernel_ms_mean.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
     L.tmx_ctx_stream.restype = C.c_void_p

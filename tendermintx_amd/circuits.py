@@ -143,6 +143,22 @@ class SkipCircuit(_Circuit):
             raise AssertionError("Signature should be valid for validator")
         return elems[0], rep
 
+    def hint_value(self, trusted_block, trusted_header_hash, target_block):
+        """SkipOffchainInputs::hint up to the value it builds: the reference's `SkipInputs<F>` (input/mod.rs:60-74) as the typed structs of
+        include/tmx.h -- (SkipInputsFixed, ValidatorValue[N], HashFieldValue[N]) -- from which the hint body assigns `VerifySkipStruct`
+        by field name (skip.rs:85-98).  No element row is produced on the device (tmx_skip_inputs_value)."""
+        proof, target, trusted = self.fetcher.get_skip_inputs(self.n, trusted_block, trusted_header_hash, target_block)
+        val, lay = self.ctx.inputs_value_batch(KIND_SKIP, proof, target, trusted, _lib.SEC_HINT)
+        buf = bytes(val[0])
+        fixed = _lib.SkipInputsFixed.from_buffer_copy(buf[:lay.fixed_bytes])
+        if fixed.report.fail_mask & 1:
+            raise AssertionError("Trusted header hash doesn't pass sanity check! An incorrect header was likely pushed to the "
+                                 "contract, typically the genesis header.")
+        if fixed.report.first_bad_sig >= 0:
+            raise AssertionError("Signature should be valid for validator")
+        return (fixed, (_lib.ValidatorValue * self.n).from_buffer_copy(buf[lay.off_validators:lay.off_validators + 240 * self.n]),
+                (_lib.HashFieldValue * self.n).from_buffer_copy(buf[lay.off_hashfields:lay.off_hashfields + 48 * self.n]))
+
     def prove_public(self, input_bytes):
         """`circuit.prove(PublicInput::Bytes(..))` at the public-value level (skip.rs:197-212): 48 B in, 32 B out."""
         tb, th, gb = C.c_uint64(), C.create_string_buffer(32), C.c_uint64()
@@ -168,6 +184,18 @@ class StepCircuit(_Circuit):
         if rep["first_bad_sig"] >= 0:
             raise AssertionError("Signature should be valid for validator")
         return elems[0], rep
+
+    def hint_value(self, prev_block_number, prev_header_hash):
+        """StepOffchainInputs::hint up to the `StepInputs<F>` value (input/mod.rs:45-58): (StepInputsFixed, ValidatorValue[N])."""
+        proof, target = self.fetcher.get_step_inputs(self.n, prev_block_number, prev_header_hash)
+        val, lay = self.ctx.inputs_value_batch(KIND_STEP, proof, target, None, _lib.SEC_HINT)
+        buf = bytes(val[0])
+        fixed = _lib.StepInputsFixed.from_buffer_copy(buf[:lay.fixed_bytes])
+        if fixed.report.fail_mask & (1 << 12):
+            raise AssertionError("Prev header hash doesn't pass sanity check")
+        if fixed.report.first_bad_sig >= 0:
+            raise AssertionError("Signature should be valid for validator")
+        return fixed, (_lib.ValidatorValue * self.n).from_buffer_copy(buf[lay.off_validators:lay.off_validators + 240 * self.n])
 
     def prove_public(self, input_bytes):
         pb, ph = C.c_uint64(), C.create_string_buffer(32)

@@ -276,6 +276,18 @@ class Context:
         check(self._L.tmx_witness_validator_sharded_device(self._h, kind, n_proofs, d_proofs, d_targets, d_trusteds, d_out, d_reports,
                                                            self._stream(stream)), self._h)
 
+    def trace_rows_sharded_device(self, kind, n_total, d_targets, d_trusteds, d_trace_out, sections=_lib.TRACE_ALL, gather=False, stream=None):
+        """Level-2 rows of this rank's proofs of a proof-sharded batch (after witness_batch_sharded_device of the same n_total); gather: all rows everywhere."""
+        check(self._L.tmx_trace_rows_sharded_device(self._h, kind, n_total, d_targets, d_trusteds, d_trace_out, sections, 1 if gather else 0,
+                                                    self._stream(stream)), self._h)
+
+    def trace_rows_validator_sharded_device(self, kind, n_proofs, d_targets, d_trusteds, d_trace_out, sections=_lib.TRACE_ALL, stream=None):
+        """Level-2 rows with the per-lane sections (ladders, SHA-512) lane-sharded and exchanged (after witness_validator_sharded_device)."""
+        check(self._L.tmx_trace_rows_validator_sharded_device(self._h, kind, n_proofs, d_targets, d_trusteds, d_trace_out, sections, self._stream(stream)), self._h)
+
+    def trace_commit_sharded_device(self, kind, n_total, section, log_blowup, cap_height, d_trace_rows, d_caps, stream=None):
+        check(self._L.tmx_trace_commit_sharded_device(self._h, kind, n_total, section, log_blowup, cap_height, d_trace_rows, d_caps, self._stream(stream)), self._h)
+
     def last_kernel_ms(self):
         ms = (C.c_float * _lib.N_KERNELS)()
         check(self._L.tmx_last_kernel_ms(self._h, ms), self._h)

@@ -1294,8 +1294,11 @@ uint64_t tmx_trace_elem_count(int32_t kind, uint32_t n) {
   return trace_elems((uint32_t)kind, n);
 }
 
-int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_targets, const void* d_trusteds, void* d_trace_out,
-                              uint32_t sections, void* hip_stream) {
+}  // extern "C"
+// lane0 / lane_count: the ladder and SHA-512 rows (the per-lane sections) of lanes [lane0, lane0 + lane_count) of the batch only -- the
+// lane-sharded form; the other sections are written for every proof either way
+static int32_t trace_rows_impl(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_targets, const void* d_trusteds, void* d_trace_out,
+                               uint32_t sections, void* hip_stream, uint32_t lane0, uint32_t lane_count) {
   if (!c || (kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP) || !d_targets || !d_trace_out || (sections & ~(uint32_t)TMX_TRACE_ALL) || sections == 0)
     return TMX_ERR_BAD_ARG;
   if (kind == TMX_KIND_SKIP && !d_trusteds) return fail(c, TMX_ERR_BAD_ARG, "skip needs the trusted hash fields");
@@ -1321,7 +1324,7 @@ int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const
     HIPCK(c, hipEventRecord(c->ev_trace_rest[0], s));
     HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_trace_rest[0], 0));
     const TraceLevel1 L1 = {reinterpret_cast<const uint8_t*>(c->d_tl) + TL_OFF_LT, c->d_lr, c->d_nodes_t, c->d_nodes_r, c->d_pf, TL_STRIDE};
-    rc = launch_trace_rest((uint32_t)kind, n, n_proofs, d_targets, d_trusteds, L1, d_trace_out, sections, c->side3);
+    rc = launch_trace_rest((uint32_t)kind, n, n_proofs, d_targets, d_trusteds, L1, d_trace_out, sections, c->side3, lane0, lane_count);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_trace launch: ") + hipGetErrorString((hipError_t)rc));
     HIPCK(c, hipEventRecord(c->ev_trace_rest[1], c->side3));
   }
@@ -1335,14 +1338,14 @@ int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const
       if (!e) HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (uint32_t g = 0; g < segs && !rc; g++) {
       const uint32_t r0 = TR_LADDER_ROWS * g / segs, r1 = TR_LADDER_ROWS * (g + 1) / segs;
-      rc = launch_trace_ladder_pass1(n, n_proofs, d_targets, edr, TL_STRIDE, c->d_trace_tmp, r0, r1, s);
+      rc = launch_trace_ladder_pass1(n, n_proofs, d_targets, edr, TL_STRIDE, c->d_trace_tmp, r0, r1, s, lane0, lane_count);
       if (rc) break;
       hipStream_t p2 = c->side;
       {
         HIPCK(c, hipEventRecord(c->ev_trace[g], s));
         HIPCK(c, hipStreamWaitEvent(p2, c->ev_trace[g], 0));
       }
-      rc = launch_trace_ladder_pass2((uint32_t)kind, n, n_proofs, d_targets, edr, TL_STRIDE, c->d_trace_tmp, d_trace_out, r0, r1, p2);
+      rc = launch_trace_ladder_pass2((uint32_t)kind, n, n_proofs, d_targets, edr, TL_STRIDE, c->d_trace_tmp, d_trace_out, r0, r1, p2, lane0, lane_count);
     }
     if (!rc) {
       HIPCK(c, hipEventRecord(c->ev_trace[16], c->side));
@@ -1351,11 +1354,16 @@ int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const
   if (!rc && rest_aside) HIPCK(c, hipStreamWaitEvent(s, c->ev_trace_rest[1], 0));
   if (!rc && (sections & ~(uint32_t)TMX_TRACE_LADDERS) && !rest_aside) {
     const TraceLevel1 L1 = {reinterpret_cast<const uint8_t*>(c->d_tl) + TL_OFF_LT, c->d_lr, c->d_nodes_t, c->d_nodes_r, c->d_pf, TL_STRIDE};
-    rc = launch_trace_rest((uint32_t)kind, n, n_proofs, d_targets, d_trusteds, L1, d_trace_out, sections, s);
+    rc = launch_trace_rest((uint32_t)kind, n, n_proofs, d_targets, d_trusteds, L1, d_trace_out, sections, s, lane0, lane_count);
   }
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_trace launch: ") + hipGetErrorString((hipError_t)rc));
   if ((sections & TMX_TRACE_LADDERS) && c->ev_trace[16]) HIPCK(c, hipStreamWaitEvent(s, c->ev_trace[16], 0));  // the call ends on the caller's stream
   return TMX_OK;
+}
+extern "C" {
+int32_t tmx_trace_rows_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_targets, const void* d_trusteds, void* d_trace_out,
+                              uint32_t sections, void* hip_stream) {
+  return trace_rows_impl(c, kind, n_proofs, d_targets, d_trusteds, d_trace_out, sections, hip_stream, 0, 0xffffffffu);
 }
 
 int32_t tmx_kernel_ms_mean(tmx_ctx* c, uint32_t last_k, float ms[TMX_N_KERNELS]) {
@@ -2177,17 +2185,21 @@ std::string rccl_load() {
   std::lock_guard<std::mutex> lk(g_rccl_mu);
   Rccl& R = g_rccl;
   if (R.lib) return std::string();
-  // an explicit TMX_RCCL_LIB wins (a host that names a library means it -- tests/fake_rccl runs two ranks on one GPU this way); then the
-  // copy the process already runs on (PyTorch's), then the loader's search path
+  // an explicit TMX_RCCL_LIB is the ONLY candidate (a host that names a library means it, and a wrong name must be an error, not a silent
+  // fall-through to some other copy -- tests/fake_rccl runs two ranks on one GPU this way); otherwise the copy the process already runs on
+  // (PyTorch's), then the loader's search path
   std::vector<std::string> names;
-  if (const char* v = std::getenv("TMX_RCCL_LIB"))
-    if (v[0]) names.push_back(v);
-  std::string loaded;
-  (void)dl_iterate_phdr(find_loaded_rccl, &loaded);
-  if (!loaded.empty()) names.push_back(loaded);
-  names.push_back("librccl.so.1");
-  names.push_back("librccl.so");
-  names.push_back("/opt/rocm/lib/librccl.so.1");
+  const char* forced = std::getenv("TMX_RCCL_LIB");
+  if (forced && forced[0]) {
+    names.push_back(forced);
+  } else {
+    std::string loaded;
+    (void)dl_iterate_phdr(find_loaded_rccl, &loaded);
+    if (!loaded.empty()) names.push_back(loaded);
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+  }
   void* h = nullptr;
   std::string why;
   for (const std::string& nm : names) {
@@ -2265,7 +2277,10 @@ int32_t tmx_comm_unique_id(uint8_t out[TMX_UNIQUE_ID_BYTES]) {
   if (!(g_tls_err = rccl_load()).empty()) return TMX_ERR_RCCL;
   RcclId id;
   std::memset(&id, 0, sizeof id);
-  if (g_rccl.GetUniqueId(&id)) return TMX_ERR_RCCL;
+  if (const int rc = g_rccl.GetUniqueId(&id)) {
+    g_tls_err = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(rc);
+    return TMX_ERR_RCCL;
+  }
   std::memcpy(out, id.internal, TMX_UNIQUE_ID_BYTES);
   return TMX_OK;
 }
@@ -2353,6 +2368,73 @@ int32_t tmx_witness_validator_sharded_device(tmx_ctx* c, int32_t kind, uint32_t 
   return tmx_finish_batch_device(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, ed, d_out_elems, d_reports, hip_stream);
 }
 
+// ---- Level-2 trace rows across the ranks (north_star: "validators AND TRACE ROWS shard across the 8 GPUs ... with an RCCL all-gather").
+// The rows are the one payload of this path that is big enough for xGMI to matter: 41 MB per proof at N = 128, 136 MB at N = 512.
+int32_t tmx_trace_rows_sharded_device(tmx_ctx* c, int32_t kind, uint32_t n_total, const void* d_targets, const void* d_trusteds, void* d_trace_out,
+                                      uint32_t sections, uint32_t gather, void* hip_stream) {
+  if (!c || (kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP) || !d_targets || !d_trace_out) return TMX_ERR_BAD_ARG;
+  if (n_total == 0) return TMX_OK;
+  uint64_t lo, hi;
+  tmx_shard_range(n_total, c->comm_rank, c->comm_world, &lo, &hi);
+  const uint32_t n = c->cfg.n_max;
+  const size_t row_bytes = (size_t)trace_elems((uint32_t)kind, n) * 8;
+  auto at = [](const void* p, size_t off) { return p ? reinterpret_cast<const uint8_t*>(p) + off : nullptr; };
+  if (hi > lo) {  // the Level-1 records this reads are those of the rank's own shard: tmx_witness_batch_sharded_device of the same n_total came first
+    int32_t st = tmx_trace_rows_device(c, kind, (uint32_t)(hi - lo), at(d_targets, lo * n * VR_STRIDE), at(d_trusteds, lo * n * HR_STRIDE),
+                                       const_cast<uint8_t*>(at(d_trace_out, lo * row_bytes)), sections, hip_stream);
+    if (st) return st;
+  }
+  if (!gather) return TMX_OK;
+  return exchange_slices(c, d_trace_out, n_total, row_bytes, reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+int32_t tmx_trace_rows_validator_sharded_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void* d_targets, const void* d_trusteds, void* d_trace_out,
+                                                uint32_t sections, void* hip_stream) {
+  if (!c || (kind != TMX_KIND_SKIP && kind != TMX_KIND_STEP) || !d_targets || !d_trace_out) return TMX_ERR_BAD_ARG;
+  if (n_proofs == 0) return TMX_OK;
+  const uint32_t n = c->cfg.n_max;
+  const uint64_t lanes = (uint64_t)n_proofs * n;
+  uint64_t lo, hi;
+  tmx_shard_range(lanes, c->comm_rank, c->comm_world, &lo, &hi);
+  // the per-lane sections (ladders: 266 KB per lane, SHA-512: 23 KB) for this rank's lanes; the small per-proof sections on every rank
+  int32_t st = trace_rows_impl(c, kind, n_proofs, d_targets, d_trusteds, d_trace_out, sections, hip_stream, (uint32_t)lo, (uint32_t)(hi - lo));
+  if (st || !c->comm) return st;
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  uint8_t* out = reinterpret_cast<uint8_t*>(d_trace_out);
+  const size_t row_bytes = (size_t)trace_elems((uint32_t)kind, n) * 8;
+  struct Sec { uint32_t bit; size_t off, per_lane; };
+  const Sec secs[2] = {{TMX_TRACE_LADDERS, 0, (size_t)2 * TR_LADDER_ROWS * TR_LADDER_ROW * 8},
+                       {TMX_TRACE_SHA512, (size_t)n * 2 * TR_LADDER_ROWS * TR_LADDER_ROW * 8, (size_t)2 * 80 * TR_SHA512_ROW * 8}};
+  for (const Sec& sc : secs) {
+    if (!(sections & sc.bit)) continue;
+    if (n_proofs == 1) {  // one proof: its lanes' slabs are contiguous -- the all-gather of SURVEY 8(e) when the lanes divide evenly
+      if ((st = exchange_slices(c, out + sc.off, lanes, sc.per_lane, s))) return st;
+      continue;
+    }
+    // several proofs: a rank's lanes are one run per proof it touches; every run is broadcast by its owner, grouped
+    int rc = g_rccl.GroupStart(), in_group = 0;
+    if (rc) return rccl_fail(c, "ncclGroupStart", rc);
+    for (uint32_t r = 0; r < c->comm_world; r++) {
+      uint64_t rlo, rhi;
+      tmx_shard_range(lanes, r, c->comm_world, &rlo, &rhi);
+      for (uint64_t p = rlo / n; p < n_proofs && p * n < rhi; p++) {
+        const uint64_t a = std::max<uint64_t>(rlo, p * n), b = std::min<uint64_t>(rhi, (p + 1) * n);
+        if (b <= a) continue;
+        uint8_t* ptr = out + p * row_bytes + sc.off + (a - p * n) * sc.per_lane;
+        rc = g_rccl.Broadcast(ptr, ptr, (size_t)(b - a) * sc.per_lane, RCCL_UINT8, (int)r, c->comm, s);
+        if (rc) { (void)g_rccl.GroupEnd(); return rccl_fail(c, "ncclBroadcast", rc); }
+        if (++in_group == 32) {  // (bounded groups: a group is one fused launch, and a thousand-entry group helps nobody)
+          if ((rc = g_rccl.GroupEnd())) return rccl_fail(c, "ncclGroupEnd", rc);
+          if ((rc = g_rccl.GroupStart())) return rccl_fail(c, "ncclGroupStart", rc);
+          in_group = 0;
+        }
+      }
+    }
+    if ((rc = g_rccl.GroupEnd())) return rccl_fail(c, "ncclGroupEnd", rc);
+  }
+  return TMX_OK;
+}
+
 }  // extern "C"
 
 // ---- the commit pipeline on the device: section rows -> columns -> LDE -> Poseidon Merkle cap (include/tmx.h) ---------------------------
@@ -2416,6 +2498,27 @@ int32_t tmx_trace_commit_device(tmx_ctx* c, int32_t kind, uint32_t n_proofs, uin
   HIPCK(c, hipMemcpyAsync(d_cap, levels + 4 * (n_dig - n_cap), n_cap * 32, hipMemcpyDeviceToDevice, s));
   HIPCK(c, hipEventRecord(c->ev_commit[3], s));
   return TMX_OK;
+}
+
+// the commit of a proof-sharded batch: every rank commits the columns of ITS proofs (their rows are already in its HBM: no row crosses a
+// link), its cap lands in slot `rank` of d_caps, and ONE all-gather of the caps (16 digests each at cap_height 4: 512 B) leaves all of
+// them on every rank -- the batch's commitment is the `world` caps, each over n_shard * width columns
+int32_t tmx_trace_commit_sharded_device(tmx_ctx* c, int32_t kind, uint32_t n_total, uint32_t section, uint32_t log_blowup, uint32_t cap_height,
+                                        const void* d_trace_rows, uint64_t* d_caps, void* hip_stream) {
+  if (!c || !d_trace_rows || !d_caps || n_total == 0) return TMX_ERR_BAD_ARG;
+  uint64_t lo, hi;
+  tmx_shard_range(n_total, c->comm_rank, c->comm_world, &lo, &hi);
+  const size_t row_bytes = (size_t)trace_elems((uint32_t)kind, c->cfg.n_max) * 8, cap_bytes = ((size_t)4 << cap_height) * 8;
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  uint64_t* mine = d_caps + (size_t)c->comm_rank * (cap_bytes / 8);
+  if (hi > lo) {
+    int32_t st = tmx_trace_commit_device(c, kind, (uint32_t)(hi - lo), section, log_blowup, cap_height, reinterpret_cast<const uint8_t*>(d_trace_rows) + lo * row_bytes,
+                                         mine, hip_stream);
+    if (st) return st;
+  } else {
+    HIPCK(c, hipMemsetAsync(mine, 0, cap_bytes, s));  // an empty shard commits to nothing: a zero cap
+  }
+  return exchange_slices(c, d_caps, c->comm_world, cap_bytes, s);
 }
 
 int32_t tmx_trace_commit_last_ms(tmx_ctx* c, float ms[3]) {

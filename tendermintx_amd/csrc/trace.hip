@@ -134,11 +134,12 @@ __device__ __forceinline__ void pt_store(int32_t* __restrict__ p, uint32_t t, co
   *reinterpret_cast<tr_i32x2*>(p + 512 + 2 * t) = c;
 }
 
-__global__ __launch_bounds__(64) void k_trace_ladder_pass1(uint32_t n_lanes, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
+__global__ __launch_bounds__(64) void k_trace_ladder_pass1(uint32_t lane0, uint32_t n_lanes, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
                                                            uint32_t ed_stride, int32_t* __restrict__ pts, uint32_t row0, uint32_t row1) {
+  // (lanes [lane0, lane0 + n_lanes) of the batch: a rank of a validator-sharded launch traces only its own -- api.cpp tmx_trace_rows_validator_sharded_device)
   const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t;
   const bool live = id < 2u * n_lanes;
-  const LadderIn L = ladder_inputs(live ? id >> 1 : 0u, id & 1u, in_target, ed, ed_stride, true);
+  const LadderIn L = ladder_inputs(lane0 + (live ? id >> 1 : 0u), id & 1u, in_target, ed, ed_stride, true);
   int32_t* blk = pts + (size_t)blockIdx.x * TR_LADDER_ROWS * TR_ROW_WORDS;
   ge_proj acc = ext_to_proj(ge_identity());
   fe prod = fe_one();
@@ -235,7 +236,7 @@ __device__ __forceinline__ LadderRow ladder_row_load(const int32_t* __restrict__
 }
 
 template <int R>
-__global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t n_lanes, uint32_t n, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
+__global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t lane0, uint32_t n_lanes, uint32_t n, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
                                                            uint32_t ed_stride, const int32_t* __restrict__ pts, uint64_t* __restrict__ out,
                                                            uint64_t proof_stride, uint32_t row0) {
   __shared__ uint32_t stage[64][TR_STAGE];
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t n_lanes, uin
   const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t;
   const int r_first = (int)(row0 + blockIdx.y * R), r_end = r_first + R;  // this thread's rows
   const bool live = id < 2u * n_lanes;
-  const uint32_t lane = live ? id >> 1 : 0u, k = id & 1u;
+  const uint32_t lane = lane0 + (live ? id >> 1 : 0u), k = id & 1u;
   const uint64_t base = (uint64_t)(lane / n) * proof_stride + (uint64_t)((2u * (lane % n) + k) * TR_LADDER_ROWS) * TR_LADDER_ROW;
   for (uint32_t i = t; i < 4 * TR_SPAN_MAX + 16; i += 64) lut[i] = i < 4 * TR_SPAN_MAX ? (uint8_t)span_word(i % TR_SPAN_MAX, i / TR_SPAN_MAX) : (uint8_t)0;
   const LadderIn L = ladder_inputs(lane, k, in_target, ed, ed_stride, false);
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t n_lanes, uin
 }
 
 // SHA-512(R | A | M) of the effective triple of one lane (at most two blocks), 18 values per round
-__global__ __launch_bounds__(64) void k_trace_sha512(uint32_t n_lanes, uint32_t n, const uint8_t* __restrict__ in_target, uint64_t* __restrict__ out,
+__global__ __launch_bounds__(64) void k_trace_sha512(uint32_t lane0, uint32_t n_lanes, uint32_t n, const uint8_t* __restrict__ in_target, uint64_t* __restrict__ out,
                                                      uint64_t proof_stride) {
   constexpr int RPF = 4, NV = RPF * TR_SHA512_ROW;  // rounds per flush
   __shared__ uint32_t stage[64][NV + 1];
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(64) void k_trace_sha512(uint32_t n_lanes, uint32_t 
   __shared__ uint8_t s_live[64];
   const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t;
   const bool live = id < n_lanes;
-  const uint32_t lane = live ? id : 0u;
+  const uint32_t lane = lane0 + (live ? id : 0u);
   {
     const uint32_t p = lane / n, i = lane - p * n;
     s_base[t] = (uint64_t)p * proof_stride + (uint64_t)n * (2u * TR_LADDER_ROWS * TR_LADDER_ROW) + (uint64_t)i * (2u * 80u * TR_SHA512_ROW);
@@ -654,20 +655,20 @@ size_t trace_tmp_bytes(uint32_t n, uint32_t n_proofs) { return (size_t)((2ull * 
 
 // rows [row0, row1) of every ladder: the chain (pass 1) and, once it is done, the affine rows (pass 2); row0 / row1 multiples of eight
 int launch_trace_ladder_pass1(uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_ed, uint32_t ed_stride, void* d_tmp, uint32_t row0,
-                              uint32_t row1, void* stream) {
-  if (n_proofs == 0) return 0;
-  const uint32_t lanes = n_proofs * n;
-  hipLaunchKernelGGL(k_trace_ladder_pass1, dim3((2 * lanes + 63) / 64), dim3(64), 0, S_(stream), lanes, reinterpret_cast<const uint8_t*>(d_target),
+                              uint32_t row1, void* stream, uint32_t lane0, uint32_t lane_count) {
+  const uint32_t lanes = lane_count == 0xffffffffu ? n_proofs * n : lane_count;
+  if (lanes == 0) return 0;
+  hipLaunchKernelGGL(k_trace_ladder_pass1, dim3((2 * lanes + 63) / 64), dim3(64), 0, S_(stream), lane0, lanes, reinterpret_cast<const uint8_t*>(d_target),
                      reinterpret_cast<const uint8_t*>(d_ed), ed_stride, reinterpret_cast<int32_t*>(d_tmp), row0, row1);
   return (int)hipGetLastError();
 }
 int launch_trace_ladder_pass2(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_ed, uint32_t ed_stride, const void* d_tmp,
-                              void* d_out, uint32_t row0, uint32_t row1, void* stream) {
-  if (n_proofs == 0) return 0;
-  const uint32_t lanes = n_proofs * n, rows = row1 - row0;
+                              void* d_out, uint32_t row0, uint32_t row1, void* stream, uint32_t lane0, uint32_t lane_count) {
+  const uint32_t lanes = lane_count == 0xffffffffu ? n_proofs * n : lane_count, rows = row1 - row0;
+  if (lanes == 0) return 0;
   // rows per inversion (= per thread): the inversion is ~13 k instructions, a row ~3 k; fewer rows = more, shorter threads.  TMX_TRACE_ROWS overrides.
 #define TMX_TRACE_P2(RR)                                                                                                                       \
-  hipLaunchKernelGGL((k_trace_ladder_pass2<RR>), dim3((2 * lanes + 63) / 64, rows / RR), dim3(64), 0, S_(stream), lanes, n,                      \
+  hipLaunchKernelGGL((k_trace_ladder_pass2<RR>), dim3((2 * lanes + 63) / 64, rows / RR), dim3(64), 0, S_(stream), lane0, lanes, n,                      \
                      reinterpret_cast<const uint8_t*>(d_target), reinterpret_cast<const uint8_t*>(d_ed), ed_stride,                             \
                      reinterpret_cast<const int32_t*>(d_tmp), reinterpret_cast<uint64_t*>(d_out), trace_elems(kind, n), row0)
   static const int r_env = std::getenv("TMX_TRACE_ROWS") ? std::atoi(std::getenv("TMX_TRACE_ROWS")) : 16;
@@ -681,14 +682,15 @@ int launch_trace_ladder_pass2(uint32_t kind, uint32_t n, uint32_t n_proofs, cons
 
 // the other sections (bits 1, 2, 3 of `sections`)
 int launch_trace_rest(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_trusted, const TraceLevel1& L1, void* d_out,
-                      uint32_t sections, void* stream) {
+                      uint32_t sections, void* stream, uint32_t lane0, uint32_t lane_count) {
   if (n_proofs == 0) return 0;
   const uint32_t lanes = n_proofs * n;
+  const uint32_t l512 = lane_count == 0xffffffffu ? lanes : lane_count;  // (only the per-lane SHA-512 section takes a lane range)
   const uint64_t stride = trace_elems(kind, n);
   uint64_t* out = reinterpret_cast<uint64_t*>(d_out);
   const uint8_t* tg = reinterpret_cast<const uint8_t*>(d_target);
   const uint8_t* tr = reinterpret_cast<const uint8_t*>(d_trusted);
-  if (sections & 2u) hipLaunchKernelGGL(k_trace_sha512, dim3((lanes + 63) / 64), dim3(64), 0, S_(stream), lanes, n, tg, out, stride);
+  if ((sections & 2u) && l512) hipLaunchKernelGGL(k_trace_sha512, dim3((l512 + 63) / 64), dim3(64), 0, S_(stream), lane0, l512, n, tg, out, stride);
   if (sections & 4u)
     hipLaunchKernelGGL(k_trace_sha256, dim3(((kind == 0 ? 2 : 1) * lanes + 63) / 64), dim3(64), 0, S_(stream), kind, lanes, n, tg, tr, out, stride);
   if ((sections & 8u) && kind == 0) {

@@ -296,3 +296,29 @@ def test_value_call_rejects_what_the_reference_asserts(tmx, cases):
         assert L.tmx_inputs_value_batch(ctx._h, 0, 1, proof, target, trusted, _lib.SEC_DERIVED, ok.ctypes.data, ok.nbytes) == -1         # derived alone
         assert L.tmx_inputs_value_batch(ctx._h, 0, 2, proof, target, trusted, _lib.SEC_HINT, ok.ctypes.data, 2 * ok.nbytes) == -4        # max_batch = 1
         assert L.tmx_inputs_value_batch(ctx._h, 0, 1, proof, target, trusted, _lib.SEC_HINT, ok.ctypes.data, ok.nbytes) == 0
+
+
+@pytest.mark.gpu
+def test_hint_value_reads_like_the_reference(tmx, kat):
+    """test_skip_small / test_step_small (skip.rs:252-265, step.rs:230-241) through SkipCircuit.hint_value / StepCircuit.hint_value: the
+    typed SkipInputs / StepInputs, the fields the hint body assigns by name"""
+    circ = tmx.SkipCircuit(4, tmx.MOCHA_4_CHAIN_ID_BYTES, tmx.SKIP_MAX, fetcher=tmx.InputDataFetcher(FX))
+    try:
+        f, vals, hfs = circ.hint_value(10000, bytes.fromhex("A0123D5E4B8B8888A61F931EE2252D83568B97C223E0ECA9795B29B8BD8CBA2D"), 10500)
+        assert bytes(f.target_header).hex().upper() == "E2BA1B86926925A69C2FCC32E5178E7E6653D386C956BB975142FA73211A9444" and f.report.all_ok
+        assert bytes(f.trusted_header).hex().upper() == "A0123D5E4B8B8888A61F931EE2252D83568B97C223E0ECA9795B29B8BD8CBA2D"
+        assert f.target_block_height_proof.height == 10500 and f.target_block_chain_id_proof.enc_chain_id_byte_length == 9
+        assert bytes(f.target_block_chain_id_proof.chain_id)[:9] == b"\x0a\x07mocha-4" and f.round == 0
+        assert f.nb_target_validators <= 4 and all(v.message_byte_length >= 32 and v.validator_byte_length in range(38, 47) for v in vals)
+        assert len(hfs) == 4
+        with pytest.raises(AssertionError, match="Trusted header hash doesn't pass sanity check"):
+            circ.hint_value(10000, bytes(32), 10500)
+    finally:
+        circ.close()
+    circ = tmx.StepCircuit(2, tmx.MOCHA_4_CHAIN_ID_BYTES, fetcher=tmx.InputDataFetcher(FX))
+    try:
+        f, vals = circ.hint_value(10000, bytes.fromhex("A0123D5E4B8B8888A61F931EE2252D83568B97C223E0ECA9795B29B8BD8CBA2D"))
+        assert bytes(f.next_header).hex().upper() == "F2A340CC2AEF6FE163254B326A52334B45793EB11417029F9548418F88B38E26" and f.report.all_ok
+        assert f.next_block_height_proof.height == 10001 and bytes(f.next_block_last_block_id_proof.leaf)[:4] == b"\x0a\x20" + bytes.fromhex("A012")
+    finally:
+        circ.close()
