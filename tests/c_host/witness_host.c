@@ -147,9 +147,10 @@ int main(int argc, char** argv) {
            (unsigned long long)f->round, (unsigned long long)f->next_block_height_proof.height, f->next_block_height_proof.enc_height_byte_length,
            f->next_block_last_block_id_proof.leaf[0], f->next_block_last_block_id_proof.leaf[1], vals[0].signed_, (unsigned long long)vals[0].voting_power);
     dump(out, val, lay.bytes);
+    const int same = memcmp(f->next_header, f->report.header, 32) == 0;
     tmx_host_free(ctx, val);
     tmx_ctx_destroy(ctx);
-    return memcmp(f->next_header, f->report.header, 32) ? 1 : 0;
+    return same ? 0 : 1;
   }
   if (!strcmp(mode, "step")) {
     tmx_ctx* ctx = make_ctx(n, chain);
