@@ -272,6 +272,7 @@ struct Knobs {
   bool proof_roles = true;   // TMX_PROOF_ROLES=0: k_proof as one workgroup per proof (the round-3 kernel) instead of four role workgroups
   int p1_early = -1;         // TMX_P1_EARLY=0|1|2: D.1a behind k_proof's sections on the side stream (1: on a capped grid, 2: full grid) instead of behind k_ed_fin (default: capped, from 131072 lanes)
   int hash_first = -1;       // TMX_HASH_FIRST=0|1: warm schedule with the hash role in front of the dedup (which moves to side2); default: see run_eddsa
+  bool walk_split = true;    // TMX_WALK_SPLIT=0: the warm schedule's table walk as ONE launch behind the table build (the round-4 form) instead of resident lanes at once + new-key lanes behind the build
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
 static Knobs read_knobs() {
@@ -286,6 +287,7 @@ static Knobs read_knobs() {
   k.ext_events = !((v = std::getenv("TMX_EXT_EVENTS")) && v[0] == '0');
   k.warm_schedule = (v = std::getenv("TMX_SCHEDULE")) ? (v[0] == 'w' ? 1 : 0) : -1;
   k.tiny = (v = std::getenv("TMX_TINY")) ? (v[0] != '0' ? 1 : 0) : -1;
+  k.walk_split = !((v = std::getenv("TMX_WALK_SPLIT")) && v[0] == '0');
   k.proof_roles = !((v = std::getenv("TMX_PROOF_ROLES")) && v[0] == '0');
   if ((v = std::getenv("TMX_PHASE1_MAX"))) k.phase1_max = std::atoi(v);
   k.hash_first = (v = std::getenv("TMX_HASH_FIRST")) ? (v[0] != '0' ? 1 : 0) : -1;
@@ -801,14 +803,23 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     rc = launch_ed_tab_mult(Q, 0, 1, c->side2, xt ? c->ev_part[0] : nullptr);
     if (rc) return rc;
     if (!xt && (e = hipEventRecord(c->ev_part[0], c->side2)) != hipSuccess) return (int)e;
-    if (!tiny) {  // s*B (only the finish needs it) beside the hash role and the walk, then the table-free lanes: ev_direct = both done
+    // Split by residency (round 5).  The lanes of RESIDENT keys walk on s as soon as their h exists -- they wait for nothing else.  The lanes
+    // of keys that are new to the cache walk in a tail launch on side2, in stream order behind the build of their tables (no event), then
+    // the table-free lanes; ev_direct = all of side2's lanes done, and only the finish waits for it.  Round 4 made the WHOLE walk wait for
+    // ev_part[0]: four new keys of 401 (the daily churn of a validator set) stalled 32 768 lanes behind a 252-doubling chain (+28 % step).
+    const bool split_walk = !tiny && K.walk_split;
+    if (!tiny) {  // s*B (only the finish needs it) beside the hash role and the walk, then the new-key lanes and the table-free lanes: ev_direct = all done
       rc = sb_with_hash ? 0 : launch_ed_base(Q, c->side2);
       if (rc) return rc;
+      if (split_walk) {
+        if ((e = hipStreamWaitEvent(c->side2, c->ev_hash, 0)) != hipSuccess) return (int)e;
+        if ((rc = launch_ed_mul_tab(Q, 0, 1, c->side2, 2u))) return rc;
+      }
       if ((rc = direct_on_side2(false))) return rc;
     }
     if ((rc = side2_tail())) return rc;
-    if (!tiny && (e = hipStreamWaitEvent(s, c->ev_part[0], 0)) != hipSuccess) return (int)e;  // (an expectation that fails: s waits for the build)
-    rc = launch_ed_mul_tab(Q, 0, 1, s);
+    if (!tiny && !split_walk && (e = hipStreamWaitEvent(s, c->ev_part[0], 0)) != hipSuccess) return (int)e;  // (the round-4 form: s waits for the build)
+    rc = launch_ed_mul_tab(Q, 0, 1, s, split_walk ? 1u : 0u);
     if (rc) return rc;
     if ((e = hipStreamWaitEvent(s, c->ev_direct, 0)) != hipSuccess) return (int)e;
     rc = launch_ed_fin(Q, s, fuse);

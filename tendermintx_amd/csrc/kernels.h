@@ -67,7 +67,8 @@ int launch_kc_epilogue(const EdQuad& Q, void* stream);
 int launch_ed_mul_direct(const EdQuad& Q, void* stream, bool fuse_fin = false, void* done = nullptr);
 int launch_ed_phase1(const EdQuad& Q, void* stream, void* done = nullptr);
 int launch_ed_hash(const EdQuad& Q, void* stream, void* done = nullptr);
-int launch_ed_mul_tab(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream);
+// which: 0 every lane whose key has a table, 1 only lanes of resident keys, 2 only lanes of keys whose table this launch builds
+int launch_ed_mul_tab(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream, uint32_t which = 0);
 int launch_ed_base(const EdQuad& Q, void* stream, void* done = nullptr);  // s*B alone (the hash role ran as k_ed_hash)
 int launch_ed_fin(const EdQuad& Q, void* stream, bool fused_direct = false);
 int launch_proof(const ProofParams& P, uint32_t n_proofs, const void* d_proofs, const void* d_target, const void* d_trusted, void* d_lt,

@@ -593,7 +593,10 @@ KNOBS = [
     # the warm schedule opening with the hash role (dedup + key pipeline on side2): off, forced onto a launch with new keys, with the
     # hash role as a kernel of its own, with record packets instead of completion signals
     {"TMX_HASH_FIRST": "0"}, {"TMX_HASH_FIRST": "1", "TMX_SCHEDULE": "warm"}, {"TMX_HASH_FIRST": "1", "TMX_PHASE1_MAX": "0"},
-    {"TMX_HASH_FIRST": "1", "TMX_EXT_EVENTS": "0", "TMX_TINY": "0"}]
+    {"TMX_HASH_FIRST": "1", "TMX_EXT_EVENTS": "0", "TMX_TINY": "0"},
+    # round 5: the warm walk split by residency (resident lanes at once, new-key lanes behind the table build on the side stream): off; forced
+    # onto launches with new keys (the mixed case is what the split is for: the batch below brings 100 new keys under a warm hint)
+    {"TMX_WALK_SPLIT": "0", "TMX_SCHEDULE": "warm"}, {"TMX_SCHEDULE": "warm", "TMX_TINY": "0"}, {"TMX_SCHEDULE": "warm", "TMX_HASH_FIRST": "0", "TMX_KEY_CACHE_KEYS": "60"}]
 
 
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
