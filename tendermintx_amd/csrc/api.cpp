@@ -273,6 +273,7 @@ struct Knobs {
   int p1_early = -1;         // TMX_P1_EARLY=0|1|2: D.1a behind k_proof's sections on the side stream (1: on a capped grid, 2: full grid) instead of behind k_ed_fin (default: capped, from 131072 lanes)
   int hash_first = -1;       // TMX_HASH_FIRST=0|1: warm schedule with the hash role in front of the dedup (which moves to side2); default: see run_eddsa
   bool walk_split = true;    // TMX_WALK_SPLIT=0: the warm schedule's table walk as ONE launch behind the table build (the round-4 form) instead of resident lanes at once + new-key lanes behind the build
+  bool base_early = true;    // TMX_BASE_EARLY=0: s*B of a warm batch on side2 behind the (usually empty) new-key kernels, the round-4 place, instead of first on side3
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
 static Knobs read_knobs() {
@@ -288,6 +289,7 @@ static Knobs read_knobs() {
   k.warm_schedule = (v = std::getenv("TMX_SCHEDULE")) ? (v[0] == 'w' ? 1 : 0) : -1;
   k.tiny = (v = std::getenv("TMX_TINY")) ? (v[0] != '0' ? 1 : 0) : -1;
   k.walk_split = !((v = std::getenv("TMX_WALK_SPLIT")) && v[0] == '0');
+  k.base_early = !((v = std::getenv("TMX_BASE_EARLY")) && v[0] == '0');
   k.proof_roles = !((v = std::getenv("TMX_PROOF_ROLES")) && v[0] == '0');
   if ((v = std::getenv("TMX_PHASE1_MAX"))) k.phase1_max = std::atoi(v);
   k.hash_first = (v = std::getenv("TMX_HASH_FIRST")) ? (v[0] != '0' ? 1 : 0) : -1;
@@ -323,6 +325,9 @@ struct tmx_ctx {
   bool last_stream_valid = false;
   hipEvent_t ev_done = nullptr;
   hipEvent_t ev_value = nullptr;  // end of the last typed-value batch (its k_pack_value launch)
+  hipEvent_t ev_base = nullptr;   // s*B of the batch being enqueued is done (side3), when run_batch launched it there
+  // the EdDSA schedule of the batch being enqueued, decided ONCE (the hint it looks at lives in host memory the device writes)
+  struct EdPlan { bool valid, tiny, warm, hash_first, sb_with_hash, base_early; } plan = {};
   int32_t last_kind = -1;       // kind and size of the last Level-1 batch (tmx_trace_rows_device reads its lane records)
   uint32_t last_n_proofs = 0;
   Program prog[2];
@@ -401,6 +406,24 @@ static ProofParams proof_params(const tmx_ctx* c, int32_t kind, bool leaves_done
   return P;
 }
 
+// which EdDSA schedule a launch of n_lanes takes (run_eddsa has the graphs).  in_batch: the launch is the EdDSA stage of run_batch, which
+// can put s*B first on its low-priority stream.
+static tmx_ctx::EdPlan ed_plan(const tmx_ctx* c, uint32_t n_lanes, bool in_batch) {
+  const Knobs& K = c->knobs;
+  tmx_ctx::EdPlan P = {};
+  P.valid = true;
+  P.tiny = n_lanes != 0 && n_lanes <= 512;
+  P.warm = K.warm_schedule >= 0 ? K.warm_schedule != 0
+                                : (c->kc.persist && K.dedup_mode != 0 && c->h_hint && c->h_hint[0] != 0 && c->h_hint[1] == 0);
+  P.hash_first = P.warm && !P.tiny && n_lanes != 0 && (K.hash_first >= 0 ? K.hash_first != 0 : n_lanes <= TMX_HASH_FIRST_MAX);
+  P.sb_with_hash = P.tiny || (K.phase1_max >= 0 ? n_lanes <= (uint32_t)K.phase1_max : n_lanes <= 16384);
+  // s*B as its own launch (a warm batch above 16384 lanes) FIRST on side3: it needs only the input records, so it starts with the batch and
+  // runs beside the dedup and the hash role; side2 then carries nothing but the new-key pipeline -- round 4 had it on side2 behind the
+  // (usually empty) new-key kernels, where a launch that did bring new keys found 60 us of s*B between their tables and their walk
+  P.base_early = in_batch && K.base_early && P.warm && !P.tiny && !P.sb_with_hash && n_lanes != 0;
+  return P;
+}
+
 // Launch sequence of one batch.  Caller's stream s: [ev0] EdDSA kernels [ev1] k_serialize of the EdDSA-dependent section [ev3]
 //                               side:   (after ev0) [side0] k_proof [side1], then the sections that only need it -> ev_join
 //                               side3:  (after ev0) the sections that only expand the input records -> ev_join3
@@ -476,6 +499,15 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // still write at the rate these sections need: step -3 % at 256 proofs x 128 (1024 workgroups; 512: the EdDSA stage -48 us but the
   // sections end after it), -4.5 % at 512, -3 % at 1024 (1536), -1 % at 64, +-0 at 32.
   HIPCK(c, hipStreamWaitEvent(c->side3, ev[0], 0));
+  c->plan = eddsa_writes_rows ? ed_plan(c, (uint32_t)lanes_all, true) : tmx_ctx::EdPlan{};
+  if (c->plan.base_early) {
+    EdQuad B;
+    std::memset(&B, 0, sizeof B);
+    B.n_lanes = (uint32_t)lanes_all; B.d_target = d_targets; B.d_qtable = c->d_qtable; B.d_mulout = c->d_mulout;
+    rc = launch_ed_base(B, c->side3, K.ext_events ? c->ev_base : nullptr);
+    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_ed_base launch: ") + hipGetErrorString((hipError_t)rc));
+    if (!K.ext_events) HIPCK(c, hipEventRecord(c->ev_base, c->side3));
+  }
   if (K.ser_split && (st0 = serialize(prog.mask_inputs, c->side3, beside_chain_wgs))) return st0;
   if (leaves_first) {
     HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_leaves, 0));
@@ -497,6 +529,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   const uint32_t mask_final = row.rows ? 0u : prog.mask_final;
   c->row = row;
   int32_t st = ed_producer(s);
+  c->plan.valid = false;
   c->fin_done = nullptr;
   c->row = RowOut{};
   if (st) return st;
@@ -710,9 +743,6 @@ static int32_t check_batch_args(tmx_ctx* c, int32_t kind, uint32_t n_proofs, con
 //                              needs) fills the machine beside the 512 latency-bound waves of the hash role
 //   tiny (<= 512 lanes):       s: dedup -> phase 1 -> walk of the resident keys -> [table-free lanes + their finish, on side2] -> finish;
 //                              never waits for tables: the tables of new keys are built on side2 for the next call
-#ifndef TMX_HASH_FIRST_MAX
-#define TMX_HASH_FIRST_MAX 16384u  // measured: 64 / 128 proofs at N = 128 -3 %, 256 +2 %, 1024 +6 % (the dedup beside the hash role on a full chip)
-#endif
 static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_ed, uint32_t ed_stride, hipStream_t s) {
   const Knobs& K = c->knobs;
   EdQuad Q;
@@ -727,9 +757,8 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * c->parity;
   Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1);
   c->parity ^= 1;
-  const bool tiny = n_lanes != 0 && n_lanes <= 512;
-  const bool warm = K.warm_schedule >= 0 ? K.warm_schedule != 0
-                                         : (c->kc.persist && Q.mode != 0 && c->h_hint && c->h_hint[0] != 0 && c->h_hint[1] == 0);
+  const tmx_ctx::EdPlan plan = c->plan.valid ? c->plan : ed_plan(c, n_lanes, false);
+  const bool tiny = plan.tiny, warm = plan.warm;
   Q.use_new = tiny ? 0u : 1u;
   Q.warm = warm ? 1u : 0u;
   hipError_t e;
@@ -738,12 +767,12 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   // Hash first (warm schedule, not tiny): SHA-512 mod l reads the lane records only, so it opens the chain on s while the dedup (cache
   // probe) and the key pipeline run on side2 -- the walk waits for side2's ev_part[0] either way.  s then carries no wait for
   // ev_hash_clean either (side2 is in order behind its own tail of the previous launch).
-  const bool hash_first = warm && !tiny && n_lanes != 0 && (K.hash_first >= 0 ? K.hash_first != 0 : n_lanes <= TMX_HASH_FIRST_MAX);
+  const bool hash_first = plan.hash_first;
   // Events that mark the end of one kernel ride on its dispatch (completion signal) instead of a record packet behind it: on the
   // chain every packet is latency.  `x` = that is on and the kernel really is launched.
   const bool x = K.ext_events && n_lanes != 0, xt = x && Q.mode != 0 && Q.kc.cap != 0;
   int rc = 0;
-  const bool sb_with_hash_hf = K.phase1_max >= 0 ? n_lanes <= (uint32_t)K.phase1_max : n_lanes <= 16384;
+  const bool sb_with_hash_hf = plan.sb_with_hash;
   if (hash_first) {
     if ((e = hipEventRecord(c->ev_fork2, s)) != hipSuccess) return (int)e;
     rc = sb_with_hash_hf ? launch_ed_phase1(Q, s, x ? c->ev_hash : nullptr) : launch_ed_hash(Q, s, x ? c->ev_hash : nullptr);
@@ -787,7 +816,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     // hash role (tiny: all of phase 1 -- a launch of a few waves is pure latency, its roles side by side) on s
     // (a few thousand lanes: s*B as a role of the same launch as the hash, as in a tiny launch -- on side2 it started behind three empty
     // launches, ran into the walk and held the finish back by ~50 us: profiles/r04_p32_timeline.txt)
-    const bool sb_with_hash = tiny || (K.phase1_max >= 0 ? n_lanes <= (uint32_t)K.phase1_max : n_lanes <= 16384);
+    const bool sb_with_hash = plan.sb_with_hash;
     if (!hash_first) {
       rc = sb_with_hash ? launch_ed_phase1(Q, s, x ? c->ev_hash : nullptr) : launch_ed_hash(Q, s, x ? c->ev_hash : nullptr);
       if (rc) return rc;
@@ -809,12 +838,13 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     // ev_part[0]: four new keys of 401 (the daily churn of a validator set) stalled 32 768 lanes behind a 252-doubling chain (+28 % step).
     const bool split_walk = !tiny && K.walk_split;
     if (!tiny) {  // s*B (only the finish needs it) beside the hash role and the walk, then the new-key lanes and the table-free lanes: ev_direct = all done
-      rc = sb_with_hash ? 0 : launch_ed_base(Q, c->side2);
+      rc = (sb_with_hash || plan.base_early) ? 0 : launch_ed_base(Q, c->side2);
       if (rc) return rc;
       if (split_walk) {
         if ((e = hipStreamWaitEvent(c->side2, c->ev_hash, 0)) != hipSuccess) return (int)e;
         if ((rc = launch_ed_mul_tab(Q, 0, 1, c->side2, 2u))) return rc;
       }
+      if (plan.base_early && (e = hipStreamWaitEvent(c->side2, c->ev_base, 0)) != hipSuccess) return (int)e;  // ev_direct covers s*B too
       if ((rc = direct_on_side2(false))) return rc;
     }
     if ((rc = side2_tail())) return rc;
@@ -1055,6 +1085,7 @@ void tmx_ctx_destroy(tmx_ctx* c) {
   if (c->ev_hash_clean) (void)hipEventDestroy(c->ev_hash_clean);
   if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
   if (c->ev_value) (void)hipEventDestroy(c->ev_value);
+  if (c->ev_base) (void)hipEventDestroy(c->ev_base);
   for (hipEvent_t e : c->ev_trace_rest)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_trace)
@@ -1085,6 +1116,7 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   c->have_streams = true;
   HIPCK(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_value, hipEventDisableTiming));
+  HIPCK(c, hipEventCreateWithFlags(&c->ev_base, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
   HIPCK(c, hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming));
   for (auto& ev : c->ev_part) HIPCK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));

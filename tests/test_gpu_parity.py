@@ -437,7 +437,8 @@ def test_device_resident_path_with_torch(tmx, oracle):
             ctx.witness_batch_device(0, P, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), out.data_ptr(), rep.data_ptr(), s.cuda_stream)
         s.synchronize()
         ms = ctx.kernel_ms_mean(1)
-        assert all(v > 0 for v in ms.values())
+        # (2048 lanes = a small launch: k_tiny is attributed ONCE, to the EdDSA slot -- the four figures are disjoint intervals of the launch)
+        assert all(v >= 0 for v in ms.values()) and ms["k_eddsa"] > 0 and ms["k_verdict"] > 0 and ms["k_proof"] == 0
     got = out[:, :count].cpu().numpy().view(np.uint64)
     want, oreps = oracle.witness_batch(0, P, wl.proofs, wl.targets, wl.trusteds, n, b"celestia", 100800, n_threads=8)
     assert np.array_equal(got, want)
@@ -596,7 +597,8 @@ KNOBS = [
     {"TMX_HASH_FIRST": "1", "TMX_EXT_EVENTS": "0", "TMX_TINY": "0"},
     # round 5: the warm walk split by residency (resident lanes at once, new-key lanes behind the table build on the side stream): off; forced
     # onto launches with new keys (the mixed case is what the split is for: the batch below brings 100 new keys under a warm hint)
-    {"TMX_WALK_SPLIT": "0", "TMX_SCHEDULE": "warm"}, {"TMX_SCHEDULE": "warm", "TMX_TINY": "0"}, {"TMX_SCHEDULE": "warm", "TMX_HASH_FIRST": "0", "TMX_KEY_CACHE_KEYS": "60"}]
+    {"TMX_WALK_SPLIT": "0", "TMX_SCHEDULE": "warm"}, {"TMX_SCHEDULE": "warm", "TMX_TINY": "0"}, {"TMX_SCHEDULE": "warm", "TMX_HASH_FIRST": "0", "TMX_KEY_CACHE_KEYS": "60"},
+    {"TMX_BASE_EARLY": "0", "TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0"}, {"TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0"}]
 
 
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
