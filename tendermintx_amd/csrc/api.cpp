@@ -273,7 +273,6 @@ struct Knobs {
   int p1_early = -1;         // TMX_P1_EARLY=0|1|2: D.1a behind k_proof's sections on the side stream (1: on a capped grid, 2: full grid) instead of behind k_ed_fin (default: capped, from 131072 lanes)
   int hash_first = -1;       // TMX_HASH_FIRST=0|1: warm schedule with the hash role in front of the dedup (which moves to side2); default: see run_eddsa
   bool walk_split = true;    // TMX_WALK_SPLIT=0: the warm schedule's table walk as ONE launch behind the table build (the round-4 form) instead of resident lanes at once + new-key lanes behind the build
-  bool base_early = true;    // TMX_BASE_EARLY=0: s*B of a warm batch on side2 behind the (usually empty) new-key kernels, the round-4 place, instead of first on side3
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
 static Knobs read_knobs() {
@@ -289,7 +288,6 @@ static Knobs read_knobs() {
   k.warm_schedule = (v = std::getenv("TMX_SCHEDULE")) ? (v[0] == 'w' ? 1 : 0) : -1;
   k.tiny = (v = std::getenv("TMX_TINY")) ? (v[0] != '0' ? 1 : 0) : -1;
   k.walk_split = !((v = std::getenv("TMX_WALK_SPLIT")) && v[0] == '0');
-  k.base_early = !((v = std::getenv("TMX_BASE_EARLY")) && v[0] == '0');
   k.proof_roles = !((v = std::getenv("TMX_PROOF_ROLES")) && v[0] == '0');
   if ((v = std::getenv("TMX_PHASE1_MAX"))) k.phase1_max = std::atoi(v);
   k.hash_first = (v = std::getenv("TMX_HASH_FIRST")) ? (v[0] != '0' ? 1 : 0) : -1;
@@ -325,9 +323,9 @@ struct tmx_ctx {
   bool last_stream_valid = false;
   hipEvent_t ev_done = nullptr;
   hipEvent_t ev_value = nullptr;  // end of the last typed-value batch (its k_pack_value launch)
-  hipEvent_t ev_base = nullptr;   // s*B of the batch being enqueued is done (side3), when run_batch launched it there
+  hipEvent_t ev_base = nullptr;   // s*B of the batch being enqueued is done (the split warm schedule: its own launch on side2)
   // the EdDSA schedule of the batch being enqueued, decided ONCE (the hint it looks at lives in host memory the device writes)
-  struct EdPlan { bool valid, tiny, warm, hash_first, sb_with_hash, base_early; } plan = {};
+  struct EdPlan { bool valid, tiny, warm, hash_first, sb_with_hash, split; } plan = {};
   int32_t last_kind = -1;       // kind and size of the last Level-1 batch (tmx_trace_rows_device reads its lane records)
   uint32_t last_n_proofs = 0;
   Program prog[2];
@@ -420,10 +418,8 @@ static tmx_ctx::EdPlan ed_plan(const tmx_ctx* c, uint32_t n_lanes, bool in_batch
                                 : (c->kc.persist && K.dedup_mode != 0 && c->h_hint && c->h_hint[0] != 0 && c->h_hint[1] == 0);
   P.hash_first = P.warm && !P.tiny && n_lanes != 0 && (K.hash_first >= 0 ? K.hash_first != 0 : n_lanes <= TMX_HASH_FIRST_MAX);
   P.sb_with_hash = P.tiny || (K.phase1_max >= 0 ? n_lanes <= (uint32_t)K.phase1_max : n_lanes <= 16384);
-  // s*B as its own launch (a warm batch above 16384 lanes) FIRST on side3: it needs only the input records, so it starts with the batch and
-  // runs beside the dedup and the hash role; side2 then carries nothing but the new-key pipeline -- round 4 had it on side2 behind the
-  // (usually empty) new-key kernels, where a launch that did bring new keys found 60 us of s*B between their tables and their walk
-  P.base_early = in_batch && K.base_early && P.warm && !P.tiny && !P.sb_with_hash && n_lanes != 0;
+  // the warm schedule split by residency (run_eddsa_split): only as the EdDSA stage of a batch (run_batch reorders its low-priority stream for it)
+  P.split = in_batch && K.walk_split && P.warm && !P.tiny && n_lanes != 0 && K.dedup_mode != 0 && c->kc.cap != 0;
   return P;
 }
 
@@ -501,22 +497,21 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // priority (a pure store stream beside the EdDSA stage: k_ed_keys 50 -> 103 us, the stage 0.42 -> 0.72 ms).  Four workgroups per CU
   // still write at the rate these sections need: step -3 % at 256 proofs x 128 (1024 workgroups; 512: the EdDSA stage -48 us but the
   // sections end after it), -4.5 % at 512, -3 % at 1024 (1536), -1 % at 64, +-0 at 32.
-  HIPCK(c, hipStreamWaitEvent(c->side3, ev[0], 0));
+  // (the split warm schedule puts the new-key pipeline on side3 IN FRONT of these sections -- usually three empty launches; with new keys
+  // the pipeline must not queue behind 200 us of trickling stores -- so the sections are enqueued behind the EdDSA stage then)
   c->plan = eddsa_writes_rows ? ed_plan(c, (uint32_t)lanes_all, true) : tmx_ctx::EdPlan{};
-  if (c->plan.base_early) {
-    EdQuad B;
-    std::memset(&B, 0, sizeof B);
-    B.n_lanes = (uint32_t)lanes_all; B.d_target = d_targets; B.d_qtable = c->d_qtable; B.d_mulout = c->d_mulout;
-    rc = launch_ed_base(B, c->side3, K.ext_events ? c->ev_base : nullptr);
-    if (rc) return fail(c, TMX_ERR_HIP, std::string("k_ed_base launch: ") + hipGetErrorString((hipError_t)rc));
-    if (!K.ext_events) HIPCK(c, hipEventRecord(c->ev_base, c->side3));
-  }
-  if (K.ser_split && (st0 = serialize(prog.mask_inputs, c->side3, beside_chain_wgs))) return st0;
-  if (leaves_first) {
-    HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_leaves, 0));
-    if ((st0 = serialize(prog.mask_leaves, c->side3, beside_chain_wgs))) return st0;
-  }
-  HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
+  auto side3_inputs = [&]() -> int32_t {
+    HIPCK(c, hipStreamWaitEvent(c->side3, ev[0], 0));
+    if (K.ser_split && (st0 = serialize(prog.mask_inputs, c->side3, beside_chain_wgs))) return st0;
+    if (leaves_first) {
+      HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_leaves, 0));
+      if ((st0 = serialize(prog.mask_leaves, c->side3, beside_chain_wgs))) return st0;
+    }
+    HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
+    return TMX_OK;
+  };
+  const bool defer3 = c->plan.split;
+  if (!defer3 && (st0 = side3_inputs())) return st0;
 
   // ev[1] rides on the k_ed_fin dispatch itself (TMX_EXT_EVENTS=0: a record packet behind it)
   c->fin_done = K.ext_events ? ev[1] : nullptr;
@@ -532,10 +527,12 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   const uint32_t mask_final = row.rows ? 0u : prog.mask_final;
   c->row = row;
   int32_t st = ed_producer(s);
+  const bool fin_split = c->plan.split;  // (the lanes of new keys are finished on side2: whatever reads every lane's verdict on s waits for ev_direct)
   c->plan.valid = false;
   c->fin_done = nullptr;
   c->row = RowOut{};
   if (st) return st;
+  if (defer3 && (st0 = side3_inputs())) return st0;
   if (leaves_first) {  // side3, behind the input sections and D.2a: D.1a as soon as phase 1 is done; ev_join3 moves behind it
     if (!c->ev_hash_recorded) HIPCK(c, hipEventRecord(c->ev_hash, s));  // (a producer without a phase-1 event: everything it enqueued)
     HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_hash, 0));
@@ -567,6 +564,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     // D.1a (needs the leaves and the hash role, both long done) goes with k_proof's sections on the side stream; what follows the join of
     // k_proof and the EdDSA finish on s is ONE launch: verdict + the sections that carry it + the seam spans (k_verdict_tail)
     HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
+    if (fin_split) HIPCK(c, hipStreamWaitEvent(s, c->ev_direct, 0));
     const bool xv = K.ext_events && n_proofs != 0;  // the verdict's two timing events ride on its dispatch
     if (!xv) HIPCK(c, hipEventRecord(evs[2], s));
     const bool with_rows = d_out_elems != nullptr;
@@ -596,6 +594,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     HIPCK(c, hipStreamWaitEvent(s, c->ev_tail, 0));
   } else {
     HIPCK(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    if (fin_split) HIPCK(c, hipStreamWaitEvent(s, c->ev_direct, 0));
     HIPCK(c, hipEventRecord(evs[2], s));
     rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, row, s);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
@@ -776,6 +775,60 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   const bool x = K.ext_events && n_lanes != 0, xt = x && Q.mode != 0 && Q.kc.cap != 0;
   int rc = 0;
   const bool sb_with_hash_hf = plan.sb_with_hash;
+  if (plan.split) {
+    // ---- warm, split by residency (round 5).  Three chains that meet only where the data says so:
+    //   s      [dedup] -> hash -> walk of the RESIDENT lanes -> [s*B] finish of the RESIDENT lanes          (the critical chain: waits for no table)
+    //   side3  [dedup] -> k_ed_keys -> anchors -> multiples -> cache epilogue                                (the new-key pipeline: usually four empty launches)
+    //   side2  s*B -> [tables, hash] walk of the NEW-KEY lanes -> table-free lanes -> finish of both         (usually: s*B and three empty launches)
+    // Round 4 ran the new-key kernels and s*B one after the other on side2 and made the whole walk and the whole finish wait for them:
+    // four new keys of 401 -- the daily churn of a validator set -- stalled 32 768 lanes behind a decode + 252-doubling chain + 60 us of
+    // s*B (+28 % step).  Now only the lanes that need the new tables wait for them, and the lanes' D.1b rows are written by whichever
+    // finish owns the lane.  Everything that reads ALL lanes' verdicts (k_verdict, on side2 itself or behind ev_direct) is ordered after both.
+    hipStream_t kq = c->side3;
+    if (hash_first) {
+      if ((e = hipEventRecord(c->ev_fork2, s)) != hipSuccess) return (int)e;
+    } else {
+      if ((e = hipStreamWaitEvent(s, c->ev_hash_clean, 0)) != hipSuccess) return (int)e;
+      if ((rc = launch_ed_dedup(Q, s, x ? c->ev_fork2 : nullptr))) return rc;
+      if (!x && (e = hipEventRecord(c->ev_fork2, s)) != hipSuccess) return (int)e;
+    }
+    rc = plan.sb_with_hash ? launch_ed_phase1(Q, s, x ? c->ev_hash : nullptr) : launch_ed_hash(Q, s, x ? c->ev_hash : nullptr);
+    if (rc) return rc;
+    if (!x && (e = hipEventRecord(c->ev_hash, s)) != hipSuccess) return (int)e;
+    c->ev_hash_recorded = true;
+    // side3: the new-key pipeline and the end of the launch's cache bookkeeping
+    if ((e = hipStreamWaitEvent(kq, c->ev_fork2, 0)) != hipSuccess) return (int)e;
+    if (hash_first && (rc = launch_ed_dedup(Q, kq, nullptr))) return rc;
+    if ((rc = launch_ed_keys(Q, kq, nullptr))) return rc;
+    if ((rc = launch_ed_tab_anchor(Q, 0, 1, kq))) return rc;
+    if ((rc = launch_ed_tab_mult(Q, 0, 1, kq, xt ? c->ev_part[0] : nullptr))) return rc;
+    if (!xt && (e = hipEventRecord(c->ev_part[0], kq)) != hipSuccess) return (int)e;
+    if ((size_t)c->hash_mask + 1 > KC_EPILOGUE_CLEARS_UP_TO && (e = hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, kq)) != hipSuccess) return (int)e;
+    if ((rc = launch_kc_epilogue(Q, kq))) return rc;
+    if ((e = hipEventRecord(c->ev_hash_clean, kq)) != hipSuccess) return (int)e;
+    // side2: s*B (a launch of its own above 16384 lanes), then the lanes that are not resident
+    if ((e = hipStreamWaitEvent(c->side2, c->ev_fork2, 0)) != hipSuccess) return (int)e;
+    if (!plan.sb_with_hash) {
+      if ((rc = launch_ed_base(Q, c->side2, x ? c->ev_base : nullptr))) return rc;
+      if (!x && (e = hipEventRecord(c->ev_base, c->side2)) != hipSuccess) return (int)e;
+    }
+    if ((e = hipStreamWaitEvent(c->side2, c->ev_part[0], 0)) != hipSuccess) return (int)e;
+    if ((e = hipStreamWaitEvent(c->side2, c->ev_hash, 0)) != hipSuccess) return (int)e;
+    if ((rc = launch_ed_mul_tab(Q, 0, 1, c->side2, 2u))) return rc;
+    if ((rc = launch_ed_mul_direct(Q, c->side2, false, nullptr))) return rc;
+    {
+      EdQuad Q2 = Q;
+      Q2.fin_done = nullptr;
+      if ((rc = launch_ed_fin(Q2, c->side2, false, 2u))) return rc;
+    }
+    if ((e = hipEventRecord(c->ev_direct, c->side2)) != hipSuccess) return (int)e;
+    // s: the resident lanes
+    if ((rc = launch_ed_mul_tab(Q, 0, 1, s, 1u))) return rc;
+    if (!plan.sb_with_hash && (e = hipStreamWaitEvent(s, c->ev_base, 0)) != hipSuccess) return (int)e;
+    rc = launch_ed_fin(Q, s, false, 1u);
+    c->fin_done_attached = rc == 0 && Q.fin_done != nullptr;
+    return rc;
+  }
   if (hash_first) {
     if ((e = hipEventRecord(c->ev_fork2, s)) != hipSuccess) return (int)e;
     rc = sb_with_hash_hf ? launch_ed_phase1(Q, s, x ? c->ev_hash : nullptr) : launch_ed_hash(Q, s, x ? c->ev_hash : nullptr);
@@ -835,24 +888,14 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     rc = launch_ed_tab_mult(Q, 0, 1, c->side2, xt ? c->ev_part[0] : nullptr);
     if (rc) return rc;
     if (!xt && (e = hipEventRecord(c->ev_part[0], c->side2)) != hipSuccess) return (int)e;
-    // Split by residency (round 5).  The lanes of RESIDENT keys walk on s as soon as their h exists -- they wait for nothing else.  The lanes
-    // of keys that are new to the cache walk in a tail launch on side2, in stream order behind the build of their tables (no event), then
-    // the table-free lanes; ev_direct = all of side2's lanes done, and only the finish waits for it.  Round 4 made the WHOLE walk wait for
-    // ev_part[0]: four new keys of 401 (the daily churn of a validator set) stalled 32 768 lanes behind a 252-doubling chain (+28 % step).
-    const bool split_walk = !tiny && K.walk_split;
-    if (!tiny) {  // s*B (only the finish needs it) beside the hash role and the walk, then the new-key lanes and the table-free lanes: ev_direct = all done
-      rc = (sb_with_hash || plan.base_early) ? 0 : launch_ed_base(Q, c->side2);
+    if (!tiny) {  // s*B (only the finish needs it) beside the hash role and the walk, then the table-free lanes: ev_direct = both done
+      rc = sb_with_hash ? 0 : launch_ed_base(Q, c->side2);
       if (rc) return rc;
-      if (split_walk) {
-        if ((e = hipStreamWaitEvent(c->side2, c->ev_hash, 0)) != hipSuccess) return (int)e;
-        if ((rc = launch_ed_mul_tab(Q, 0, 1, c->side2, 2u))) return rc;
-      }
-      if (plan.base_early && (e = hipStreamWaitEvent(c->side2, c->ev_base, 0)) != hipSuccess) return (int)e;  // ev_direct covers s*B too
       if ((rc = direct_on_side2(false))) return rc;
     }
     if ((rc = side2_tail())) return rc;
-    if (!tiny && !split_walk && (e = hipStreamWaitEvent(s, c->ev_part[0], 0)) != hipSuccess) return (int)e;  // (the round-4 form: s waits for the build)
-    rc = launch_ed_mul_tab(Q, 0, 1, s, split_walk ? 1u : 0u);
+    if (!tiny && (e = hipStreamWaitEvent(s, c->ev_part[0], 0)) != hipSuccess) return (int)e;  // (an expectation that fails: s waits for the build)
+    rc = launch_ed_mul_tab(Q, 0, 1, s);
     if (rc) return rc;
     if ((e = hipStreamWaitEvent(s, c->ev_direct, 0)) != hipSuccess) return (int)e;
     rc = launch_ed_fin(Q, s, fuse);

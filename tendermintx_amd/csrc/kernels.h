@@ -70,7 +70,8 @@ int launch_ed_hash(const EdQuad& Q, void* stream, void* done = nullptr);
 // which: 0 every lane whose key has a table, 1 only lanes of resident keys, 2 only lanes of keys whose table this launch builds
 int launch_ed_mul_tab(const EdQuad& Q, uint32_t part, uint32_t parts, void* stream, uint32_t which = 0);
 int launch_ed_base(const EdQuad& Q, void* stream, void* done = nullptr);  // s*B alone (the hash role ran as k_ed_hash)
-int launch_ed_fin(const EdQuad& Q, void* stream, bool fused_direct = false);
+// which: 0 every lane, 1 only lanes of resident keys (cache hits), 2 only the others (the split warm schedule finishes them on the side stream)
+int launch_ed_fin(const EdQuad& Q, void* stream, bool fused_direct = false, uint32_t which = 0);
 int launch_proof(const ProofParams& P, uint32_t n_proofs, const void* d_proofs, const void* d_target, const void* d_trusted, void* d_lt,
                  uint32_t lt_stride, void* d_lr, void* d_pf, void* d_nodes_t, void* d_nodes_r, void* d_reports, void* stream, void* started = nullptr,
                  void* done = nullptr);

@@ -598,7 +598,7 @@ KNOBS = [
     # round 5: the warm walk split by residency (resident lanes at once, new-key lanes behind the table build on the side stream): off; forced
     # onto launches with new keys (the mixed case is what the split is for: the batch below brings 100 new keys under a warm hint)
     {"TMX_WALK_SPLIT": "0", "TMX_SCHEDULE": "warm"}, {"TMX_SCHEDULE": "warm", "TMX_TINY": "0"}, {"TMX_SCHEDULE": "warm", "TMX_HASH_FIRST": "0", "TMX_KEY_CACHE_KEYS": "60"},
-    {"TMX_BASE_EARLY": "0", "TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0"}, {"TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0"}]
+    {"TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0"}, {"TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0", "TMX_EXT_EVENTS": "0", "TMX_TINY": "0"}]
 
 
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
