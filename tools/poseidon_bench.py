@@ -13,7 +13,7 @@ import torch  # noqa: E402
 from tendermintx_amd import Context  # noqa: E402
 
 SIMDS, CLOCK_GHZ, CYC = 1024, 2.4, 4.07          # bench.py: issue cost of a wave64 VALU instruction per SIMD (profiles/r03_valu_isa.txt)
-INSTS_PER_PERM_WAVE = float(os.environ.get("POS_INSTS", "0")) or None   # from the PMC pass (tools/_poseidon_prof.sh); None: not reported
+INSTS_PER_PERM_WAVE = float(os.environ.get("POS_INSTS", "0")) or None   # from the PMC pass (tools/recipes.sh poseidon_prof); None: not reported
 shapes = [(16, 256, 4), (19, 64, 4), (21, 64, 4), (21, 256, 4), (22, 16, 4)]
 if len(sys.argv) > 3:
     a = [int(x) for x in sys.argv[1:]]
