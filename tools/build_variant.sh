@@ -6,5 +6,5 @@ name=$1; shift
 cd "$(dirname "$0")/../tendermintx_amd/csrc"
 mkdir -p ../../build_ab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. "$@" -c kernels.hip -o /tmp/kernels_$name.o
-g++ -shared -o ../../build_ab/$name.so /tmp/kernels_$name.o ntt.o trace.o poseidon.o api.o codec.o
+g++ -shared -o ../../build_ab/$name.so /tmp/kernels_$name.o ntt.o trace.o poseidon.o value.o api.o codec.o
 echo built build_ab/$name.so
