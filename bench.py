@@ -551,6 +551,25 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
         roofline["traffic"] = measured_traffic["bytes_per_step"]
         roofline["traffic_source"] = measured_traffic["source"]
         roofline["traffic_detail"] = measured_traffic
+        # per kernel: wave-level VALU instructions and time ALONE (the counter pass serializes the kernels) -> the fraction of the chip's issue
+        # slots the kernel fills on its own; HBM bytes beside it.  The chain kernels (hash, walk, finish) and k_proof are latency-bound
+        # launches of 512 - 4096 waves: their roof is this one, not HBM.
+        pkr = {}
+        for k, v in measured_traffic["per_kernel"].items():
+            if "SQ_INSTS_VALU" not in v or not v.get("alone_us"):
+                continue
+            pkr[k] = {"valu_insts": int(v["SQ_INSTS_VALU"]), "alone_us": v["alone_us"],
+                      "issue_frac": round(v["SQ_INSTS_VALU"] * CYCLES_SLOW / (SIMDS * CLOCK_GHZ * 1e3 * v["alone_us"]), 3),
+                      "hbm_bytes": int(v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)),
+                      "hbm_frac": round((v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) / (v["alone_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)}
+        roofline["per_kernel"] = dict(sorted(pkr.items(), key=lambda kv: -kv[1]["alone_us"]))
+        roofline["per_kernel_note"] = ("issue_frac = wave-level VALU instructions x 4.07 cycles / (1024 SIMDs x 2.4 GHz x the kernel's time alone); alone_us = "
+                                       "its launches of one batch summed, kernels serialized by the counter pass (inside a step they overlap: kernels_ms)")
+        ser = {k: v for k, v in measured_traffic["per_kernel"].items() if k.startswith("k_serialize")}
+        if ser:   # the serializer launches of the SPLIT configuration the step runs (five k_serialize + two k_serialize_few + the seams)
+            roofline["k_serialize"]["traffic"] = int(sum(v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0) for v in ser.values()))
+            roofline["k_serialize"]["traffic_source"] = measured_traffic["source"] + " (the split launches of the step; `ms_alone` is the unsplit launch of TMX_SER_SPLIT=0)"
+            roofline["k_serialize"]["split_alone_us"] = round(sum(v.get("alone_us", 0) for v in ser.values()), 1)
 
     # ---- PMC figures of the committed rocprofv3 passes (profiles/pmc_latest.json), only if they were taken on this configuration.
     # NOT measured by this run: replayed from the builder's profile collection, and marked as such in the line
@@ -562,8 +581,9 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
             if not measured_traffic:
                 roofline["traffic"] = int(sum(pk[g].get("fetch_kb", 0) + pk[g].get("write_kb", 0) for g in pk) * 1024)
                 roofline["traffic_source"] = src
-            roofline["k_serialize"]["traffic"] = int((pk["k_serialize"]["fetch_kb"] + pk["k_serialize"]["write_kb"]) * 1024)
-            roofline["k_serialize"]["traffic_source"] = src
+            if "traffic" not in roofline["k_serialize"]:
+                roofline["k_serialize"]["traffic"] = int((pk["k_serialize"]["fetch_kb"] + pk["k_serialize"]["write_kb"]) * 1024)
+                roofline["k_serialize"]["traffic_source"] = src
             try:
                 mix = json.load(open(os.path.join(ROOT, "profiles", "r03_isa_mix.json")))["kernels"]
             except (OSError, KeyError, ValueError):
@@ -706,13 +726,21 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
             "roofline": {"kernel": "k_trace_ladder_pass1 + _pass2", "bound": "hbm", "achieved": l2["ladders"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(l2["ladders"]["gbs"] / HBM_PEAK_GBS, 4), "algorithmic_bytes": l2["ladders"]["bytes"], "traffic": None,
                          "note": "pass 1 (the double-and-add chain + the running product of the Z's, one thread per ladder) is one latency-bound "
-                                 "wave per SIMD; pass 2 (one inversion per 16 rows, Montgomery's trick walked backwards over the stored prefix "
-                                 "products, canonical limbs, stores) runs beside the next segment's chain at four waves per SIMD; ~3.3 k + ~3.7 k "
-                                 "instructions per row: DESIGN.md 'The writer, measured'"}}
+                                 "wave per SIMD; pass 2 (one wave-shared inversion per 64 x 16 rows, Montgomery's trick walked backwards over the stored "
+                                 "prefix products, canonical limbs, stores) runs beside the next segment's chain at four waves per SIMD; ~3.1 k + ~3.3 k "
+                                 "instructions per row; the scratch rows are 280 B (round 4: 320): DESIGN.md 'The writer, measured'"}}
         l2_traffic = measure_level2_traffic(n, P, args.workload)  # (extras() runs on rank 0 of a one-GPU run only)
         if l2_traffic:
             result["level2_trace_rows"]["roofline"]["traffic"] = l2_traffic["bytes_per_call"]
             result["level2_trace_rows"]["roofline"]["traffic_detail"] = l2_traffic
+            # raw counters, and with the guide's x2 on the fetches of pass 2 (the scratch rows are read back with 16-byte loads)
+            p2f = l2_traffic["per_kernel"].get("k_trace_ladder_pass2", {}).get("FETCH_SIZE", 0)
+            result["level2_trace_rows"]["roofline"]["traffic_over_rows"] = {
+                "raw": round(l2_traffic["bytes_per_call"] / l2["ladders"]["bytes"], 3),
+                "fetch_x2": round((l2_traffic["bytes_per_call"] + p2f) / l2["ladders"]["bytes"], 3),
+                "note": "HBM bytes of both passes over the bytes of ladder rows; the floor with a scratch buffer is 1 + 2 x 280 / 520 = 2.08 (pass 1 writes "
+                        "seven field elements per row, pass 2 reads them back): recomputing them in pass 2 instead costs 15 more field products per row on a "
+                        "kernel pair that is instruction-bound (docs/kernels.md 'Level-2 ladders, round 5')"}
         tr0 = d_tr[:te].cpu().numpy().view(np.uint64)
         del d_tr
     except Exception as e:  # the trace rows are a widening row: never let them take the headline line down
@@ -787,6 +815,12 @@ def measure_traffic(n, P, workload):
                     tot[counter] = tot.get(counter, 0.0) + value / steps
                     short = name.split("(")[0].replace("void ", "").replace("tmx::", "")
                     per_kernel.setdefault(short, {})[counter] = round(value / steps * (1 if counter == "SQ_INSTS_VALU" else 1024))
+                if counter == "SQ_INSTS_VALU":  # the same pass, kernels serialized by the counter collection: each kernel's time ALONE, per batch
+                    t_first = sorted(x[0] for x in db.execute("select start from kernels where name like '%k_proof%'"))[warm]
+                    for name, ns in db.execute("select name, sum(end - start) from kernels where start >= ? and name like '%tmx::%' "
+                                               "and name not like '%k_init_base%' group by name", (t_first,)):
+                        short = name.split("(")[0].replace("void ", "").replace("tmx::", "")
+                        per_kernel.setdefault(short, {})["alone_us"] = round(ns / steps / 1e3, 2)
         if "FETCH_SIZE" not in tot or "WRITE_SIZE" not in tot:
             return None
         valu = {k: v["SQ_INSTS_VALU"] for k, v in per_kernel.items() if "SQ_INSTS_VALU" in v}
@@ -831,7 +865,7 @@ def measure_level2_traffic(n, P, workload):
                 "write_bytes": int(tot["WRITE_SIZE"] * 1024), "per_kernel": per_kernel,
                 "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over tools/trace_bench.py "
                           f"(SECTIONS=ladders), mean of {calls} calls; uncorrected sums (MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced "
-                          "reads by 2x -- pass 2 reads the 5.4 GB of scratch pass 1 writes with 16-byte loads)"}
+                          "reads by 2x -- pass 2 reads the 4.7 GB of scratch pass 1 writes with 16-byte loads)"}
     except Exception:
         return None
 

@@ -18,6 +18,7 @@
 
 #include "ge25519.hpp"
 #include "inv25519.hpp"
+#include "winv25519.hpp"
 #include "sha2.hpp"
 
 namespace tmx {
@@ -63,17 +64,17 @@ __device__ __forceinline__ void coop_flush(const uint32_t (*stage)[NV + 1], cons
 // ---- ladders, in two passes so that the expensive half (inversions, canonical limbs, the stores) is not a 256-step chain:
 //   pass 1  one thread per (lane, ladder): the double-and-add chain in extended coordinates.  (X:Y:Z) of dbl_r and add_r of every row go to
 //           a scratch buffer together with the PREFIX PRODUCT of all Z's up to that point (P_2r = Z(dbl_0) Z(add_0) ... Z(dbl_r),
-//           P_2r+1 = P_2r Z(add_r): two more products per row, off the point chain) -- 320 B per row, every store / load instruction a
-//           contiguous run of 16 bytes per lane (layout below).
-//   pass 2  one thread per (ladder, R rows), a wave = the same 64 ladders as in pass 1: ONE safegcd inversion of P at the thread's last
-//           point, then Montgomery's trick walked BACKWARDS -- 1 / Z_k = inv(P_k) P_k-1, inv(P_k-1) = inv(P_k) Z_k: two products per
+//           P_2r+1 = P_2r Z(add_r): two more products per row, off the point chain); P_2r+1 is stored with them -- 280 B per row, every
+//           store / load instruction a contiguous run of 16 bytes per lane (layout below).
+//   pass 2  one thread per (ladder, R rows), a wave = the same 64 ladders as in pass 1: the inverse of P at the thread's last point (ONE
+//           inversion per wave: winv25519.hpp), then Montgomery's trick walked BACKWARDS -- 1 / Z_k = inv(P_k) P_k-1, inv(P_k-1) = inv(P_k) Z_k: two products per
 //           point and nothing recomputed (the first version swept the Z's of its rows three times for the suffix products it could not keep:
 //           14 products per row against 8) --, the affine words staged in LDS and written by the whole wave.
 // What a thread writes per row is the 65 CONTIGUOUS elements  dbl_r | add_r | nxt_r | bit_r+1 | acc_r+1  (acc_r+1 = nxt_r: elements 17 ... 64
 // of row r and 0 ... 16 of row r + 1), so that no thread needs the affine form of the point its rows start from; the thread with row 0 adds
 // the ladder's first 17 elements (bit_0, the identity), the one with row 255 stops after nxt.
 // Measured per 256-proof batch at N = 128 (8.7 GB of rows): one pass 8.3 ms; two passes with suffix products 6.1 ms (round 3); this form
-// 4.95 ms -- pass 2 alone 0.52 ms per 64-row segment without its stores, 0.8 - 0.9 with them: what is left is the write stream of 520-byte
+// 4.95 ms (round 4; 4.6 ms with the wave-shared inversion and without P(dbl) in the scratch rows, round 5) -- pass 2 alone 0.52 ms per 64-row segment without its stores, 0.8 - 0.9 with them: what is left is the write stream of 520-byte
 // pieces 130 KB apart (DESIGN.md "The writer, measured").
 // (the scalar as a VECTOR: a wave-uniform dynamic index into a vector is a register select; into an array it became a scratch load per row,
 // and every scratch load waits for ALL memory operations of the wave -- vmcnt counts in order -- i.e. for the stores of the row before)
@@ -107,11 +108,13 @@ __device__ __forceinline__ uint32_t scalar_bit(const tr_u32x8& sc, int r) {  // 
   const int b = 255 - r;
   return (sc[(b >> 5) & 7] >> (b & 31)) & 1u;
 }
-// The scratch buffer: per block of 64 ladders and per row eight field elements -- dbl (X, Y, Z), add (X, Y, Z), P(dbl), P(add) --, each as
+// The scratch buffer: per block of 64 ladders and per row SEVEN field elements -- dbl (X, Y, Z), add (X, Y, Z), P(add) --, each as
 // 640 words [part][thread][words of the part] with parts of 4, 4 and 2 limbs: a wave moves one element with three instructions (16, 16 and
-// 8 bytes per lane, every one of them a contiguous run: 24 loads or stores per row instead of 80 of one word -- a wave may have 63 in flight).
-constexpr uint32_t TR_FE_WORDS = 640, TR_PT_FES = 8, TR_ROW_WORDS = TR_FE_WORDS * TR_PT_FES;
-enum : uint32_t { TR_DX = 0, TR_DY = 1, TR_DZ = 2, TR_AX = 3, TR_AY = 4, TR_AZ = 5, TR_PD = 6, TR_PA = 7 };
+// 8 bytes per lane, every one of them a contiguous run: 21 loads or stores per row instead of 70 of one word -- a wave may have 63 in flight).
+// (P(dbl_r) = P(add_r-1) Z(dbl_r) is one product of two values pass 2 loads anyway: round 4 stored it too -- 320 B per row, 12.5 % more
+// scratch traffic in both directions.)
+constexpr uint32_t TR_FE_WORDS = 640, TR_PT_FES = 7, TR_ROW_WORDS = TR_FE_WORDS * TR_PT_FES;
+enum : uint32_t { TR_DX = 0, TR_DY = 1, TR_DZ = 2, TR_AX = 3, TR_AY = 4, TR_AZ = 5, TR_PA = 6 };
 typedef int32_t tr_i32x4 __attribute__((ext_vector_type(4)));
 typedef int32_t tr_i32x2 __attribute__((ext_vector_type(2)));
 // `blk` = the block's part of the buffer; t = the thread
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(64) void k_trace_ladder_pass1(uint32_t lane0, uint3
     int32_t* row = blk + (size_t)r * TR_ROW_WORDS;
     pt_store(row + TR_DX * TR_FE_WORDS, t, d.X); pt_store(row + TR_DY * TR_FE_WORDS, t, d.Y); pt_store(row + TR_DZ * TR_FE_WORDS, t, d.Z);
     pt_store(row + TR_AX * TR_FE_WORDS, t, a.X); pt_store(row + TR_AY * TR_FE_WORDS, t, a.Y); pt_store(row + TR_AZ * TR_FE_WORDS, t, a.Z);
-    pt_store(row + TR_PD * TR_FE_WORDS, t, pd); pt_store(row + TR_PA * TR_FE_WORDS, t, prod);
+    pt_store(row + TR_PA * TR_FE_WORDS, t, prod);
     acc.X = fe_select(d.X, a.X, bit); acc.Y = fe_select(d.Y, a.Y, bit); acc.Z = fe_select(d.Z, a.Z, bit);
   }
 }
@@ -218,29 +221,14 @@ __device__ __forceinline__ void ladder_flush(const uint32_t (*stage)[TR_STAGE], 
   __syncthreads();
 }
 
-// what pass 2 reads for one row: P(dbl), add (X, Y, Z), P(add) of the row before, dbl (X, Y, Z)
-struct LadderRow {
-  fe pd, ax, ay, az, pp, dx, dy, dz;
-};
-__device__ __forceinline__ LadderRow ladder_row_load(const int32_t* __restrict__ blk, int r, uint32_t t) {
-  LadderRow w;
-  w.pd = pt_load(pt_at(blk, r, TR_PD), t);
-  w.az = pt_load(pt_at(blk, r, TR_AZ), t);
-  w.ax = pt_load(pt_at(blk, r, TR_AX), t);
-  w.ay = pt_load(pt_at(blk, r, TR_AY), t);
-  w.pp = r > 0 ? pt_load(pt_at(blk, r - 1, TR_PA), t) : fe_one();
-  w.dz = pt_load(pt_at(blk, r, TR_DZ), t);
-  w.dx = pt_load(pt_at(blk, r, TR_DX), t);
-  w.dy = pt_load(pt_at(blk, r, TR_DY), t);
-  return w;
-}
-
 template <int R>
 __global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t lane0, uint32_t n_lanes, uint32_t n, const uint8_t* __restrict__ in_target, const uint8_t* __restrict__ ed,
                                                            uint32_t ed_stride, const int32_t* __restrict__ pts, uint64_t* __restrict__ out,
                                                            uint64_t proof_stride, uint32_t row0) {
   __shared__ uint32_t stage[64][TR_STAGE];
   __shared__ uint8_t lut[4 * TR_SPAN_MAX + 16];
+  __shared__ int32_t s_t[10];
+  __shared__ uint32_t s_inv[64];
   const uint32_t t = threadIdx.x, id = blockIdx.x * 64u + t;
   const int r_first = (int)(row0 + blockIdx.y * R), r_end = r_first + R;  // this thread's rows
   const bool live = id < 2u * n_lanes;
@@ -256,19 +244,22 @@ __global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t lane0, uint3
 #pragma unroll
     for (int q = 0; q < 16; q++) dst[1 + q] = q == 8 ? (1u & z) : 0u;
   }
-  fe inv = fe_invert_safegcd(pt_load(pt_at(blk, r_end - 1, TR_PA), t));  // 1 / P(add of the last row)
+  // 1 / P(add of the thread's last row): ONE inversion per wave (winv25519.hpp: Montgomery's trick across the lanes + a cooperative Fermat chain,
+  // ~13 k instructions) instead of 64 Bernstein-Yang inversions side by side (~21 k).  P is a product of Z coordinates of points on the curve: never zero.
+  fe inv = wave_batch_invert(pt_load(pt_at(blk, r_end - 1, TR_PA), t), t, s_t, s_inv);
   uint32_t bit_above = r_end < (int)TR_LADDER_ROWS ? scalar_bit(L.sc, r_end) : 0u;
   const uint32_t out_align = (uint32_t)(reinterpret_cast<uintptr_t>(out) >> 3);  // (lines are 64 bytes of the ADDRESS, not of the element index)
-  // A point's four elements are requested together (the first form loaded each where it used it: six exposed memory latencies per row), and
+  // A point's operands are requested together (the first form loaded each where it used it: six exposed memory latencies per row), and
   // those of the NEXT row's first point before this row's stores go out: vmcnt counts loads and stores in order, so a load issued behind the
   // 65 stores of a flush cannot be waited for without waiting for the stores -- the first point of a row is made affine while they drain.
-  fe pd = pt_load(pt_at(blk, r_end - 1, TR_PD), t), az = pt_load(pt_at(blk, r_end - 1, TR_AZ), t), ax = pt_load(pt_at(blk, r_end - 1, TR_AX), t),
-     ay = pt_load(pt_at(blk, r_end - 1, TR_AY), t);
+  // pp = P(add of the row below) (row 0: the empty product), dz = Z(dbl): P(dbl_r) = pp dz is formed here, not stored by pass 1.
+  fe az = pt_load(pt_at(blk, r_end - 1, TR_AZ), t), ax = pt_load(pt_at(blk, r_end - 1, TR_AX), t), ay = pt_load(pt_at(blk, r_end - 1, TR_AY), t);
+  fe pp = r_end - 1 > 0 ? pt_load(pt_at(blk, r_end - 2, TR_PA), t) : fe_one(), dz = pt_load(pt_at(blk, r_end - 1, TR_DZ), t);
 #pragma unroll 1
   for (int r = r_end - 1; r >= r_first; r--) {
     {  // add_r: 1 / Z = inv(P_add) P_dbl, then inv(P_dbl) = inv(P_add) Z
       uint32_t o[16];
-      const fe zinv = fe_mul(inv, pd);
+      const fe zinv = fe_mul(inv, fe_mul(pp, dz));
       inv = fe_mul(inv, az);
       fe_to_words(fe_mul(ax, zinv), o);
       fe_to_words(fe_mul(ay, zinv), o + 8);
@@ -277,8 +268,8 @@ __global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t lane0, uint3
     }
     {  // dbl_r: 1 / Z = inv(P_dbl) P_add(r - 1)   (row 0: the empty product)
       uint32_t o[16];
-      const fe zinv = r > 0 ? fe_mul(inv, pt_load(pt_at(blk, r - 1, TR_PA), t)) : inv;
-      if (r > r_first) inv = fe_mul(inv, pt_load(pt_at(blk, r, TR_DZ), t));
+      const fe zinv = r > 0 ? fe_mul(inv, pp) : inv;
+      if (r > r_first) inv = fe_mul(inv, dz);
       fe_to_words(fe_mul(pt_load(pt_at(blk, r, TR_DX), t), zinv), o);
       fe_to_words(fe_mul(pt_load(pt_at(blk, r, TR_DY), t), zinv), o + 8);
 #pragma unroll
@@ -287,8 +278,8 @@ __global__ __launch_bounds__(64) void k_trace_ladder_pass2(uint32_t lane0, uint3
       for (int q = 0; q < 7; q++) stage[t][TR_ST_CARRY + ((r & 1) ? 0 : 7) + q] = o[q] & z;  // (for the flush of the row below)
     }
     if (r > r_first) {
-      pd = pt_load(pt_at(blk, r - 1, TR_PD), t); az = pt_load(pt_at(blk, r - 1, TR_AZ), t); ax = pt_load(pt_at(blk, r - 1, TR_AX), t);
-      ay = pt_load(pt_at(blk, r - 1, TR_AY), t);
+      az = pt_load(pt_at(blk, r - 1, TR_AZ), t); ax = pt_load(pt_at(blk, r - 1, TR_AX), t); ay = pt_load(pt_at(blk, r - 1, TR_AY), t);
+      pp = r - 1 > 0 ? pt_load(pt_at(blk, r - 2, TR_PA), t) : fe_one(); dz = pt_load(pt_at(blk, r - 1, TR_DZ), t);
     }
     const uint32_t bit = scalar_bit(L.sc, r);
     stage[t][TR_ST_BIT] = bit_above & z;  // (an undecodable lane stores zero bits too)
