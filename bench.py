@@ -682,7 +682,10 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
                         "columns_stage": {"bytes": cols * rows * 8 + col_b, "frac_of_hbm": round(gbs(cols * rows * 8 + col_b, ms["columns"]) / HBM_PEAK_GBS, 4),
                                           "note": "the section's own rows read once, the zero-padded columns written once"},
                         "lde_stage": {"bytes_one_read_one_write_per_pass": 2 * (2 * col_b) + 2 * (2 * lde_b) + 2 * lde_b,
-                                      "frac_of_hbm": round(gbs(4 * col_b + 6 * lde_b, ms["lde"]) / HBM_PEAK_GBS, 4)},
+                                      "frac_passes": round(gbs(4 * col_b + 6 * lde_b, ms["lde"]) / HBM_PEAK_GBS, 4),
+                                      "frac_1r1w": round(gbs(col_b + lde_b, ms["lde"]) / HBM_PEAK_GBS, 4),
+                                      "note": "frac_passes: what the two-pass inverse + two-pass forward transforms move (a read and a write per pass); "
+                                              "frac_1r1w: the algorithmic minimum, the columns read once and the extended columns written once"},
                         "merkle_stage": {"permutations": perms, "gperm_per_s": round(perms / (ms["merkle"] * 1e-3) / 1e9, 3),
                                          "bytes_read": lde_b, "frac_of_hbm": round(gbs(lde_b, ms["merkle"]) / HBM_PEAK_GBS, 4)},
                         "cap0": [int(x) & (2**64 - 1) for x in cap[:4].cpu().numpy()]}

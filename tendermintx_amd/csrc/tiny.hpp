@@ -545,8 +545,10 @@ __device__ __forceinline__ void tiny_header(const TinyProof& A, uint32_t p, uint
     uint32_t len = hrec[li];
     if (len > 79) len = 79;
     const uint8_t* leaf = hrec + 16 + 80 * li;
-    uint32_t dig[8];
-    sha256_short([&](uint32_t pos) -> uint32_t { return pos == 0 ? 0u : (uint32_t)leaf[pos - 1]; }, len + 1, dig);
+    uint32_t fw0[20], dig[8];  // (twenty word loads masked to the field's length: proof_body phase 1a)
+#pragma unroll
+    for (int w = 0; w < 20; w++) fw0[w] = ld32(leaf + 4 * w) & field_keep(len, w);
+    sha256_leaf80(fw0, len, dig);
 #pragma unroll
     for (int k = 0; k < 8; k++) s_hdr[hsel][li][k] = dig[k];
   }
@@ -581,7 +583,12 @@ __device__ __forceinline__ void tiny_header(const TinyProof& A, uint32_t p, uint
   {
     uint32_t hl = hdr_a[2];
     if (hl > 79) hl = 79;
-    for (uint32_t k = 1, s = 0; k < hl && k <= 10; k++, s += 7) height_a |= (uint64_t)(hdr_a[16 + 80 * 2 + k] & 0x7f) << s;
+    const uint32_t hw0 = ld32(hdr_a + 16 + 80 * 2), hw1 = ld32(hdr_a + 16 + 80 * 2 + 4), hw2 = ld32(hdr_a + 16 + 80 * 2 + 8);
+#pragma unroll
+    for (uint32_t k = 1; k <= 10; k++) {  // (bytes 1 .. 10 of the height field from three word loads: proof_body phase 4)
+      const uint32_t word = k < 4 ? hw0 : (k < 8 ? hw1 : hw2), byte = (word >> (8 * (k & 3))) & 0x7fu;
+      if (k < hl) height_a |= (uint64_t)byte << (7 * (k - 1));
+    }
   }
   if (t < (int)n_incl) {
     const int q = t;
@@ -676,14 +683,22 @@ __device__ __forceinline__ void tiny_header(const TinyProof& A, uint32_t p, uint
   uint32_t fails = 0;
   for (uint32_t i = t; i < n; i += blockDim.x) {
     const uint8_t* rec = tg + (size_t)i * VR_STRIDE;
-    const uint8_t* msg = rec + VR_OFF_MSG;
     const bool sgn = rec[VR_OFF_FLAGS] & 1, enabled = i < nb;
-    const int off = round_ == 0 ? 16 : 25;
-    bool hash_in_msg = true;
-    for (int k = 0; k < 32; k++) hash_in_msg = hash_in_msg && ((uint32_t)msg[off + k] == digest_byte(hdr_hash, k));
-    const bool is_precommit = msg[1] == 8 && msg[2] == 2;
-    uint64_t mh = 0, mr = 0;
-    for (int k = 7; k >= 0; k--) { mh = (mh << 8) | msg[4 + k]; mr = (mr << 8) | msg[13 + k]; }
+    // (the first 60 sign-bytes as fifteen word loads, the 32-byte comparison word-wise at both possible offsets: proof_body phase 3a)
+    uint32_t mw[15];
+#pragma unroll
+    for (int w = 0; w < 15; w++) mw[w] = ld32(rec + VR_OFF_MSG + 4 * w);
+    auto word_at = [&](int q) -> uint32_t { return (q & 3) ? __builtin_amdgcn_alignbyte(mw[(q >> 2) + 1], mw[q >> 2], q & 3) : mw[q >> 2]; };
+    uint32_t d16 = 0, d25 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t want = bswap32(hdr_hash[k]);
+      d16 |= word_at(16 + 4 * k) ^ want; d25 |= word_at(25 + 4 * k) ^ want;
+    }
+    const bool hash_in_msg = (round_ == 0 ? d16 : d25) == 0;
+    const bool is_precommit = (mw[0] & 0x00ffff00u) == 0x00020800u;
+    const uint64_t mh = (uint64_t)mw[1] | ((uint64_t)mw[2] << 32);
+    const uint64_t mr = (uint64_t)word_at(13) | ((uint64_t)word_at(17) << 32);
     const bool height_ok = mh == block_b;
     const bool round_ok = round_ == 0 ? true : (mr == round_);
     const bool valid = sgn && enabled && hash_in_msg && is_precommit && height_ok && round_ok;

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Goldilocks NTT / LDE throughput on one GPU (HIP events on the launch stream) beside the CPU oracle on one column.
-Algorithmic HBM bytes: one read + one write of every element per pass (one pass up to 2^11, two above)."""
+Two HBM fractions per shape: `frac_passes` counts what the kernels really move -- one read + one write of every element per pass (one pass up
+to 2^11, two above: the four-step split) -- and `frac_1r1w` the algorithmic minimum of ONE read and ONE write of the column (what a transform
+that kept a 2^20-element column on chip would move).  Neither is the kernel's roof: `valu_issue_frac` is (profiles/r04_ntt_rocprofv3_summary.txt:
+6.65e8 wave-level VALU instructions per pass at 2^20 x 256 = 158 per element and pass, 15.8 per element and stage, scaled by the stage count)
+the fraction of the chip's issue slots the butterflies need in the measured time."""
 import json
 import os
 import sys
@@ -45,7 +49,9 @@ for log_n, cols in CASES:
     cpu_ms = 1e3 * (time.perf_counter() - a)
     ok = bool(np.array_equal(out[0].cpu().numpy().view(np.uint64), ref))
     rows.append({"log_n": log_n, "cols": cols, "ms": round(ms, 4), "elements_per_s": round(n * cols / (ms * 1e-3), 0),
-                 "algorithmic_gbs": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac_of_8tbs": round(nbytes / (ms * 1e-3) / 8e12, 3),
+                 "algorithmic_gbs": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac_passes": round(nbytes / (ms * 1e-3) / 8e12, 3),
+                 "frac_1r1w": round(2 * 8 * n * cols / (ms * 1e-3) / 8e12, 3), "passes": passes,
+                 "valu_issue_frac": round(15.8 * log_n * n * cols / 64 * 4.07 / (1024 * 2.4e9) / (ms * 1e-3), 3),
                  "butterfly_mul_per_s": round(n * cols * log_n / 2 / (ms * 1e-3), 0),
                  "cpu_oracle_ms_one_column": round(cpu_ms, 2), "speedup_vs_one_core": round(cpu_ms * cols / ms, 0), "bit_exact_col0": ok})
     print(json.dumps(rows[-1]), flush=True)
