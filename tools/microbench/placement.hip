@@ -23,12 +23,13 @@ __global__ void k_place(unsigned* out, int iters, unsigned seed) {
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   unsigned a = seed + threadIdx.x;
   const unsigned b = seed | 1u;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; it++) asm volatile(".rept 64\nv_mad_u32_u24 %0, %0, %1, %0\n.endr" : "+v"(a) : "v"(b));
   const unsigned long long t1 = __builtin_readcyclecounter();
   const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if ((threadIdx.x & 63) == 0) {
-    out[4 * wave] = hw; out[4 * wave + 1] = xcc; out[4 * wave + 2] = (unsigned)(t1 - t0); out[4 * wave + 3] = a;
+    out[4 * wave] = hw; out[4 * wave + 1] = xcc | ((unsigned)r0 << 4); out[4 * wave + 2] = (unsigned)(t1 - t0); out[4 * wave + 3] = a;
   }
 }
 
@@ -85,9 +86,9 @@ static void run_straight(const char* name, K kern, int n, unsigned* d, int G) {
 
 int main() {
   const int iters = 400;  // 25.6 k dependent instructions ~ 50 us for a lone wave
-  const int shapes[][2] = {{1, 64}, {256, 64}, {512, 64}, {1024, 64}, {2048, 64}, {256, 128}, {128, 256}, {64, 512}, {512, 128}, {256, 256}, {1024, 128}};
+  const int shapes[][2] = {{1, 64}, {256, 64}, {512, 64}, {1024, 64}, {2048, 64}, {256, 128}, {128, 256}, {64, 512}, {512, 128}, {256, 256}, {1024, 128}, {4096, 64}, {8192, 64}, {2048, 128}};
   unsigned* d;
-  CK(hipMalloc(&d, 4 * 4 * 8192));
+  CK(hipMalloc(&d, 4 * 4 * 16384));
   for (auto& sh : shapes) {
     const int G = sh[0], T = sh[1], waves = G * T / 64;
     hipEvent_t e0, e1;
@@ -104,8 +105,11 @@ int main() {
     CK(hipMemcpy(h.data(), d, 4 * 4 * waves, hipMemcpyDeviceToHost));
     std::map<unsigned, int> per_simd, per_cu;
     unsigned long long cyc = 0;
+    unsigned rmin = 0xffffffffu, rmax = 0;
+    std::vector<unsigned> starts;
     for (int w = 0; w < waves; w++) {
-      const unsigned hw = h[4 * w], xcc = h[4 * w + 1] & 0xf;
+      const unsigned hw = h[4 * w], xcc = h[4 * w + 1] & 0xf, r0 = h[4 * w + 1] >> 4;
+      starts.push_back(r0); if (r0 < rmin) rmin = r0; if (r0 > rmax) rmax = r0;
       const unsigned simd = (hw >> 4) & 3, cu = (hw >> 8) & 0xf, shid = (hw >> 12) & 1, se = (hw >> 13) & 7;
       const unsigned cu_key = xcc << 16 | se << 8 | shid << 4 | cu;
       per_cu[cu_key]++; per_simd[cu_key << 2 | simd]++;
@@ -119,7 +123,9 @@ int main() {
     for (auto& kv : hist_simd) std::printf(" %dx%d", kv.second, kv.first);
     std::printf(" | waves per CU:");
     for (auto& kv : hist_cu) std::printf(" %dx%d", kv.second, kv.first);
-    std::printf("\n");
+    int late = 0;
+    for (unsigned r0 : starts) if (((r0 - rmin) & 0x0fffffffu) > 500) late++;  // started more than 5 us behind the first wave
+    std::printf(" | start spread %.1f us, %d waves started > 5 us late\n", ((rmax - rmin) & 0x0fffffffu) / 100.0, late);
   }
   for (int G : {1, 512, 1024}) {
     run_straight("loop64", k_s64, 64, d, G);
