@@ -273,6 +273,7 @@ struct Knobs {
   int p1_early = -1;         // TMX_P1_EARLY=0|1|2: D.1a behind k_proof's sections on the side stream (1: on a capped grid, 2: full grid) instead of behind k_ed_fin (default: capped, from 131072 lanes)
   int hash_first = -1;       // TMX_HASH_FIRST=0|1: warm schedule with the hash role in front of the dedup (which moves to side2); default: see run_eddsa
   bool walk_split = true;    // TMX_WALK_SPLIT=0: the warm schedule's table walk as ONE launch behind the table build (the round-4 form) instead of resident lanes at once + new-key lanes behind the build
+  bool compact = true;       // TMX_COMPACT=0: every lane through the EdDSA kernels (round 4), also the ones that did not sign
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
 static Knobs read_knobs() {
@@ -292,6 +293,7 @@ static Knobs read_knobs() {
   if ((v = std::getenv("TMX_PHASE1_MAX"))) k.phase1_max = std::atoi(v);
   k.hash_first = (v = std::getenv("TMX_HASH_FIRST")) ? (v[0] != '0' ? 1 : 0) : -1;
   k.p1_early = (v = std::getenv("TMX_P1_EARLY")) && v[0] >= '0' && v[0] <= '2' ? v[0] - '0' : -1;
+  k.compact = !((v = std::getenv("TMX_COMPACT")) && v[0] == '0');
   return k;
 }
 
@@ -336,6 +338,9 @@ struct tmx_ctx {
   void *d_qtable = nullptr, *d_pre = nullptr, *d_mulout = nullptr;
   // EdDSA stage: the launch's own dedup structures, the key records (cache slots, then one per lane for keys without a slot), the
   // anchor scratch of the tables being built, and the persistent key cache
+  // the lanes that did not sign: one precomputed record for all of them (dummy_record), the dense list of the others per launch
+  void *d_live = nullptr, *d_dummy_ed = nullptr, *d_dummy_in = nullptr;
+  bool dummy_ready = false;
   void *d_hash = nullptr, *d_cnt = nullptr, *d_owner_of = nullptr, *d_slot_of_owner = nullptr, *d_slot_of_uid = nullptr, *d_owners = nullptr,
        *d_keyrec = nullptr, *d_anchors = nullptr, *d_keytab = nullptr;
   KeyCache kc = {};
@@ -651,8 +656,8 @@ static int32_t tiny_key_pipeline(tmx_ctx* c, uint32_t n_lanes, hipEvent_t after)
   Q.d_hash = c->d_hash; Q.hash_mask = c->hash_mask; Q.d_owner_of = c->d_owner_of; Q.d_slot_of_owner = c->d_slot_of_owner;
   Q.d_slot_of_uid = c->d_slot_of_uid; Q.d_owners = c->d_owners; Q.d_keyrec = c->d_keyrec; Q.d_anchors = c->d_anchors; Q.d_keytab = c->d_keytab;
   Q.kc = c->kc; Q.mode = K.dedup_mode;
-  Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * c->parity;
-  Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1);
+  Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 8 * c->parity;
+  Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 8 * (c->parity ^ 1);
   c->parity ^= 1;
   Q.use_new = 0;  // nobody waits for the tables of this launch: they are for the next call
   Q.warm = (c->kc.persist && c->h_hint && c->h_hint[0] != 0 && c->h_hint[1] == 0) ? 1u : 0u;  // (grid sizes of the new-key kernels only)
@@ -756,11 +761,16 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   Q.fin_done = c->fin_done; c->fin_done = nullptr;
   Q.row = c->row;
   c->last_lanes = n_lanes;
-  Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * c->parity;
-  Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 4 * (c->parity ^ 1);
+  Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 8 * c->parity;
+  Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 8 * (c->parity ^ 1);
   c->parity ^= 1;
   const tmx_ctx::EdPlan plan = c->plan.valid ? c->plan : ed_plan(c, n_lanes, false);
   const bool tiny = plan.tiny, warm = plan.warm;
+  // Compacted launch (kernels.h EdQuad): where the dedup opens the chain on s and the hash / s*B / walk / finish kernels are launches of their
+  // own -- the warm schedules above 16384 lanes.  Smaller launches are latency-bound (fewer lanes do not shorten them); a cold launch keeps
+  // the round-4 form.
+  Q.compact = (c->dummy_ready && K.compact && warm && !tiny && !plan.hash_first && !plan.sb_with_hash && Q.mode != 0 && Q.kc.cap != 0) ? 1u : 0u;
+  Q.d_live = c->d_live; Q.d_dummy_ed = c->d_dummy_ed;
   Q.use_new = tiny ? 0u : 1u;
   Q.warm = warm ? 1u : 0u;
   hipError_t e;
@@ -1039,6 +1049,31 @@ void release_streams(int device) {
 }
 }  // namespace
 
+// The EdDSA values of a lane that did not sign -- the dummy public key, signature and message of plonky2x (verify.rs:248-259 evaluates every
+// such lane on them) -- are the same for every lane of every proof: computed ONCE per context, by the same kernels, on a one-lane launch over
+// an all-zero lane record (flags = 0: did not sign); the key cache is emptied again afterwards, so a context starts as it always did.
+static int32_t dummy_record(tmx_ctx* c) {
+  hipStream_t ts = nullptr;
+  HIPCK(c, hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
+  int32_t st = TMX_OK;
+  if (use_tiny(c, 1)) st = run_tiny_lanes(c, 1, c->d_dummy_in, c->d_dummy_ed, ED_STRIDE, ts);
+  else if (int rc = run_eddsa(c, 1, c->d_dummy_in, c->d_dummy_ed, ED_STRIDE, ts)) st = fail(c, TMX_ERR_HIP, std::string("dummy record: ") + hipGetErrorString((hipError_t)rc));
+  hipError_t e = hipStreamSynchronize(ts);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->side2);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->side);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->side3);
+  (void)hipStreamDestroy(ts);
+  if (st) return st;
+  if (e != hipSuccess) return fail(c, TMX_ERR_HIP, std::string("dummy record: ") + hipGetErrorString(e));
+  int rc = launch_kc_reset(c->kc, c->side2);
+  if (rc) return fail(c, TMX_ERR_HIP, std::string("k_kc_reset launch: ") + hipGetErrorString((hipError_t)rc));
+  HIPCK(c, hipStreamSynchronize(c->side2));
+  c->h_hint[0] = 0; c->h_hint[1] = 0;
+  c->last_stream_valid = false;
+  c->dummy_ready = true;
+  return TMX_OK;
+}
+
 // (re)allocate the key cache for `keys` slots and empty it.  The caller has made sure nothing of this context is in flight.
 // Transactional: the new buffers are allocated and reset first; the old cache is freed only when all of that succeeded, so a failed
 // (e.g. oversized) request leaves the context exactly as it was.  A request whose tables cannot fit in the device's free memory is
@@ -1098,7 +1133,7 @@ void tmx_ctx_destroy(tmx_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipDeviceSynchronize();
   }
-  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_owner_of, c->d_slot_of_owner, c->d_slot_of_uid, c->d_owners, c->d_keyrec,
+  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_live, c->d_dummy_ed, c->d_dummy_in, c->d_owner_of, c->d_slot_of_owner, c->d_slot_of_uid, c->d_owners, c->d_keyrec,
                   c->d_anchors, c->d_keytab, c->kc.d_hash, c->kc.d_pk, c->kc.d_used, c->kc.d_free, c->kc.d_state, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
                   c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out, c->d_pack, c->d_trace_tmp, c->d_tiny, c->d_shadow, c->d_commit,
                   c->d_val_lut[0], c->d_val_lut[1], c->d_value};
@@ -1220,9 +1255,14 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     while (cap < 2 * (uint64_t)lanes) cap <<= 1;  // <= 2^31: the open-addressing table of the launch's own key deduplication
     c->hash_mask = (uint32_t)(cap - 1);
     HIPCK(c, hipMalloc(&c->d_hash, (size_t)cap * 4));
-    HIPCK(c, hipMalloc(&c->d_cnt, 32));
+    HIPCK(c, hipMalloc(&c->d_cnt, 64));
     HIPCK(c, hipMemsetAsync(c->d_hash, 0xff, (size_t)cap * 4, c->side2));
-    HIPCK(c, hipMemsetAsync(c->d_cnt, 0, 32, c->side2));
+    HIPCK(c, hipMemsetAsync(c->d_cnt, 0, 64, c->side2));
+    HIPCK(c, hipMalloc(&c->d_live, lanes * 4));
+    HIPCK(c, hipMalloc(&c->d_dummy_ed, 512));
+    HIPCK(c, hipMalloc(&c->d_dummy_in, VR_STRIDE));
+    HIPCK(c, hipMemsetAsync(c->d_dummy_ed, 0, 512, c->side2));
+    HIPCK(c, hipMemsetAsync(c->d_dummy_in, 0, VR_STRIDE, c->side2));
     HIPCK(c, hipMalloc(&c->d_owner_of, lanes * 4));
     HIPCK(c, hipMalloc(&c->d_slot_of_owner, lanes * 4));
     HIPCK(c, hipMalloc(&c->d_slot_of_uid, lanes * 4));
@@ -1241,7 +1281,7 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_init_base_quad launch: ") + hipGetErrorString((hipError_t)rc));
   HIPCK(c, hipEventRecord(c->ev_hash_clean, c->side2));
   HIPCK(c, hipStreamSynchronize(c->side2));
-  return TMX_OK;
+  return dummy_record(c);
 }
 
 static int32_t ensure_host_stream(tmx_ctx* c) {

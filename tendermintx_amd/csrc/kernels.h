@@ -48,6 +48,11 @@ struct EdQuad {
   uint32_t warm;      // 1: the launch expects (nearly) all of its keys to be resident: small grids for the new-key kernels (they loop)
   RowOut row;         // where the finish writes D.1b straight into the witness rows (rows = null: lane records only)
   void* fin_done;     // event attached to the k_ed_fin dispatch as its completion signal (no separate record packet), or null
+  // Compacted launch: lanes that did not sign receive the context's precomputed dummy record in k_ed_dedup, the lanes that signed are listed
+  // densely in d_live (their count in cnt[4]) and the hash / s*B / walk / finish kernels run over that list.
+  uint32_t compact = 0;
+  void* d_live = nullptr;
+  const void* d_dummy_ed = nullptr;
 };
 size_t quad_table_bytes();
 size_t pre_bytes_per_lane();
