@@ -598,7 +598,10 @@ KNOBS = [
     # round 5: the warm walk split by residency (resident lanes at once, new-key lanes behind the table build on the side stream): off; forced
     # onto launches with new keys (the mixed case is what the split is for: the batch below brings 100 new keys under a warm hint)
     {"TMX_WALK_SPLIT": "0", "TMX_SCHEDULE": "warm"}, {"TMX_SCHEDULE": "warm", "TMX_TINY": "0"}, {"TMX_SCHEDULE": "warm", "TMX_HASH_FIRST": "0", "TMX_KEY_CACHE_KEYS": "60"},
-    {"TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0"}, {"TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0", "TMX_EXT_EVENTS": "0", "TMX_TINY": "0"}]
+    {"TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0"}, {"TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0", "TMX_EXT_EVENTS": "0", "TMX_TINY": "0"},
+    # round 5: lanes that did not sign take the context's precomputed record and the EdDSA kernels run over the dense list of the others (every
+    # launch of > 2048 lanes whose chain the dedup opens: the cold calls of this test, the warm ones with TMX_HASH_FIRST=0): off; on in both schedules
+    {"TMX_COMPACT": "0"}, {"TMX_COMPACT": "0", "TMX_HASH_FIRST": "0"}, {"TMX_HASH_FIRST": "0", "TMX_PHASE1_MAX": "0"}, {"TMX_HASH_FIRST": "0", "TMX_SCHEDULE": "cold"}]
 
 
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
@@ -625,6 +628,20 @@ def test_schedule_knobs_give_the_same_bits(tmx, oracle, monkeypatch, knobs):
             _, reps = _check_vs_oracle(tmx, oracle, 0, n, wl.proofs[p0 * 2336:p1 * 2336], bytes(targets[p0 * n * 256:p1 * n * 256]),
                                        wl.trusteds[p0 * n * 48:p1 * n * 48], b"celestia", ctx=ctx)
             assert [r["first_bad_sig"] for r in reps] == ([lane] if p0 == 0 else [-1]) + [-1] * (p1 - p0 - 1)
+
+
+@pytest.mark.parametrize("permille", [0, 1000, 500])
+def test_compacted_launch_edges(tmx, oracle, monkeypatch, permille):
+    """The dense list of lanes that signed (k_ed_dedup, kernels.h EdQuad.compact) at its edges: NOBODY signed in the whole batch (an empty
+    list: every lane is the precomputed dummy record, every proof fails its threshold), EVERYBODY signed (the list is every lane), half of
+    them -- 24 proofs x 128 lanes, cold and warm on one context with the dedup opening the chain (TMX_HASH_FIRST=0), bit-exact vs the oracle."""
+    from tendermintx_amd.synth import Workload
+    monkeypatch.setenv("TMX_HASH_FIRST", "0")
+    n, P = 128, 24
+    wl = Workload(0, n, P, 128 if permille == 1000 else 90, chain_id=b"celestia", seed=515 + permille, signed_permille=permille)
+    with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+        _, reps = _check_vs_oracle(tmx, oracle, 0, n, wl.proofs, wl.targets, wl.trusteds, b"celestia", ctx=ctx, repeat=2)
+        assert all(r["first_bad_sig"] == -1 for r in reps) and (permille != 0 or not any(r["all_ok"] for r in reps))
 
 
 def test_many_distinct_keys_take_the_throughput_forms(tmx, oracle):
