@@ -410,6 +410,14 @@ typedef struct {
 int32_t tmx_key_cache_stats(tmx_ctx* ctx, tmx_key_cache_info* out);
 int32_t tmx_key_cache_flush(tmx_ctx* ctx);                                      /* forget every key */
 int32_t tmx_key_cache_config(tmx_ctx* ctx, uint32_t enabled, uint32_t max_keys); /* max_keys = 0 keeps the capacity; a new capacity flushes */
+/* The validator-set cache of a context (round 5): marshalled validators, leaf hashes and every node of the fixed-shape tree
+ * (reference circuits/builder/validator.rs:185-252) depend on the validator set alone -- (pubkey, voting power, validator_byte_length) of every lane and
+ * the number of enabled lanes -- not on the proof, and a light client re-verifies the same slowly changing sets.  A batch's k_proof looks both
+ * sets of a proof up by a 64-bit fingerprint, compares EVERY key byte, and copies the cached values instead of hashing (15 SHA-256
+ * compressions off its chain); sets it had to compute are inserted (256 sets per context; a full cache stops inserting; tmx_key_cache_flush
+ * empties it too; TMX_SET_CACHE=0 disables).  Bit-identical by construction.  out: [0] sets resident [1] sets served from the cache
+ * [2] sets computed [3] sets inserted (totals since creation / the last flush). */
+int32_t tmx_set_cache_stats(tmx_ctx* ctx, uint32_t out[4]);
 
 /* ---- Level-2 trace rows (SURVEY 8a "Level-2", 8f rank 2): the row-level execution trace behind the Level-1 values -- what the reference
  * produces inside Curta's trace generators for `curta_eddsa_verify_sigs_conditional` (reference circuits/builder/verify.rs:248-259) and

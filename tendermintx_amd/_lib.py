@@ -258,6 +258,7 @@ def lib():
     L.tmx_key_cache_stats.argtypes = [C.c_void_p, C.POINTER(KeyCacheInfo)]
     L.tmx_key_cache_flush.argtypes = [C.c_void_p]
     L.tmx_key_cache_config.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.tmx_set_cache_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.tmx_eddsa_lanes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.tmx_skip_inputs_from_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64,
                                             C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]

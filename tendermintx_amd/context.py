@@ -311,6 +311,12 @@ class Context:
         check(self._L.tmx_key_cache_stats(self._h, C.byref(info)), self._h)
         return info.as_dict()
 
+    def set_cache_stats(self):
+        """The validator-set cache (tmx_set_cache_stats): sets resident / served from the cache / computed / inserted."""
+        out = (C.c_uint32 * 4)()
+        check(self._L.tmx_set_cache_stats(self._h, out), self._h)
+        return dict(zip(("resident", "served", "computed", "inserted"), (int(x) for x in out)))
+
     def key_cache_flush(self):
         check(self._L.tmx_key_cache_flush(self._h), self._h)
 

@@ -274,6 +274,7 @@ struct Knobs {
   int hash_first = -1;       // TMX_HASH_FIRST=0|1: warm schedule with the hash role in front of the dedup (which moves to side2); default: see run_eddsa
   bool walk_split = true;    // TMX_WALK_SPLIT=0: the warm schedule's table walk as ONE launch behind the table build (the round-4 form) instead of resident lanes at once + new-key lanes behind the build
   bool compact = true;       // TMX_COMPACT=0: every lane through the EdDSA kernels (round 4), also the ones that did not sign
+  bool set_cache = true;     // TMX_SET_CACHE=0: k_proof computes the leaves and the tree of every validator set of every proof (round 4)
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
 static Knobs read_knobs() {
@@ -294,6 +295,7 @@ static Knobs read_knobs() {
   k.hash_first = (v = std::getenv("TMX_HASH_FIRST")) ? (v[0] != '0' ? 1 : 0) : -1;
   k.p1_early = (v = std::getenv("TMX_P1_EARLY")) && v[0] >= '0' && v[0] <= '2' ? v[0] - '0' : -1;
   k.compact = !((v = std::getenv("TMX_COMPACT")) && v[0] == '0');
+  k.set_cache = !((v = std::getenv("TMX_SET_CACHE")) && v[0] == '0');
   return k;
 }
 
@@ -341,6 +343,7 @@ struct tmx_ctx {
   // the lanes that did not sign: one precomputed record for all of them (dummy_record), the dense list of the others per launch
   void *d_live = nullptr, *d_dummy_ed = nullptr, *d_dummy_in = nullptr;
   bool dummy_ready = false;
+  SetCache setc = {};   // the validator-set cache (layout.h); table == nullptr: off (TMX_SET_CACHE=0)
   void *d_hash = nullptr, *d_cnt = nullptr, *d_owner_of = nullptr, *d_slot_of_owner = nullptr, *d_slot_of_uid = nullptr, *d_owners = nullptr,
        *d_keyrec = nullptr, *d_anchors = nullptr, *d_keytab = nullptr;
   KeyCache kc = {};
@@ -493,7 +496,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
            ? launch_proof_roles(proof_params(c, kind, leaves_first), n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf,
                                 c->d_nodes_t, c->d_nodes_r, reports, c->d_tiny, c->side, xp ? evs[0] : nullptr, xp ? evs[1] : nullptr)
            : launch_proof(proof_params(c, kind, leaves_first), n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf,
-                          c->d_nodes_t, c->d_nodes_r, reports, c->side, xp ? evs[0] : nullptr, xp ? evs[1] : nullptr);
+                          c->d_nodes_t, c->d_nodes_r, reports, c->side, xp ? evs[0] : nullptr, xp ? evs[1] : nullptr, c->setc);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_proof launch: ") + hipGetErrorString((hipError_t)rc));
   if (!xp) HIPCK(c, hipEventRecord(evs[1], c->side));
   // side3: the sections that are a pure expansion of the input records (42 % of a skip row) -- HBM is idle while EdDSA runs.
@@ -1133,7 +1136,7 @@ void tmx_ctx_destroy(tmx_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipDeviceSynchronize();
   }
-  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_live, c->d_dummy_ed, c->d_dummy_in, c->d_owner_of, c->d_slot_of_owner, c->d_slot_of_uid, c->d_owners, c->d_keyrec,
+  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_live, c->d_dummy_ed, c->d_dummy_in, c->setc.table, c->setc.state, c->setc.slots, c->d_owner_of, c->d_slot_of_owner, c->d_slot_of_uid, c->d_owners, c->d_keyrec,
                   c->d_anchors, c->d_keytab, c->kc.d_hash, c->kc.d_pk, c->kc.d_used, c->kc.d_free, c->kc.d_state, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
                   c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out, c->d_pack, c->d_trace_tmp, c->d_tiny, c->d_shadow, c->d_commit,
                   c->d_val_lut[0], c->d_val_lut[1], c->d_value};
@@ -1259,6 +1262,15 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     HIPCK(c, hipMemsetAsync(c->d_hash, 0xff, (size_t)cap * 4, c->side2));
     HIPCK(c, hipMemsetAsync(c->d_cnt, 0, 64, c->side2));
     HIPCK(c, hipMalloc(&c->d_live, lanes * 4));
+    if (c->knobs.set_cache) {  // 256 validator sets (20 KB each at N = 128, 82 KB at N = 512), a table of 1024 entries
+      SetCache& sc = c->setc;
+      sc.cap = 256; sc.tab_mask = 1023; sc.slot_bytes = (setcache_slot_bytes(n, tree_nodes(n)) + 63u) & ~63u;
+      HIPCK(c, hipMalloc(reinterpret_cast<void**>(&sc.table), (sc.tab_mask + 1) * 4));
+      HIPCK(c, hipMalloc(reinterpret_cast<void**>(&sc.state), 32));
+      HIPCK(c, hipMalloc(reinterpret_cast<void**>(&sc.slots), (size_t)sc.cap * sc.slot_bytes));
+      HIPCK(c, hipMemsetAsync(sc.table, 0, (sc.tab_mask + 1) * 4, c->side2));
+      HIPCK(c, hipMemsetAsync(sc.state, 0, 32, c->side2));
+    }
     HIPCK(c, hipMalloc(&c->d_dummy_ed, 512));
     HIPCK(c, hipMalloc(&c->d_dummy_in, VR_STRIDE));
     HIPCK(c, hipMemsetAsync(c->d_dummy_ed, 0, 512, c->side2));
@@ -1346,8 +1358,23 @@ int32_t tmx_key_cache_flush(tmx_ctx* c) {
   if (q) return q;
   int rc = launch_kc_reset(c->kc, c->side2);
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_kc_reset launch: ") + hipGetErrorString((hipError_t)rc));
+  if (c->setc.table) {  // (the validator-set cache goes with it: "flush" = a context as new)
+    HIPCK(c, hipMemsetAsync(c->setc.table, 0, (c->setc.tab_mask + 1) * 4, c->side2));
+    HIPCK(c, hipMemsetAsync(c->setc.state, 0, 32, c->side2));
+  }
   HIPCK(c, hipStreamSynchronize(c->side2));
   c->h_hint[0] = 0; c->h_hint[1] = 0;  // an empty cache: the next enqueue takes the cold schedule, as the first call of a context does
+  return TMX_OK;
+}
+
+int32_t tmx_set_cache_stats(tmx_ctx* c, uint32_t out[4]) {
+  if (!c || !out) return TMX_ERR_BAD_ARG;
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (!c->setc.table) return TMX_OK;
+  int32_t q = quiesce(c);
+  if (q) return q;
+  HIPCK(c, hipMemcpy(out, c->setc.state, 16, hipMemcpyDeviceToHost));
+  if (out[0] > c->setc.cap) out[0] = c->setc.cap;
   return TMX_OK;
 }
 

@@ -79,7 +79,7 @@ int launch_ed_base(const EdQuad& Q, void* stream, void* done = nullptr);  // s*B
 int launch_ed_fin(const EdQuad& Q, void* stream, bool fused_direct = false, uint32_t which = 0);
 int launch_proof(const ProofParams& P, uint32_t n_proofs, const void* d_proofs, const void* d_target, const void* d_trusted, void* d_lt,
                  uint32_t lt_stride, void* d_lr, void* d_pf, void* d_nodes_t, void* d_nodes_r, void* d_reports, void* stream, void* started = nullptr,
-                 void* done = nullptr);
+                 void* done = nullptr, const SetCache& SC = SetCache{});
 constexpr uint32_t KC_EPILOGUE_CLEARS_UP_TO = 1u << 16;  // launch hash tables up to this many words are cleared by k_kc_epilogue itself
 // marshalled validators + leaf hashes of both sets as a launch of its own; k_proof then reads them (ProofParams::leaves_done)
 int launch_leaves(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_target, const void* d_trusted, void* d_lt, uint32_t lt_stride, void* d_lr,

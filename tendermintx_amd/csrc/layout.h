@@ -108,6 +108,24 @@ struct RowOut {
 // ---- Level-2 trace rows (trace.hip): row widths in elements
 constexpr uint32_t TR_LADDER_ROW = 65, TR_LADDER_ROWS = 256, TR_SHA512_ROW = 18, TR_SHA256_ROW = 9;
 
+// The validator-set cache of a context (round 5).  marshal + leaf hash of every lane and the fixed-shape tree above them depend on the set
+// alone -- (pubkey, voting power, validator_byte_length) of every lane and the number of enabled lanes -- not on the proof: a light client
+// re-verifies the same slowly changing sets (reference bin/tendermintx.rs:171), and the 256 proofs of a batch share a handful.  Content
+// addressed like the key cache: a 64-bit fingerprint finds a slot, ALL key bytes are compared before its values are used.
+//   table[tab_mask + 1]   0 = empty, (slot + 1) = valid, (slot + 1) | SETC_PENDING = claimed and being written
+//   state[8]              [0] next free slot  [1] sets served from the cache  [2] sets computed  [3] sets inserted
+//   slot                  u64 fingerprint | u32 nb | u32 varint-msb failures | pad to 32 | root[32] | keys n x 48 B (pubkey, power, vlen) |
+//                         per-lane values n x 80 B (marshalled validator 48, leaf hash 32) | tree nodes tree_nodes x 32 B
+// Slots are never rewritten while the cache lives (tmx_key_cache_flush empties it; a full cache stops inserting).
+constexpr uint32_t SETC_PENDING = 0x80000000u, SETC_HDR = 64, SETC_KEY = 48, SETC_VAL = 80;
+struct SetCache {
+  uint32_t* table;  // null: no cache (every set is computed)
+  uint32_t* state;
+  uint8_t* slots;
+  uint32_t cap, tab_mask, slot_bytes, pad;
+};
+constexpr uint32_t setcache_slot_bytes(uint32_t n, uint32_t tree_nodes) { return SETC_HDR + n * (SETC_KEY + SETC_VAL) + tree_nodes * 32; }
+
 struct ProofParams {
   uint32_t kind, n, tree_nodes, chain_id_len;
   uint32_t pad0_, pad1_;

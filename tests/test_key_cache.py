@@ -190,3 +190,37 @@ def test_step_and_skip_share_the_cache(tmx, oracle):
         _check(ctx, oracle, sk, n, kind=0)
         _check(ctx, oracle, st_, n, kind=1)
         assert ctx.key_cache_stats()["last_hit_lanes"] == 2 * n
+
+
+@pytest.mark.gpu
+def test_validator_set_cache(tmx, oracle, monkeypatch):
+    """The validator-set cache of a context (include/tmx.h tmx_set_cache_stats; layout.h SetCache): a batch of 24 proofs over three validator
+    sets computes each (target, trusted) set once per workgroup that finds it missing and inserts it once; the second call serves all 48 sets
+    from the cache; a set that differs in ONE byte (a voting power) is a different set; rows bit-exact vs the oracle every time, and equal to a
+    context without the cache (TMX_SET_CACHE=0)."""
+    from tendermintx_amd.synth import Workload
+    n, P = 128, 24
+    wl = Workload(0, n, P, 100, chain_id=b"celestia", seed=9001, signed_permille=900, n_sets=3)
+    with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+        e1, _ = ctx.witness_batch(0, wl.proofs, wl.targets, wl.trusteds)
+        s1 = ctx.set_cache_stats()
+        assert s1["served"] == 0 and s1["computed"] == 2 * P and 1 <= s1["resident"] <= 2 * P and s1["inserted"] == s1["resident"]
+        e2, _ = ctx.witness_batch(0, wl.proofs, wl.targets, wl.trusteds)
+        s2 = ctx.set_cache_stats()
+        assert s2["served"] == 2 * P and s2["computed"] == s1["computed"] and s2["resident"] == s1["resident"]
+        want, _ = oracle.witness_batch(0, P, wl.proofs, wl.targets, wl.trusteds, n, b"celestia", 100800, n_threads=8)
+        assert np.array_equal(e1, want) and np.array_equal(e2, want)
+        # one byte of one lane's voting power in proof 5's target set: that proof's target set is new, everything else is served
+        t2 = bytearray(wl.targets)
+        t2[(5 * n + 17) * 256 + 224] ^= 1
+        e3, _ = ctx.witness_batch(0, wl.proofs, bytes(t2), wl.trusteds)
+        s3 = ctx.set_cache_stats()
+        assert s3["computed"] == s2["computed"] + 1 and s3["served"] == s2["served"] + 2 * (P - 1) and s3["resident"] == s2["resident"] + 1
+        want3, _ = oracle.witness_batch(0, P, wl.proofs, bytes(t2), wl.trusteds, n, b"celestia", 100800, n_threads=8)
+        assert np.array_equal(e3, want3)
+        ctx.key_cache_flush()
+        assert ctx.set_cache_stats() == {"resident": 0, "served": 0, "computed": 0, "inserted": 0}
+    monkeypatch.setenv("TMX_SET_CACHE", "0")
+    with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+        e4, _ = ctx.witness_batch(0, wl.proofs, wl.targets, wl.trusteds)
+        assert ctx.set_cache_stats()["computed"] == 0 and np.array_equal(e4, want)
