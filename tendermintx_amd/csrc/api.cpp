@@ -275,6 +275,8 @@ struct Knobs {
   bool walk_split = true;    // TMX_WALK_SPLIT=0: the warm schedule's table walk as ONE launch behind the table build (the round-4 form) instead of resident lanes at once + new-key lanes behind the build
   bool compact = true;       // TMX_COMPACT=0: every lane through the EdDSA kernels (round 4), also the ones that did not sign
   bool set_cache = true;     // TMX_SET_CACHE=0: k_proof computes the leaves and the tree of every validator set of every proof (round 4)
+  bool epi_late = true;      // TMX_EPI_LATE=0: the cache epilogue of a split warm batch in front of the input sections on side3 (the first round-5 form)
+  int few_wgs = 0;           // TMX_FEW_WGS=<n>: workgroups of the serializer launches beside the chain (A/B; 0: 1024, 1536 from 131072 lanes)
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
 static Knobs read_knobs() {
@@ -296,6 +298,8 @@ static Knobs read_knobs() {
   k.p1_early = (v = std::getenv("TMX_P1_EARLY")) && v[0] >= '0' && v[0] <= '2' ? v[0] - '0' : -1;
   k.compact = !((v = std::getenv("TMX_COMPACT")) && v[0] == '0');
   k.set_cache = !((v = std::getenv("TMX_SET_CACHE")) && v[0] == '0');
+  k.epi_late = !((v = std::getenv("TMX_EPI_LATE")) && v[0] == '0');
+  if ((v = std::getenv("TMX_FEW_WGS"))) k.few_wgs = std::atoi(v);
   return k;
 }
 
@@ -330,6 +334,8 @@ struct tmx_ctx {
   hipEvent_t ev_base = nullptr;   // s*B of the batch being enqueued is done (the split warm schedule: its own launch on side2)
   // the EdDSA schedule of the batch being enqueued, decided ONCE (the hint it looks at lives in host memory the device writes)
   struct EdPlan { bool valid, tiny, warm, hash_first, sb_with_hash, split; } plan = {};
+  bool epilogue_pending = false;  // (TMX_EPI_LATE) the epilogue of the batch being enqueued goes behind the input sections on side3
+  EdQuad pending_q;
   int32_t last_kind = -1;       // kind and size of the last Level-1 batch (tmx_trace_rows_device reads its lane records)
   uint32_t last_n_proofs = 0;
   Program prog[2];
@@ -471,7 +477,11 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   HIPCK(c, hipStreamWaitEvent(c->side, ev[0], 0));
   int32_t st0 = TMX_OK;
   int rc = 0;
-  const uint32_t beside_chain_wgs = (uint64_t)n_proofs * n >= 131072 ? 1536u : 1024u;  // (warm key cache, 256 proofs: 2048 / 4096 / uncapped +10 / +4 / +2 %)
+  // (round 5, once the compaction and the validator-set cache had shortened the chain and the step's end was the row writes: 2048 workgroups at
+  // 256 proofs 0.377 - 0.387 vs 0.395 - 0.410 ms with 1024; 512 / 768: 0.455 / 0.432; 3072 / 4096 / 8192: 0.385 / 0.381 / 0.393; no difference
+  // at 64, 128, 512 and 1024 proofs)
+  const uint64_t lanes_bc = (uint64_t)n_proofs * n;
+  const uint32_t beside_chain_wgs = K.few_wgs > 0 ? (uint32_t)K.few_wgs : (lanes_bc >= 131072 ? 1536u : (lanes_bc > 16384 && lanes_bc < 65536 ? 2048u : 1024u));  // (warm key cache, 256 proofs: 2048 / 4096 / uncapped +10 / +4 / +2 %)
   // Leaves first (TMX_LEAVES=1|0, default by size): marshalled validators + leaf hashes as a 10-us launch of their own in front of k_proof,
   // so that the byte fields of the two per-lane derived sections (D.2a: the leaves; D.1a: the leaves + phase 1 -- 42 % of a skip row) are
   // written by the low-priority stream behind the input sections instead of behind k_proof (which ends at ~300 us inside a step) / k_ed_fin.
@@ -539,8 +549,15 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   c->plan.valid = false;
   c->fin_done = nullptr;
   c->row = RowOut{};
-  if (st) return st;
+  if (st) { c->epilogue_pending = false; return st; }
   if (defer3 && (st0 = side3_inputs())) return st0;
+  if (c->epilogue_pending) {
+    c->epilogue_pending = false;
+    if ((size_t)c->hash_mask + 1 > KC_EPILOGUE_CLEARS_UP_TO) HIPCK(c, hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, c->side3));
+    if ((rc = launch_kc_epilogue(c->pending_q, c->side3))) return fail(c, TMX_ERR_HIP, std::string("k_kc_epilogue launch: ") + hipGetErrorString((hipError_t)rc));
+    HIPCK(c, hipEventRecord(c->ev_hash_clean, c->side3));
+    HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
+  }
   if (leaves_first) {  // side3, behind the input sections and D.2a: D.1a as soon as phase 1 is done; ev_join3 moves behind it
     if (!c->ev_hash_recorded) HIPCK(c, hipEventRecord(c->ev_hash, s));  // (a producer without a phase-1 event: everything it enqueued)
     HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_hash, 0));
@@ -816,9 +833,16 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     if ((rc = launch_ed_tab_anchor(Q, 0, 1, kq))) return rc;
     if ((rc = launch_ed_tab_mult(Q, 0, 1, kq, xt ? c->ev_part[0] : nullptr))) return rc;
     if (!xt && (e = hipEventRecord(c->ev_part[0], kq)) != hipSuccess) return (int)e;
-    if ((size_t)c->hash_mask + 1 > KC_EPILOGUE_CLEARS_UP_TO && (e = hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, kq)) != hipSuccess) return (int)e;
-    if ((rc = launch_kc_epilogue(Q, kq))) return rc;
-    if ((e = hipEventRecord(c->ev_hash_clean, kq)) != hipSuccess) return (int)e;
+    // (the epilogue -- one 1024-thread workgroup that needs sixteen free wave slots on one CU: 50 - 65 us to get them on the busy chip -- and the
+    // clearing of the launch's hash table are needed by the NEXT launch only: run_batch enqueues them behind the input sections of side3, which then
+    // start at ~70 instead of ~160 us.  0.401 -> 0.391, 0.382 -> 0.376 ms once the step's end was the row writes: round 5, after the compaction)
+    if (K.epi_late) {
+      c->epilogue_pending = true; c->pending_q = Q;
+    } else {
+      if ((size_t)c->hash_mask + 1 > KC_EPILOGUE_CLEARS_UP_TO && (e = hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, kq)) != hipSuccess) return (int)e;
+      if ((rc = launch_kc_epilogue(Q, kq))) return rc;
+      if ((e = hipEventRecord(c->ev_hash_clean, kq)) != hipSuccess) return (int)e;
+    }
     // side2: s*B (a launch of its own above 16384 lanes), then the lanes that are not resident
     if ((e = hipStreamWaitEvent(c->side2, c->ev_fork2, 0)) != hipSuccess) return (int)e;
     if (!plan.sb_with_hash) {

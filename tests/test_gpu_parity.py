@@ -601,7 +601,9 @@ KNOBS = [
     {"TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0"}, {"TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0", "TMX_EXT_EVENTS": "0", "TMX_TINY": "0"},
     # round 5: lanes that did not sign take the context's precomputed record and the EdDSA kernels run over the dense list of the others (every
     # launch of > 2048 lanes whose chain the dedup opens: the cold calls of this test, the warm ones with TMX_HASH_FIRST=0): off; on in both schedules
-    {"TMX_COMPACT": "0"}, {"TMX_COMPACT": "0", "TMX_HASH_FIRST": "0"}, {"TMX_HASH_FIRST": "0", "TMX_PHASE1_MAX": "0"}, {"TMX_HASH_FIRST": "0", "TMX_SCHEDULE": "cold"}]
+    {"TMX_COMPACT": "0"}, {"TMX_COMPACT": "0", "TMX_HASH_FIRST": "0"}, {"TMX_HASH_FIRST": "0", "TMX_PHASE1_MAX": "0"}, {"TMX_HASH_FIRST": "0", "TMX_SCHEDULE": "cold"},
+    # the cache epilogue in front of / behind the input sections of the low-priority stream; no validator-set cache
+    {"TMX_EPI_LATE": "0", "TMX_SCHEDULE": "warm"}, {"TMX_SET_CACHE": "0"}, {"TMX_SET_CACHE": "0", "TMX_SCHEDULE": "warm", "TMX_TINY": "0"}]
 
 
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
