@@ -276,6 +276,7 @@ struct Knobs {
   bool compact = true;       // TMX_COMPACT=0: every lane through the EdDSA kernels (round 4), also the ones that did not sign
   bool set_cache = true;     // TMX_SET_CACHE=0: k_proof computes the leaves and the tree of every validator set of every proof (round 4)
   bool epi_late = true;      // TMX_EPI_LATE=0: the cache epilogue of a split warm batch in front of the input sections on side3 (the first round-5 form)
+  bool ser_lanes = true;     // TMX_SER_LANES=0: no scalar-lane path for the spans that lie inside one lane of a per-lane section (serialize_span)
   int few_wgs = 0;           // TMX_FEW_WGS=<n>: workgroups of the serializer launches beside the chain (A/B; 0: 1024, 1536 from 131072 lanes)
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
@@ -300,6 +301,7 @@ static Knobs read_knobs() {
   k.set_cache = !((v = std::getenv("TMX_SET_CACHE")) && v[0] == '0');
   k.epi_late = !((v = std::getenv("TMX_EPI_LATE")) && v[0] == '0');
   if ((v = std::getenv("TMX_FEW_WGS"))) k.few_wgs = std::atoi(v);
+  if ((v = std::getenv("TMX_SER_LANES"))) k.ser_lanes = std::atoi(v) != 0;
   return k;
 }
 
@@ -1080,8 +1082,9 @@ void release_streams(int device) {
 // such lane on them) -- are the same for every lane of every proof: computed ONCE per context, by the same kernels, on a one-lane launch over
 // an all-zero lane record (flags = 0: did not sign); the key cache is emptied again afterwards, so a context starts as it always did.
 static int32_t dummy_record(tmx_ctx* c) {
-  hipStream_t ts = nullptr;
-  HIPCK(c, hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
+  // (on the context's own side stream, idle at creation: a stream created and destroyed here would shift which hardware queues the
+  // streams of the process's NEXT context land on -- second context of a process: 0.63 instead of 0.38 ms per step, tools/churn_probe.py)
+  hipStream_t ts = c->side;
   int32_t st = TMX_OK;
   if (use_tiny(c, 1)) st = run_tiny_lanes(c, 1, c->d_dummy_in, c->d_dummy_ed, ED_STRIDE, ts);
   else if (int rc = run_eddsa(c, 1, c->d_dummy_in, c->d_dummy_ed, ED_STRIDE, ts)) st = fail(c, TMX_ERR_HIP, std::string("dummy record: ") + hipGetErrorString((hipError_t)rc));
@@ -1089,7 +1092,6 @@ static int32_t dummy_record(tmx_ctx* c) {
   if (e == hipSuccess) e = hipStreamSynchronize(c->side2);
   if (e == hipSuccess) e = hipStreamSynchronize(c->side);
   if (e == hipSuccess) e = hipStreamSynchronize(c->side3);
-  (void)hipStreamDestroy(ts);
   if (st) return st;
   if (e != hipSuccess) return fail(c, TMX_ERR_HIP, std::string("dummy record: ") + hipGetErrorString(e));
   int rc = launch_kc_reset(c->kc, c->side2);
@@ -1250,6 +1252,7 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
   if (lanes > ((size_t)1 << 30)) return fail(c, TMX_ERR_CAPACITY, "max_batch * n_max exceeds 2^30 lanes");
   for (int k = 0; k < 2; k++) {
     c->prog[k] = build_program(k, n);
+    c->prog[k].sp.lane_fast = c->knobs.ser_lanes ? 1u : 0u;
     if (c->prog[k].sp.elem_count != tmx_elem_count(k, n) || c->prog[k].d1b_start == 0xffffffffu) return fail(c, TMX_ERR_BAD_ARG, "internal: layout size mismatch");
     HIPCK(c, hipMalloc(&c->d_lut[k], c->prog[k].lut.size() * 4));
     HIPCK(c, hipMemcpyAsync(c->d_lut[k], c->prog[k].lut.data(), c->prog[k].lut.size() * 4, hipMemcpyHostToDevice, c->side2));

@@ -86,6 +86,7 @@ struct SerializeProgram {
   uint32_t elem_stride;  // row stride (even)
   uint32_t n;            // lanes per proof
   uint32_t tree_nodes;   // nodes per validator tree
+  uint32_t lane_fast;    // 1: a span that lies inside ONE lane of a per-lane section takes the scalar-lane path (serialize_span; TMX_SER_LANES=0: never)
   uint32_t span;         // elements one wave serializes (128, 256 or 512): SPAN/128 coalesced 16-byte stores per thread, all loads in flight together
 };
 struct SerializeSources {

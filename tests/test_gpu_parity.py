@@ -603,7 +603,9 @@ KNOBS = [
     # launch of > 2048 lanes whose chain the dedup opens: the cold calls of this test, the warm ones with TMX_HASH_FIRST=0): off; on in both schedules
     {"TMX_COMPACT": "0"}, {"TMX_COMPACT": "0", "TMX_HASH_FIRST": "0"}, {"TMX_HASH_FIRST": "0", "TMX_PHASE1_MAX": "0"}, {"TMX_HASH_FIRST": "0", "TMX_SCHEDULE": "cold"},
     # the cache epilogue in front of / behind the input sections of the low-priority stream; no validator-set cache
-    {"TMX_EPI_LATE": "0", "TMX_SCHEDULE": "warm"}, {"TMX_SET_CACHE": "0"}, {"TMX_SET_CACHE": "0", "TMX_SCHEDULE": "warm", "TMX_TINY": "0"}]
+    {"TMX_EPI_LATE": "0", "TMX_SCHEDULE": "warm"}, {"TMX_SET_CACHE": "0"}, {"TMX_SET_CACHE": "0", "TMX_SCHEDULE": "warm", "TMX_TINY": "0"},
+    # per-lane sections of the row span by span (k_serialize) instead of lane by lane (k_serialize_lanes, the default above 8 proofs)
+    {"TMX_SER_LANES": "0"}, {"TMX_SER_LANES": "0", "TMX_SER_SPLIT": "0"}, {"TMX_SER_SPLIT": "0"}]
 
 
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))

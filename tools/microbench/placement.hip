@@ -84,7 +84,68 @@ static void run_straight(const char* name, K kern, int n, unsigned* d, int G) {
               (double)cyc / G / 25600.0);
 }
 
+
+// (round 5) Is workgroup b of a dispatch on XCD b % 8 also when other queues are dispatching, and what do k of the 8 XCDs write?  A kernel whose
+// workgroups leave at once unless (mask >> (blockIdx.x & 7)) & 1 is then confined to those XCDs without a CU-masked stream (which would have
+// no priority and could not be the caller's stream).
+__global__ void k_xcd_check(unsigned* bad, unsigned* per_xcd) {
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 0xf;
+  if (threadIdx.x == 0) {
+    if (xcc != (blockIdx.x & 7u)) atomicAdd(bad, 1u);
+    atomicAdd(&per_xcd[(blockIdx.x & 7u) * 8 + (xcc & 7u)], 1u);  // [b % 8][XCC_ID]
+  }
+}
+__global__ __launch_bounds__(256) void k_store_xcd(uint4* out, size_t n16, unsigned mask) {
+  if (!((mask >> (blockIdx.x & 7u)) & 1u)) return;
+  const unsigned pc = __builtin_popcount(mask), rank = __builtin_popcount(mask & ((1u << (blockIdx.x & 7u)) - 1u));
+  const size_t wg = (size_t)(blockIdx.x >> 3) * pc + rank, nwg = (size_t)(gridDim.x >> 3) * pc;
+  typedef unsigned v4 __attribute__((ext_vector_type(4)));
+  v4 v = {blockIdx.x, threadIdx.x, 1u, 2u};
+  for (size_t i = wg * 256 + threadIdx.x; i < n16; i += nwg * 256) __builtin_nontemporal_store(v, reinterpret_cast<v4*>(out) + i);
+}
+static void xcd_section() {
+  unsigned *bad, *per;
+  CK(hipMalloc(&bad, 4)); CK(hipMalloc(&per, 256));
+  hipStream_t st[3];
+  for (auto& s_ : st) CK(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+  CK(hipMemset(bad, 0, 4)); CK(hipMemset(per, 0, 256));
+  CK(hipDeviceSynchronize());
+  const int grids[3] = {512, 2048, 1000};
+  for (int rep = 0; rep < 50; rep++)
+    for (int k = 0; k < 3; k++) hipLaunchKernelGGL(k_xcd_check, dim3(grids[k]), dim3(64), 0, st[k], bad, per);
+  CK(hipDeviceSynchronize());
+  unsigned hb = 0, hp[64];
+  CK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hp, per, 256, hipMemcpyDeviceToHost));
+  std::printf("XCC_ID != b %% 8 for %u of %d workgroups (three queues dispatching at once); XCC_ID values seen for b %% 8 = 0..7:", hb, 50 * (512 + 2048 + 1000));
+  for (int b = 0; b < 8; b++) {
+    std::printf(" [");
+    for (int x = 0; x < 8; x++) if (hp[b * 8 + x]) std::printf("%d:%u ", x, hp[b * 8 + x]);
+    std::printf("]");
+  }
+  std::printf("\n");
+  const size_t bytes = (size_t)1 << 30;
+  uint4* buf;
+  CK(hipMalloc(&buf, bytes));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (unsigned mask : {0xffu, 0xf0u, 0xe0u, 0xc0u, 0x80u})
+    for (int G : {2048, 8192}) {
+      hipLaunchKernelGGL(k_store_xcd, dim3(G), dim3(256), 0, 0, buf, bytes / 16, mask);
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(k_store_xcd, dim3(G), dim3(256), 0, 0, buf, bytes / 16, mask);
+      CK(hipEventRecord(e1, 0));
+      CK(hipDeviceSynchronize());
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      std::printf("1 GiB of non-temporal 16-byte stores from XCD mask 0x%02x, %4d workgroups launched: %.1f us, %.0f GB/s\n", mask, G, ms * 1e3, bytes / ms / 1e6);
+    }
+}
+
 int main() {
+  xcd_section();
   const int iters = 400;  // 25.6 k dependent instructions ~ 50 us for a lone wave
   const int shapes[][2] = {{1, 64}, {256, 64}, {512, 64}, {1024, 64}, {2048, 64}, {256, 128}, {128, 256}, {64, 512}, {512, 128}, {256, 256}, {1024, 128}, {4096, 64}, {8192, 64}, {2048, 128}};
   unsigned* d;
