@@ -192,6 +192,35 @@ def test_step_and_skip_share_the_cache(tmx, oracle):
         assert ctx.key_cache_stats()["last_hit_lanes"] == 2 * n
 
 
+@pytest.mark.parametrize("fresh_proofs", [1, 4])
+def test_a_few_proofs_bring_new_keys_into_a_warm_batch(tmx, oracle, fresh_proofs):
+    """The daily churn of a validator set: a warm batch (the warm walk split by residency: resident lanes at once, the lanes of new keys behind
+    their tables on the side streams) in which one / four proofs bring 40 keys each that the cache has not seen -- N = 64, 40 proofs, one of
+    the new-key lanes with a corrupted signature.  Bit-exact vs the oracle, the failing lane found, and the counters say the keys are
+    resident afterwards."""
+    from tendermintx_amd.synth import Workload
+    n, P = 64, 40
+    base = Workload(0, n, P, 50, chain_id=b"celestia", seed=9001, signed_permille=900)
+    fresh = Workload(0, n, fresh_proofs, 40, chain_id=b"celestia", seed=9100 + fresh_proofs, signed_permille=1000, n_sets=fresh_proofs)
+    k = fresh_proofs
+    proofs = fresh.proofs + base.proofs[k * 2336:]
+    targets = bytearray(fresh.targets + base.targets[k * n * 256:])
+    trusteds = fresh.trusteds + base.trusteds[k * n * 48:]
+    lane = next(l for l in range(n) if targets[l * 256 + 223] & 1)
+    targets[lane * 256 + 45] ^= 0x04      # a failing signature on a lane of a NEW key
+    mixed = type("W", (), {"proofs": proofs, "targets": bytes(targets), "trusteds": trusteds})
+    with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+        _check(ctx, oracle, base, n)
+        _check(ctx, oracle, base, n)          # warm: the schedule hint now says so
+        st0 = ctx.key_cache_stats()
+        _, reps = _check(ctx, oracle, mixed, n)
+        st1 = ctx.key_cache_stats()
+        assert reps[0]["first_bad_sig"] == lane and all(r["first_bad_sig"] == -1 for r in reps[1:])
+        assert st1["last_new_keys"] == 40 * fresh_proofs and st1["resident_keys"] == st0["resident_keys"] + 40 * fresh_proofs
+        _check(ctx, oracle, mixed, n)          # the same batch again: every key resident, its table built by the call above
+        assert ctx.key_cache_stats()["last_new_keys"] == 0
+
+
 @pytest.mark.gpu
 def test_validator_set_cache(tmx, oracle, monkeypatch):
     """The validator-set cache of a context (include/tmx.h tmx_set_cache_stats; layout.h SetCache): a batch of 24 proofs over three validator

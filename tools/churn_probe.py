@@ -56,10 +56,12 @@ def main():
 
             run(30)
             acc[v].setdefault("warm", []).append(timed(40))
-            for new_keys, reps in ((1, 8), (4, 8), (40, 8), (401, 6)):
+            for new_keys, reps in ((0, 8), (1, 8), (4, 8), (40, 8), (401, 6)):  # (0: the same single step behind a synchronize, no new key)
                 xs = []
                 for j in range(reps):
-                    if new_keys == 401:
+                    if new_keys == 0:
+                        bufs = None
+                    elif new_keys == 401:
                         wj = bench_workload("survey8d", n, P, seed=0x600000 + 977 * j + 13 * rnd)
                         bufs = tuple(up(b) for b in (wj.proofs, wj.targets, wj.trusteds))
                     else:

@@ -31,4 +31,12 @@ run(WARM)
 t0 = time.perf_counter()
 run(STEPS)
 print(f"profile_step: {1e3 * (time.perf_counter() - t0) / STEPS:.4f} ms/step over {STEPS} steps (+{WARM} warm), P={P} N={n} workload={WORKLOAD}")
+NEW_KEYS = int(os.environ.get("NEW_KEYS", "0"))  # then: one more step in which that many keys are new to the cache, and a plain one behind it
+if NEW_KEYS:                                      # (tools/step_timeline.py prints the step before the last: the one with the new keys)
+    from tendermintx_amd.synth import Workload
+    wj = Workload(0, n, 1, NEW_KEYS, chain_id=b"celestia", seed=0x700000 + NEW_KEYS, signed_permille=1000)
+    d1 = [torch.frombuffer(bytearray(a + b[len(a):]), dtype=torch.uint8).to(dev) for a, b in ((wj.proofs, w.proofs), (wj.targets, w.targets), (wj.trusteds, w.trusteds))]
+    ctx.witness_batch_device(KIND_SKIP, P, d1[0].data_ptr(), d1[1].data_ptr(), d1[2].data_ptr(), out.data_ptr(), rep.data_ptr(), s.cuda_stream)
+    torch.cuda.synchronize()
+    run(1)
 ctx.close()
