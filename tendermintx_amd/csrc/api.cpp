@@ -829,28 +829,18 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     if (!x && (e = hipEventRecord(c->ev_hash, s)) != hipSuccess) return (int)e;
     c->ev_hash_recorded = true;
     // Enqueue order = the order of need: a step that starts on an idle device (a single call behind a synchronize) is launched at the pace of
-    // the host, ~4 us per call, and the resident walk used to be the twelfth launch of the stage (it started at ~125 instead of ~70 us).
-    // side2: s*B (a launch of its own above 16384 lanes), then the lanes that are not resident
-    if ((e = hipStreamWaitEvent(c->side2, c->ev_fork2, 0)) != hipSuccess) return (int)e;
-    if (!plan.sb_with_hash) {
-      if ((rc = launch_ed_base(Q, c->side2, x ? c->ev_base : nullptr))) return rc;
-      if (!x && (e = hipEventRecord(c->ev_base, c->side2)) != hipSuccess) return (int)e;
-    }
+    // the host, ~4 us per call, and the resident walk used to be the twelfth launch of the stage (it started at ~125 instead of ~70 us):
+    // the head of the new-key chain (it is the longer one when there are new keys), s*B, the resident walk and finish, then the rest.
     if (hash_first) {  // the dedup beside the hash role; the walk reads the owners it writes (ev_keys: free in this schedule)
       if ((e = hipStreamWaitEvent(kq, c->ev_fork2, 0)) != hipSuccess) return (int)e;
       if ((rc = launch_ed_dedup(Q, kq, x ? c->ev_keys : nullptr))) return rc;
       if (!x && (e = hipEventRecord(c->ev_keys, kq)) != hipSuccess) return (int)e;
       if ((e = hipStreamWaitEvent(s, c->ev_keys, 0)) != hipSuccess) return (int)e;
     }
-    // s: the resident lanes
-    if ((rc = launch_ed_mul_tab(Q, 0, 1, s, 1u))) return rc;
-    if (!plan.sb_with_hash && (e = hipStreamWaitEvent(s, c->ev_base, 0)) != hipSuccess) return (int)e;
-    rc = launch_ed_fin(Q, s, false, 1u);
-    c->fin_done_attached = rc == 0 && Q.fin_done != nullptr;
-    if (rc) return rc;
     // side3: the new-key pipeline and the end of the launch's cache bookkeeping
     if (!hash_first && (e = hipStreamWaitEvent(kq, c->ev_fork2, 0)) != hipSuccess) return (int)e;
-    if ((rc = launch_ed_keys(Q, kq, nullptr))) return rc;
+    if ((rc = launch_ed_keys(Q, kq, xt ? c->ev_part[1] : nullptr))) return rc;
+    if (!xt && (e = hipEventRecord(c->ev_part[1], kq)) != hipSuccess) return (int)e;
     if ((rc = launch_ed_tab_anchor(Q, 0, 1, kq))) return rc;
     if ((rc = launch_ed_tab_mult(Q, 0, 1, kq, xt ? c->ev_part[0] : nullptr))) return rc;
     if (!xt && (e = hipEventRecord(c->ev_part[0], kq)) != hipSuccess) return (int)e;
@@ -864,10 +854,25 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
       if ((rc = launch_kc_epilogue(Q, kq))) return rc;
       if ((e = hipEventRecord(c->ev_hash_clean, kq)) != hipSuccess) return (int)e;
     }
-    if ((e = hipStreamWaitEvent(c->side2, c->ev_part[0], 0)) != hipSuccess) return (int)e;
+    // side2: s*B (a launch of its own above 16384 lanes), then the lanes that are not resident
+    if ((e = hipStreamWaitEvent(c->side2, c->ev_fork2, 0)) != hipSuccess) return (int)e;
+    if (!plan.sb_with_hash) {
+      if ((rc = launch_ed_base(Q, c->side2, x ? c->ev_base : nullptr))) return rc;
+      if (!x && (e = hipEventRecord(c->ev_base, c->side2)) != hipSuccess) return (int)e;
+    }
+    // s: the resident lanes
+    if ((rc = launch_ed_mul_tab(Q, 0, 1, s, 1u))) return rc;
+    if (!plan.sb_with_hash && (e = hipStreamWaitEvent(s, c->ev_base, 0)) != hipSuccess) return (int)e;
+    rc = launch_ed_fin(Q, s, false, 1u);
+    c->fin_done_attached = rc == 0 && Q.fin_done != nullptr;
+    if (rc) return rc;
+    // (the table-free lanes -- keys the cache has no room for: usually an empty launch -- need the decoded keys, not the tables: in front of
+    // the wait for the tables instead of 12 us between the walk and the finish of the new-key lanes)
+    if ((e = hipStreamWaitEvent(c->side2, c->ev_part[1], 0)) != hipSuccess) return (int)e;
     if ((e = hipStreamWaitEvent(c->side2, c->ev_hash, 0)) != hipSuccess) return (int)e;
-    if ((rc = launch_ed_mul_tab(Q, 0, 1, c->side2, 2u))) return rc;
     if ((rc = launch_ed_mul_direct(Q, c->side2, false, nullptr))) return rc;
+    if ((e = hipStreamWaitEvent(c->side2, c->ev_part[0], 0)) != hipSuccess) return (int)e;
+    if ((rc = launch_ed_mul_tab(Q, 0, 1, c->side2, 2u))) return rc;
     {
       EdQuad Q2 = Q;
       Q2.fin_done = nullptr;
