@@ -162,7 +162,7 @@ def main():
         ok = int(rep.cpu().numpy()[32:36].view(np.uint32)[0])
         if rank == 0:
             out_bytes = ctx.elem_stride(KIND_SKIP) * 8
-            print(json.dumps({
+            emit({
                 "metric": "skip-circuit witness-gen ms at VALIDATOR_SET_SIZE_MAX=512, one proof, validator-sharded", "value": round(ms_per_step, 5),
                 "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
                 "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
@@ -173,7 +173,7 @@ def main():
                 "all_proofs_ok": bool(ok),
                 "roofline": {"kernel": "step", "bound": "hbm", "achieved": round(gbs(out_bytes, ms_per_step), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(gbs(out_bytes, ms_per_step) / HBM_PEAK_GBS, 5), "traffic": None,
-                             "note": "a single proof is latency-bound (dependent EdDSA chain), not bandwidth-bound: DESIGN.md section 6"}}), flush=True)
+                             "note": "a single proof is latency-bound (dependent EdDSA chain), not bandwidth-bound: DESIGN.md section 6"}})
         barrier()
         ctx.close()
         if use_dist:
@@ -310,12 +310,123 @@ def main():
         if rank == 0:
             result["other_scaling"] = other
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     barrier()
     if use_dist:
         dist.destroy_process_group()
     ctx.close()
     return 0
+
+
+LINE_CAP = 6144   # bytes; the driver keeps the last 8 KB of stdout and parses the LAST line (round 5's 20.5-KB line came back `parsed: null`)
+
+
+def pick(d, *keys):
+    """Sub-dict of the keys that exist (and are not None / prose)."""
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(full):
+    """The ONE driver-facing JSON line: the contract's fields + roofline + cpu_baseline + the handful of secondary figures VERDICT r5 #1 lists,
+    numbers only (no prose), built from the full record.  Everything else lives in bench_extras.json and on an EARLIER stdout line."""
+    c = pick(full, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling")
+    c["vs_baseline"] = full.get("vs_baseline")   # null: BASELINE.md holds no published number for this metric
+    c.update(pick(full, "dtype", "data"))
+    cfg = full.get("config", {})
+    c["config"] = pick(cfg, "n_max", "proofs_total", "proofs_per_gpu", "workload_name", "parallelism")
+    c["config"]["workload"] = str(cfg.get("workload", ""))[:200]
+    c["all_proofs_ok"] = full.get("all_proofs_ok")
+    if "debug_shared_gpu" in full:
+        c["debug_shared_gpu"] = True
+    r = full.get("roofline", {})
+    rr = pick(r, "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes")
+    rr.setdefault("traffic", None)
+    if "host_clock" in r:
+        rr["host_clock"] = pick(r["host_clock"], "achieved", "frac")
+    if "traffic_detail" in r:
+        rr["traffic_split"] = pick(r["traffic_detail"], "fetch_bytes", "write_bytes")
+    if "per_kernel" in r:   # top 6 by time alone
+        rr["per_kernel"] = {k.split("<")[0] + (k[k.index("<"):] if "<" in k and k.startswith("k_ed") else ""):
+                            {"insts": v.get("valu_insts"), "alone_us": v.get("alone_us"), "issue_frac": v.get("issue_frac"), "hbm_frac": v.get("hbm_frac")}
+                            for k, v in list(r["per_kernel"].items())[:6]}
+    if "valu_issue" in r:
+        rr["valu_issue"] = {"step": r["valu_issue"].get("step")}
+    if "k_serialize" in r:
+        rr["k_serialize"] = pick(r["k_serialize"], "ms_alone", "achieved", "frac", "traffic", "algorithmic_bytes", "split_alone_us")
+    c["roofline"] = rr
+    if "kernels_ms" in full:
+        c["kernels_ms"] = full["kernels_ms"]
+    if "cpu_baseline" in full:
+        b = full["cpu_baseline"]
+        cb = pick(b, "value", "unit", "cores", "kind", "compute_only_ms")
+        cb["sample"] = str(b.get("sample", ""))[:160]
+        if "all_cores" in b:
+            cb["all_cores"] = pick(b["all_cores"], "value", "cores", "scaling_efficiency")
+        if "openssl_evp_digestverify" in b:
+            cb["openssl_us_per_verify"] = b["openssl_evp_digestverify"].get("us_per_verify")
+        c["cpu_baseline"] = cb
+    if "parity_vs_oracle" in full:
+        c["parity_vs_oracle"] = full["parity_vs_oracle"]
+    kc = full.get("key_cache", {})
+    c["key_cache"] = {"state": kc.get("state_of_the_timed_steps"), "resident_keys": kc.get("resident_keys"),
+                      "cold_ms": kc.get("cold", {}).get("ms_per_step"), "warm_ms": kc.get("warm", {}).get("ms_per_step"),
+                      "churn_ms_by_new_keys": kc.get("churn", {}).get("ms_per_step_by_new_keys")}
+    if "memoized" in full and "validator_set_cache" in full["memoized"]:
+        c["memoized"] = {"lanes_that_did_not_sign": full["memoized"].get("lanes_that_did_not_sign"), "set_cache": full["memoized"]["validator_set_cache"]}
+    if "batch_sizes_ms" in full:
+        c["batch_sizes_ms"] = full["batch_sizes_ms"]
+    if "single_proof" in full:
+        c["single_proof"] = pick(full["single_proof"], "device_ms", "device_ms_cold", "host_to_host_ms", "host_to_host_typed_value_ms")
+    if "typed_value" in full and "batch" in full["typed_value"]:
+        t = full["typed_value"]
+        c["typed_value"] = {"bytes_per_proof": t.get("bytes_per_proof", {}).get("value_hint"), "single_proof_host_to_host_ms": t.get("single_proof", {}).get("host_to_host_ms"),
+                            "batch_host_to_host_ms": t["batch"].get("host_to_host_ms_per_step"), "batch_device_ms": t["batch"].get("device_resident_ms_per_step"),
+                            "bit_exact_vs_oracle": t.get("bit_exact_vs_oracle")}
+    c.update(pick(full, "value_host_to_host_ms", "value_single_proof_host_to_host_ms"))
+    for k in ("best_case", "survey8d"):
+        if k in full:
+            c[k] = pick(full[k], "ms_per_step", "ms_per_step_cold", "all_proofs_ok")
+    l2 = full.get("level2_trace_rows", {})
+    if "roofline" in l2:
+        c["level2"] = {"ms_per_batch": l2.get("ms_per_batch"), **pick(l2["roofline"], "frac", "achieved", "algorithmic_bytes", "traffic"),
+                       "traffic_over_rows": pick(l2["roofline"].get("traffic_over_rows", {}), "raw", "fetch_x2"),
+                       "violations": l2.get("constraint_check", {}).get("violations")}
+    elif "error" in l2:
+        c["level2"] = {"error": str(l2["error"])[:120]}
+    cp = full.get("commit_pipeline", {}).get("sections")
+    if cp:
+        c["commit_pipeline"] = {k: {"ms_total": v.get("ms_total"), "lde_frac_passes": v.get("lde_stage", {}).get("frac_passes"),
+                                    "lde_frac_1r1w": v.get("lde_stage", {}).get("frac_1r1w"), "gperm_per_s": v.get("merkle_stage", {}).get("gperm_per_s")}
+                                for k, v in cp.items() if k in ("sha512", "ladders")}
+    if "rccl" in full:
+        c["rccl"] = pick(full["rccl"], "torch_world", "libtmx_comm_world", "backend")
+    if "gather_rows" in full:
+        c["gather_rows"] = pick(full["gather_rows"], "ms", "bytes_per_rank_out")
+    if "other_scaling" in full:
+        c["other_scaling"] = {k: (pick(v, "ms_per_step", "value", "proofs_total", "proofs_per_gpu", "libtmx_comm_world", "error") if isinstance(v, dict) else None)
+                              for k, v in full["other_scaling"].items() if k != "note"}
+    c["extras"] = "bench_extras.json"
+    # never over the cap: shed the secondary objects, least important first
+    for k in ("commit_pipeline", "best_case", "survey8d", "memoized", "kernels_ms", "other_scaling", "level2", "typed_value", "batch_sizes_ms", "single_proof"):
+        if len(json.dumps(c)) <= LINE_CAP:
+            break
+        c.pop(k, None)
+    return c
+
+
+def emit(full):
+    """Full record -> bench_extras.json (+ gpurun_out/) and an EARLIER stdout line; the compact record is the LAST line."""
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_extras.json"), "w") as f:
+                    json.dump(full, f, indent=1)
+        except OSError:
+            pass
+    print("# bench_extras " + json.dumps(full), flush=True)   # (prefixed: no parser can take it for the record line)
+    line = json.dumps(compact_line(full))
+    assert len(line) <= LINE_CAP, len(line)
+    print(line, flush=True)
 
 
 def both_scalings(args, strong_ctx, n, world, rank, local_rank, dev, stream, dev_bytes, barrier, max_over_ranks):
