@@ -5,6 +5,9 @@ TEST INFRASTRUCTURE.  Reads only data files of the reference (circuits/fixtures/
 known-answer tables of its in-file unit tests (transcribed below with file:line); computes expected values with the
 pure-Python model in oracle/py.  Outputs:
   tests/golden/fixtures/mocha-4/<h>/{commit.json,validators_1.json}   verbatim data files the reference's tests read
+  tests/golden/fixtures/mocha-4/<h>/signed_block.json                  verbatim, the nine heights that hold nothing else (SignedBlockResponse,
+                                                                       tendermint_utils.rs:52-55, 97-112): all 17 fixture heights are pinned
+  tests/golden/signed_blocks.json  per signed_block height: header hash, validators_hash, every signature under both verification equations
   tests/golden/cases.json        per case: packed input records (hex), Level-0 header, report, element count, sha256
   tests/golden/elems_<case>.npz  full element streams of the small cases
   tests/golden/kat.json          the five CI known-answer tables + RFC 8032 vectors + dummy-lane constants
@@ -32,12 +35,20 @@ SKIP_CASES = [  # (name, trusted, target, N, chain_id)   reference tests: skip.r
     ("skip_157001_157001_n128", 157001, 157001, 128, "mocha-4"),   # largest real validator set; fails only the distance check
     ("skip_10500_157001_n128", 10500, 157001, 128, "mocha-4"),     # real non-overlapping sets: 1/3 check fails
     ("skip_10000_10500_n4_wrongchain", 10000, 10500, 4, "celestia"),
+    # the signed_block.json heights (no reference test reads them; real mocha-4 data with MANY absent votes -- whatever verdict the model gives)
+    ("skip_11000_11105_n16", 11000, 11105, 16, "mocha-4"),         # 8 -> 9 validators, 8 of 9 signed
+    ("skip_15000_50000_n128", 15000, 50000, 128, "mocha-4"),       # 34 -> 100 validators, 47 of 100 signed: the 2/3 check fails
+    ("skip_50000_157000_n128", 50000, 157000, 128, "mocha-4"),     # 100 -> 100 validators, 53 of 100 signed
 ]
+SIGNED_BLOCK_HEIGHTS = (10002, 10003, 10004, 11000, 11001, 11105, 15000, 50000, 157000)
 STEP_CASES = [  # reference tests: step.rs:170-268
     ("step_3000_n4", 3000, 4, "mocha-4"),
     ("step_10000_n2", 10000, 2, "mocha-4"),
     ("step_10500_n4", 10500, 4, "mocha-4"),       # test_step_with_dummy: validator 2 voted nil
     ("step_10500_n100", 10500, 100, "mocha-4"),   # test_step_large shape (N = 100, not a power of two)
+    ("step_10002_n2", 10002, 2, "mocha-4"),       # signed_block.json heights: 10002 -> 10003 -> 10004, 11000 -> 11001
+    ("step_10003_n4", 10003, 4, "mocha-4"),
+    ("step_11000_n8", 11000, 8, "mocha-4"),
 ]
 FULL_ELEMS_MAX = 30000
 
@@ -54,8 +65,41 @@ def main():
         os.makedirs(dst, exist_ok=True)
         for name in ("commit.json", "validators_1.json"):
             shutil.copyfile(os.path.join(fx, str(h), name), os.path.join(dst, name))
+    for h in SIGNED_BLOCK_HEIGHTS:
+        dst = os.path.join(out, "fixtures", "mocha-4", str(h))
+        os.makedirs(dst, exist_ok=True)
+        shutil.copyfile(os.path.join(fx, str(h), "signed_block.json"), os.path.join(dst, "signed_block.json"))
     f = m.FixtureFetcher(fx)
     cases = {}
+
+    # ---- the nine signed_block.json heights as data: what each pins on its own (SURVEY headline fact 4, verified by probe in round 1, now committed)
+    sb = {}
+    for h in SIGNED_BLOCK_HEIGHTS:
+        sh, vs = f.signed_header(h), f.validators(h)
+        leaves = tm.header_leaves(sh["header"])
+        hh = tm.root_from_leaf_hashes([tm.leaf_hash(x) for x in leaves])
+        vh = tm.root_from_leaf_hashes([tm.leaf_hash(tm.validator_bytes(tm.b64(v["pub_key"]["value"]), int(v["voting_power"]))) for v in vs])
+        assert hh.hex().upper() == sh["commit"]["block_id"]["hash"] and vh.hex().upper() == sh["header"]["validators_hash"], h
+        bid = sh["commit"]["block_id"]
+        block_id = (bytes.fromhex(bid["hash"]), int(bid["parts"]["total"]), bytes.fromhex(bid["parts"]["hash"]))
+        lanes = []
+        for v, cs in zip(vs, sh["commit"]["signatures"]):
+            if cs["block_id_flag"] != 2:
+                lanes.append(None)
+                continue
+            pk, sig = tm.b64(v["pub_key"]["value"]), tm.b64(cs["signature"])
+            msg = tm.sign_bytes(sh["header"]["chain_id"], int(sh["commit"]["height"]), int(sh["commit"]["round"]), block_id, cs["timestamp"])
+            t = ed.verify_trace(pk, sig, msg)
+            mul8 = lambda pt: ed.scalarmult(8, pt)
+            cofactored = t["A"] is not None and t["s"] < ed.L and mul8(t["sB"]) == ed.add(mul8(t["R"]), mul8(t["hA"]))   # RFC 8032 5.1.7
+            lanes.append(dict(pubkey=pk.hex(), signature=sig.hex(), message=msg.hex(), h=t["h"].to_bytes(32, "little").hex(),
+                              ok_cofactorless=bool(t["ok"]), ok_rfc8032=bool(cofactored)))
+        sb[str(h)] = dict(header_hash=hh.hex(), validators_hash=vh.hex(), next_validators_hash=sh["header"]["next_validators_hash"].lower(),
+                          validators=len(vs), flags=[cs["block_id_flag"] for cs in sh["commit"]["signatures"]], lanes=lanes)
+        print("signed_block", h, len(vs), "validators,", sum(x is not None for x in lanes), "signed, all verify:",
+              all(x["ok_cofactorless"] and x["ok_rfc8032"] for x in lanes if x))
+    with open(os.path.join(out, "signed_blocks.json"), "w") as fh:
+        json.dump(sb, fh, indent=0, sort_keys=True)
 
     def finish(name, kind, n, chain_id, proof, target, trusted):
         w, rep = m.witness(kind, proof, target, trusted, chain_id.encode(), 100800)

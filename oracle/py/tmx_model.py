@@ -93,11 +93,24 @@ class FixtureFetcher:
     def __init__(self, fixture_path):
         self.fixture_path = fixture_path
 
+    def _path(self, height, name):
+        return os.path.join(self.fixture_path, str(height), name)
+
+    def signed_block(self, height):
+        """SignedBlockResponse (tendermint_utils.rs:52-55, 97-112): {header, data, commit, validator_set} of one block."""
+        with open(self._path(height, "signed_block.json")) as f:
+            return json.load(f)["result"]
+
     def signed_header(self, height):
-        with open(os.path.join(self.fixture_path, str(height), "commit.json")) as f:
+        if not os.path.exists(self._path(height, "commit.json")):
+            sb = self.signed_block(height)
+            return {"header": sb["header"], "commit": sb["commit"]}
+        with open(self._path(height, "commit.json")) as f:
             return json.load(f)["result"]["signed_header"]
 
     def validators(self, height):
+        if not os.path.exists(self._path(height, "validators_1.json")):
+            return self.signed_block(height)["validator_set"]["validators"]
         out, page, so_far = [], 1, 0
         while True:
             with open(os.path.join(self.fixture_path, str(height), f"validators_{page}.json")) as f:

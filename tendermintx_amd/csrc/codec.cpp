@@ -314,6 +314,10 @@ int32_t parse_validators(const char* json, std::vector<Validator>& out, std::vec
     keep.push_back(root);
     const JVal* res = root->get("result");
     const JVal* vals = res ? res->get("validators") : nullptr;
+    if (!vals && res) {  // SignedBlockResponse (tendermint_utils.rs:52-55, 97-112): result.validator_set.validators
+      const JVal* vs = res->get("validator_set");
+      vals = vs ? vs->get("validators") : nullptr;
+    }
     if (!vals || vals->kind != JVal::Arr) return TMX_ERR_PARSE;
     for (auto& v : vals->a) {
       Validator x;
@@ -340,6 +344,9 @@ int32_t parse_commit(const char* json, SignedHeader& sh, std::vector<JPtr>& keep
   keep.push_back(root);
   const JVal* res = root->get("result");
   const JVal* s = res ? res->get("signed_header") : nullptr;
+  // CommitResponse {result: {signed_header: {header, commit}}} (tendermint_utils.rs:58-66) or SignedBlockResponse {result: {header,
+  // data, commit, validator_set}} (:52-55, 97-112; the signed_block.json fixtures): the same header + commit either way
+  if (!s && res && res->get("header") && res->get("commit")) s = res;
   if (!s) return TMX_ERR_PARSE;
   sh.header = s->get("header");
   const JVal* c = s->get("commit");
@@ -554,6 +561,7 @@ int32_t tmx_skipcheck_inputs_from_json(const char* start_validators_json, const 
   if (!P.ok) return TMX_ERR_PARSE;
   const JVal* res = root->get("result");
   const JVal* sh = res ? res->get("signed_header") : nullptr;
+  if (!sh && res && res->get("commit")) sh = res;  // SignedBlockResponse
   const JVal* cm = sh ? sh->get("commit") : nullptr;
   const JVal* sg = cm ? cm->get("signatures") : nullptr;
   if (!sg || sg->kind != JVal::Arr) return TMX_ERR_PARSE;

@@ -65,7 +65,10 @@ def test_codec_skip_equals_python_codec(built_lib, cases):
     f, pf = InputDataFetcher(FX), m.FixtureFetcher(FX)
     for name, a, b, n in [("skip_3000_3100_n4", 3000, 3100, 4), ("skip_10000_10500_n4", 10000, 10500, 4),
                           ("skip_10000_10500_n32", 10000, 10500, 32), ("skip_157001_157001_n128", 157001, 157001, 128),
-                          ("skip_10500_157001_n128", 10500, 157001, 128)]:
+                          ("skip_10500_157001_n128", 10500, 157001, 128),
+                          # heights served from signed_block.json (SignedBlockResponse): the same codec entry points
+                          ("skip_11000_11105_n16", 11000, 11105, 16), ("skip_15000_50000_n128", 15000, 50000, 128),
+                          ("skip_50000_157000_n128", 50000, 157000, 128)]:
         pr, tg, tr = m.skip_inputs_from_fixtures(pf, a, b, n)
         p2, t2, r2 = f.get_skip_inputs(n, a, m.unpack_proof(pr)["hash"], b)
         assert p2 == pr and t2 == b"".join(tg) and r2 == b"".join(tr), name
@@ -76,7 +79,8 @@ def test_codec_skip_equals_python_codec(built_lib, cases):
 def test_codec_step_equals_python_codec(built_lib, cases):
     from tendermintx_amd.circuits import InputDataFetcher
     f, pf = InputDataFetcher(FX), m.FixtureFetcher(FX)
-    for name, prev, n in [("step_3000_n4", 3000, 4), ("step_10000_n2", 10000, 2), ("step_10500_n4", 10500, 4), ("step_10500_n100", 10500, 100)]:
+    for name, prev, n in [("step_3000_n4", 3000, 4), ("step_10000_n2", 10000, 2), ("step_10500_n4", 10500, 4), ("step_10500_n100", 10500, 100),
+                          ("step_10002_n2", 10002, 2), ("step_10003_n4", 10003, 4), ("step_11000_n8", 11000, 8)]:
         pr, tg = m.step_inputs_from_fixtures(pf, prev, n)
         p2, t2 = f.get_step_inputs(n, prev, m.unpack_proof(pr)["hash"])
         assert p2 == pr and t2 == b"".join(tg), name

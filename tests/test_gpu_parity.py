@@ -3,6 +3,7 @@
 through size-independent properties.  Written to read like the reference's own tests (circuits/skip.rs:157-296,
 circuits/step.rs:141-268): same fixtures, same public inputs, same names."""
 import hashlib
+import json
 import os
 import struct
 
@@ -137,6 +138,38 @@ def test_step_large(tmx):
     """step.rs:256-267: N = 100 (the reference's VALIDATOR_SET_SIZE_MAX, not a power of two)"""
     _step_template(tmx, 100, 10500, "E2BA1B86926925A69C2FCC32E5178E7E6653D386C956BB975142FA73211A9444",
                    "CD3E0F3E47FDAC9ABE1C98CF6BE241BC23A8779E67DF068832F7F43E2DB7B05B")
+
+
+def test_signed_block_heights_through_the_hint(tmx, oracle, cases):
+    """The nine fixture heights that hold only `signed_block.json` (SignedBlockResponse, tendermint_utils.rs:52-55, 97-112), end to end:
+    fetcher -> the library's JSON codec -> HIP path, chained the way a light client advances: step 10002 -> 10003 -> 10004 with each
+    output header fed in as the next trusted hash, step 11000 -> 11001, skip 11000 -> 11105 / 15000 -> 50000 / 50000 -> 157000 (47- and
+    53-of-100 signing: real data with many absent votes).  Headers = the fixtures' block_id.hash; verdicts and rows = the goldens'."""
+    sb = json.load(open(os.path.join(GOLDEN, "signed_blocks.json")))
+    f = tmx.InputDataFetcher(FX)
+    h = bytes.fromhex(sb["10002"]["header_hash"])
+    for prev, n in ((10002, 2), (10003, 4)):
+        circ = tmx.StepCircuit(n, tmx.MOCHA_4_CHAIN_ID_BYTES, fetcher=f)
+        elems, rep = circ.hint(prev, h)
+        c = cases[f"step_{prev}_n{n}"]
+        assert rep["all_ok"] and rep["header"].hex() == sb[str(prev + 1)]["header_hash"] == c["header"]
+        assert hashlib.sha256(np.ascontiguousarray(elems).tobytes()).hexdigest() == c["elems_sha256"]
+        h = rep["header"]
+        circ.close()
+    circ = tmx.StepCircuit(8, tmx.MOCHA_4_CHAIN_ID_BYTES, fetcher=f)
+    _, rep = circ.hint(11000, bytes.fromhex(sb["11000"]["header_hash"]))
+    assert rep["all_ok"] and rep["header"].hex() == sb["11001"]["header_hash"]
+    circ.close()
+    for a, b, n in ((11000, 11105, 16), (15000, 50000, 128), (50000, 157000, 128)):
+        c = cases[f"skip_{a}_{b}_n{n}"]
+        circ = tmx.SkipCircuit(n, tmx.MOCHA_4_CHAIN_ID_BYTES, tmx.SKIP_MAX, fetcher=f)
+        proof, target, trusted = f.get_skip_inputs(n, a, bytes.fromhex(sb[str(a)]["header_hash"]), b)
+        assert proof.hex() == c["proof"] and target.hex() == c["target"] and trusted.hex() == c["trusted"]
+        elems, reps = circ.ctx.witness_batch(0, proof, target, trusted)
+        assert reps[0]["header"].hex() == sb[str(b)]["header_hash"] == c["header"]
+        assert reps[0]["all_ok"] == c["all_ok"] and reps[0]["fail_mask"] == c["fail_mask"] and reps[0]["gt_target"] == c["gt_target"]
+        assert hashlib.sha256(np.ascontiguousarray(elems[0]).tobytes()).hexdigest() == c["elems_sha256"]
+        circ.close()
 
 
 def test_step_wrong_prev_hash_panics(tmx):

@@ -1,6 +1,7 @@
 """Pins the oracle (oracle/c plain-C restatement and oracle/py big-int model) against every known answer the
 reference's own tests hold for this path, RFC 8032, hashlib, and the committed goldens.  CPU only."""
 import hashlib
+import json
 import os
 
 import numpy as np
@@ -145,6 +146,36 @@ def test_oracle_reproduces_goldens(oracle, cases):
         assert int(w.max()) < 2**32  # every element is a canonical Goldilocks value
 
 
+def test_signed_block_fixtures_pin_the_oracle(oracle):
+    """The nine fixture heights of the reference that hold only `signed_block.json` (SignedBlockResponse, tendermint_utils.rs:52-55, 97-112;
+    mocha-4 10002-10004, 11000, 11001, 11105, 15000, 50000, 157000: 2 / 8 / 9 / 34 / 100 validators, 21-of-34 and 47-of-100 signing -- the only
+    real data with many absent votes): header tree root = commit.block_id.hash, validator tree root = header.validators_hash, and every
+    flag-2 signature verifies under the cofactor-less equation the circuit checks AND under RFC 8032's -- by the C oracle, from the
+    committed data alone (tests/golden/signed_blocks.json holds what oracle/gen_golden.py derived with the big-int model)."""
+    sb = json.load(open(os.path.join(GOLDEN, "signed_blocks.json")))
+    f = m.FixtureFetcher(os.path.join(GOLDEN, "fixtures", "mocha-4"))
+    assert sorted(map(int, sb)) == [10002, 10003, 10004, 11000, 11001, 11105, 15000, 50000, 157000]
+    n_sigs = 0
+    for h, g in sb.items():
+        sh, vs = f.signed_header(int(h)), f.validators(int(h))
+        leaf_hashes = [oracle.sha256(b"\x00" + x) for x in tm.header_leaves(sh["header"])]
+        assert oracle.rfc6962_root(leaf_hashes).hex() == g["header_hash"] == sh["commit"]["block_id"]["hash"].lower(), h
+        vleaves = []
+        for v in vs:   # marshal_tendermint_validator (validator.rs:185-207): 46 bytes, the first validator_byte_length of them hashed (:209-229)
+            pk, power = tm.b64(v["pub_key"]["value"]), int(v["voting_power"])
+            vleaves.append(oracle.sha256(b"\x00" + oracle.marshal_validator(pk, power)[:len(tm.validator_bytes(pk, power))]))
+        assert oracle.rfc6962_root(vleaves).hex() == g["validators_hash"] == sh["header"]["validators_hash"].lower(), h
+        assert oracle.fixed_shape_tree(vleaves + [bytes(32)] * (128 - len(vs)), len(vs))[1].hex() == g["validators_hash"], h
+        assert [cs["block_id_flag"] for cs in sh["commit"]["signatures"]] == g["flags"] and len(vs) == g["validators"]
+        for lane in g["lanes"]:
+            if lane is None:
+                continue
+            t = oracle.eddsa_trace(bytes.fromhex(lane["pubkey"]), bytes.fromhex(lane["signature"]), bytes.fromhex(lane["message"]))
+            assert t["ok"] and lane["ok_cofactorless"] and lane["ok_rfc8032"] and t["h"].hex() == lane["h"], h
+            n_sigs += 1
+    assert n_sigs == 2 + 2 + 2 + 8 + 8 + 8 + 21 + 47 + 53
+
+
 def test_public_io_level0(cases, kat):
     """Level-0 outputs implied by the reference's end-to-end tests (skip.rs:197-199, 259-262; step.rs:178-180, 237-253)"""
     skip = {(3000, 3100): "skip_3000_3100_n4", (10000, 10500): "skip_10000_10500_n4"}
@@ -163,7 +194,7 @@ def test_public_io_level0(cases, kat):
 
 
 def test_model_equals_c_on_small_cases(oracle, cases):
-    for name in ("skip_10000_10500_n4", "step_10500_n4", "skip_10000_10500_n4_wrongchain"):
+    for name in ("skip_10000_10500_n4", "step_10500_n4", "skip_10000_10500_n4_wrongchain", "step_10002_n2", "step_11000_n8", "skip_11000_11105_n16"):
         c = cases[name]
         n = c["n"]
         proof, target = bytes.fromhex(c["proof"]), bytes.fromhex(c["target"])
