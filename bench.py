@@ -97,6 +97,9 @@ def main():
     # multi-rank control flow (sharding of the proofs, barrier, max over ranks, one JSON line) can be exercised without a second GPU.
     # The numbers of such a run mean nothing (the ranks share one device) and the line says so.
     share_gpu = os.environ.get("TMX_BENCH_SHARE_GPU") == "1"
+    # ... together with TMX_RCCL_LIB=<tests/fake_rccl>: libtmx's own communicator is made at world > 1 too (real RCCL refuses two ranks on one
+    # device), so that the strong-scaling / row-exchange / --mode c5 code of this file runs before a real node runs it (tests/test_world2_one_gpu.py)
+    share_gpu_comm = share_gpu and bool(os.environ.get("TMX_RCCL_LIB"))
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -171,6 +174,7 @@ def main():
                            "n_max": n, "parallelism": f"validator-sharded x{world}"},
                 "rccl": {"torch_world": world, "libtmx_comm_world": comm_world, "entry_point": "tmx_witness_validator_sharded_device"},
                 "all_proofs_ok": bool(ok),
+                **({"debug_shared_gpu": "TMX_BENCH_SHARE_GPU=1: every rank ran on cuda:0 (control-flow test, timings meaningless)"} if share_gpu else {}),
                 "roofline": {"kernel": "step", "bound": "hbm", "achieved": round(gbs(out_bytes, ms_per_step), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(gbs(out_bytes, ms_per_step) / HBM_PEAK_GBS, 5), "traffic": None,
                              "note": "a single proof is latency-bound (dependent EdDSA chain), not bandwidth-bound: DESIGN.md section 6"}})
@@ -199,7 +203,7 @@ def main():
     d_out = torch.empty((rows_buf, stride), dtype=torch.int64, device=dev)
     d_rep = torch.zeros(rows_buf * 64, dtype=torch.uint8, device=dev)
     gather = args.gather and world > 1
-    comm_world = sharding.connect(ctx)[1] if (use_dist and not share_gpu) else 1
+    comm_world = sharding.connect(ctx)[1] if (use_dist and (not share_gpu or share_gpu_comm)) else 1
 
     def run(c, k, bufs=None, n_proofs=None):
         dp, dt, dr = bufs or (d_proofs, d_targets, d_trusteds)
@@ -305,7 +309,7 @@ def main():
             extras(args, result, roofline, ctx, run, wl_all, n, P, stride, count, dev, stream, d_out, d_rep, dev_bytes, kms, ms_per_step, alg_bytes)
     # ---- more than one GPU: the OTHER scaling of the same record (a SCALE run of the default command then carries both the weak-scaled value
     # and BASELINE configs[3] as written: 256 proofs sharded over the ranks, without and with the row exchange)
-    if world > 1 and not args.no_extras and not share_gpu:
+    if world > 1 and not args.no_extras and (not share_gpu or share_gpu_comm):
         other = both_scalings(args, ctx if args.scaling == "strong" else None, n, world, rank, local_rank, dev, stream, dev_bytes, barrier, max_over_ranks)
         if rank == 0:
             result["other_scaling"] = other

@@ -363,13 +363,27 @@ int32_t tmx_last_dedup(tmx_ctx* ctx, uint32_t* n_unique, uint32_t* used_tables);
  *   tmx_witness_validator_sharded_device  BASELINE configs[4]: the n_proofs * n_max validator lanes split across the ranks for the EdDSA stage,
  *                                         ONE grouped exchange of the 448-byte lane records, then every rank finishes every proof
  *                                         (tmx_finish_batch_device on the reassembled records): full rows + reports on every rank.
- * Both are asynchronous on hip_stream like tmx_witness_batch_device; n_total / the lanes may be smaller than the world (empty shards). */
+ * Both are asynchronous on hip_stream like tmx_witness_batch_device; n_total / the lanes may be smaller than the world (empty shards).
+ *
+ * FAILURE CONTRACT of the sharded calls (round 6).  A collective is entered by every rank or by none.  Argument errors (TMX_ERR_BAD_ARG) are
+ * assumed to be the same on every rank and are returned before anything is enqueued.  A failure that is LOCAL to one rank between the start of
+ * a sharded call and its exchange -- its shard exceeds ITS context's max_batch, a launch fails on ITS device -- must not leave the peers waiting
+ * in the collective: the failing rank aborts its communicator (ncclCommAbort) and returns TMX_ERR_RCCL (tmx_last_error names the local cause);
+ * the peers' exchange then fails instead of hanging -- at the collective call itself, or asynchronously: a host that needs a bounded wait
+ * synchronises with tmx_comm_sync(ctx, stream, timeout_ms) instead of hipStreamSynchronize; it polls the stream and ncclCommGetAsyncError, and on
+ * an asynchronous error or the timeout aborts this rank's communicator too and returns TMX_ERR_RCCL.  After TMX_ERR_RCCL from any sharded call
+ * or from tmx_comm_sync the context refuses further sharded calls (TMX_ERR_RCCL) until tmx_comm_create is called again -- on EVERY rank, with
+ * a fresh id; the non-sharded entry points and the caches of the context are unaffected.  The buffers of a failed call hold nothing defined.
+ *   tmx_comm_abort   what a host calls on its healthy contexts when IT learns (by its own channel) that a peer process died
+ *   tmx_comm_sync    timeout_ms = 0: no timeout (asynchronous errors still end the wait) */
 #define TMX_UNIQUE_ID_BYTES 128
 void tmx_shard_range(uint64_t n_items, uint32_t rank, uint32_t world, uint64_t* lo, uint64_t* hi);
 int32_t tmx_comm_unique_id(uint8_t out[TMX_UNIQUE_ID_BYTES]);
 int32_t tmx_comm_create(tmx_ctx* ctx, const uint8_t unique_id[TMX_UNIQUE_ID_BYTES] /* NULL iff world == 1 */, uint32_t rank, uint32_t world);
 int32_t tmx_comm_destroy(tmx_ctx* ctx);
 int32_t tmx_comm_info(const tmx_ctx* ctx, uint32_t* rank, uint32_t* world);  /* (0, 1) before tmx_comm_create */
+int32_t tmx_comm_abort(tmx_ctx* ctx);
+int32_t tmx_comm_sync(tmx_ctx* ctx, void* hip_stream, uint32_t timeout_ms);
 int32_t tmx_witness_batch_sharded_device(tmx_ctx* ctx, int32_t kind, uint32_t n_total, const void* d_proofs, const void* d_targets,
                                          const void* d_trusteds, void* d_out_elems, void* d_reports, uint32_t gather, void* hip_stream);
 int32_t tmx_witness_validator_sharded_device(tmx_ctx* ctx, int32_t kind, uint32_t n_proofs, const void* d_proofs, const void* d_targets,
@@ -414,10 +428,13 @@ int32_t tmx_key_cache_config(tmx_ctx* ctx, uint32_t enabled, uint32_t max_keys);
  * (reference circuits/builder/validator.rs:185-252) depend on the validator set alone -- (pubkey, voting power, validator_byte_length) of every lane and
  * the number of enabled lanes -- not on the proof, and a light client re-verifies the same slowly changing sets.  A batch's k_proof looks both
  * sets of a proof up by a 64-bit fingerprint, compares EVERY key byte, and copies the cached values instead of hashing (15 SHA-256
- * compressions off its chain); sets it had to compute are inserted (256 sets per context; a full cache stops inserting; tmx_key_cache_flush
- * empties it too; TMX_SET_CACHE=0 disables).  Bit-identical by construction.  out: [0] sets resident [1] sets served from the cache
- * [2] sets computed [3] sets inserted (totals since creation / the last flush). */
-int32_t tmx_set_cache_stats(tmx_ctx* ctx, uint32_t out[4]);
+ * compressions off its chain); sets it had to compute are inserted.  256 sets per context, least-recently-used eviction at launch granularity
+ * (round 6): a hit or an insert stamps the set with the launch's number, and the last workgroup of a launch keeps an eighth of the slots free by
+ * evicting the sets used longest ago -- a prover that lives for months (reference bin/tendermintx.rs:171) keeps the sets it is verifying now, not
+ * the first 256 it ever saw.  tmx_key_cache_flush empties it too; TMX_SET_CACHE=0 disables; TMX_SET_CACHE_SETS=<4..256> = capacity (tests).
+ * Bit-identical by construction.  out: [0] sets resident [1] sets served from the cache [2] sets computed [3] sets inserted [4] sets evicted
+ * (totals since creation / the last flush) [5] capacity [6..7] reserved (0). */
+int32_t tmx_set_cache_stats(tmx_ctx* ctx, uint32_t out[8]);
 
 /* ---- Level-2 trace rows (SURVEY 8a "Level-2", 8f rank 2): the row-level execution trace behind the Level-1 values -- what the reference
  * produces inside Curta's trace generators for `curta_eddsa_verify_sigs_conditional` (reference circuits/builder/verify.rs:248-259) and

@@ -32,22 +32,23 @@ class InputDataFetcher:
         with open(os.path.join(self.fixture_path, str(height), name), "rb") as f:
             return f.read()
 
-    def _has(self, height, name):
-        return os.path.exists(os.path.join(self.fixture_path, str(height), name))
-
     def get_signed_header_json(self, block_number):
-        if not self._has(block_number, "commit.json") and self._has(block_number, "signed_block.json"):
+        try:
+            return self._read(block_number, "commit.json")
+        except FileNotFoundError:   # a height that holds only the SignedBlockResponse
             return self._read(block_number, "signed_block.json")
-        return self._read(block_number, "commit.json")
 
     def get_validator_set_json(self, block_number):
         """All pages back to back (mod.rs:219-241 pages until count >= total)."""
         import json
-        if not self._has(block_number, "validators_1.json") and self._has(block_number, "signed_block.json"):
-            return self._read(block_number, "signed_block.json")
         pages, page, so_far = [], 1, 0
         while True:
-            raw = self._read(block_number, f"validators_{page}.json")
+            try:
+                raw = self._read(block_number, f"validators_{page}.json")
+            except FileNotFoundError:
+                if page != 1:
+                    raise
+                return self._read(block_number, "signed_block.json")
             r = json.loads(raw)["result"]
             pages.append(raw)
             so_far += int(r["count"])

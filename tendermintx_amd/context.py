@@ -263,6 +263,13 @@ class Context:
     def comm_destroy(self):
         check(self._L.tmx_comm_destroy(self._h), self._h)
 
+    def comm_abort(self):
+        check(self._L.tmx_comm_abort(self._h), self._h)
+
+    def comm_sync(self, stream=None, timeout_ms=0):
+        """Bounded wait for `stream` after a sharded call: TmxError(-7) if a peer aborted / died or the timeout passed (include/tmx.h FAILURE CONTRACT)."""
+        check(self._L.tmx_comm_sync(self._h, self._stream(stream), int(timeout_ms)), self._h)
+
     def comm_info(self):
         r, w = C.c_uint32(), C.c_uint32()
         check(self._L.tmx_comm_info(self._h, C.byref(r), C.byref(w)), self._h)
@@ -312,10 +319,10 @@ class Context:
         return info.as_dict()
 
     def set_cache_stats(self):
-        """The validator-set cache (tmx_set_cache_stats): sets resident / served from the cache / computed / inserted."""
-        out = (C.c_uint32 * 4)()
+        """The validator-set cache (tmx_set_cache_stats): sets resident / served from the cache / computed / inserted / evicted (LRU), capacity."""
+        out = (C.c_uint32 * 8)()
         check(self._L.tmx_set_cache_stats(self._h, out), self._h)
-        return dict(zip(("resident", "served", "computed", "inserted"), (int(x) for x in out)))
+        return dict(zip(("resident", "served", "computed", "inserted", "evicted", "capacity"), (int(x) for x in out)))
 
     def key_cache_flush(self):
         check(self._L.tmx_key_cache_flush(self._h), self._h)

@@ -7,11 +7,13 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -352,6 +354,7 @@ struct tmx_ctx {
   void *d_live = nullptr, *d_dummy_ed = nullptr, *d_dummy_in = nullptr;
   bool dummy_ready = false;
   SetCache setc = {};   // the validator-set cache (layout.h); table == nullptr: off (TMX_SET_CACHE=0)
+  uint32_t setc_epoch = 1;  // LRU stamp of the next k_proof launch (never 0: a slot's 0 means free)
   void *d_hash = nullptr, *d_cnt = nullptr, *d_owner_of = nullptr, *d_slot_of_owner = nullptr, *d_slot_of_uid = nullptr, *d_owners = nullptr,
        *d_keyrec = nullptr, *d_anchors = nullptr, *d_keytab = nullptr;
   KeyCache kc = {};
@@ -364,6 +367,7 @@ struct tmx_ctx {
   size_t commit_bytes = 0;
   hipEvent_t ev_commit[4] = {};
   void* comm = nullptr;        // ncclComm_t of this context's device (tmx_comm_create), or null
+  bool comm_aborted = false;   // a local failure (or a peer's) in front of a collective aborted the communicator: tmx_comm_create again
   uint32_t comm_rank = 0, comm_world = 1;
   void* d_tiny = nullptr;      // counters of the small-launch path (kernels.h: tiny_counter_words), zero between launches
   void* d_shadow = nullptr;    // key bytes + flags of the lanes of a small launch (TINY_MAX_LANES records): what its key pipeline reads
@@ -416,6 +420,7 @@ static ProofParams proof_params(const tmx_ctx* c, int32_t kind, bool leaves_done
   P.leaves_done = leaves_done ? 1u : 0u;
   P.kind = (uint32_t)kind; P.n = c->cfg.n_max; P.tree_nodes = tree_nodes(c->cfg.n_max); P.chain_id_len = c->cfg.chain_id_len;
   P.skip_max = c->cfg.skip_max;
+  P.setc_epoch = c->setc_epoch;
   std::memcpy(P.chain_id, c->cfg.chain_id, sizeof P.chain_id);
   return P;
 }
@@ -504,6 +509,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // vs 0.41 ms) and k_proof is hidden behind it anyway (32 / 64 proofs: +-1 %)
   const uint64_t lanes_all = (uint64_t)n_proofs * n;
   const bool roles = K.proof_roles && c->d_tiny && (lanes_all <= 2048 || (!eddsa_writes_rows && lanes_all <= 16384));
+  if (!roles && c->setc.table && ++c->setc_epoch == 0) c->setc_epoch = 1;  // (ages are differences mod 2^32: a wrap is harmless)
   rc = roles
            ? launch_proof_roles(proof_params(c, kind, leaves_first), n_proofs, d_proofs, d_targets, d_trusteds, tl + TL_OFF_LT, TL_STRIDE, c->d_lr, c->d_pf,
                                 c->d_nodes_t, c->d_nodes_r, reports, c->d_tiny, c->side, xp ? evs[0] : nullptr, xp ? evs[1] : nullptr)
@@ -551,15 +557,20 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   c->plan.valid = false;
   c->fin_done = nullptr;
   c->row = RowOut{};
-  if (st) { c->epilogue_pending = false; return st; }
-  if (defer3 && (st0 = side3_inputs())) return st0;
-  if (c->epilogue_pending) {
+  // the late epilogue (TMX_EPI_LATE): owed to the NEXT launch once the producer has enqueued the dedup -- on the error paths too, or that launch
+  // would probe a dirty hash table behind an event that was never re-recorded
+  auto late_epilogue = [&]() -> int32_t {
+    if (!c->epilogue_pending) return TMX_OK;
     c->epilogue_pending = false;
     if ((size_t)c->hash_mask + 1 > KC_EPILOGUE_CLEARS_UP_TO) HIPCK(c, hipMemsetAsync(c->d_hash, 0xff, ((size_t)c->hash_mask + 1) * 4, c->side3));
     if ((rc = launch_kc_epilogue(c->pending_q, c->side3))) return fail(c, TMX_ERR_HIP, std::string("k_kc_epilogue launch: ") + hipGetErrorString((hipError_t)rc));
     HIPCK(c, hipEventRecord(c->ev_hash_clean, c->side3));
     HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
-  }
+    return TMX_OK;
+  };
+  if (st) { (void)late_epilogue(); return st; }
+  if (defer3 && (st0 = side3_inputs())) { (void)late_epilogue(); return st0; }
+  if ((st0 = late_epilogue())) return st0;
   if (leaves_first) {  // side3, behind the input sections and D.2a: D.1a as soon as phase 1 is done; ev_join3 moves behind it
     if (!c->ev_hash_recorded) HIPCK(c, hipEventRecord(c->ev_hash, s));  // (a producer without a phase-1 event: everything it enqueued)
     HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_hash, 0));
@@ -799,8 +810,8 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   // (the launch's hash table was cleared, and the cache committed, on side2 by the previous launch.  Skipping this wait when s has
   // already waited for side2's tail was measured: k_proof 0.45 -> 0.52 ms beside it and the step +2 % at 256 proofs -- the packet stays.)
   // Hash first (warm schedule, not tiny): SHA-512 mod l reads the lane records only, so it opens the chain on s while the dedup (cache
-  // probe) and the key pipeline run on side2 -- the walk waits for side2's ev_part[0] either way.  s then carries no wait for
-  // ev_hash_clean either (side2 is in order behind its own tail of the previous launch).
+  // probe) and the key pipeline run on a side stream -- the walk waits for its ev_part[0] either way.  s then carries no wait for
+  // ev_hash_clean; the side stream that runs the dedup does (the previous launch's tail may have run on the other one).
   const bool hash_first = plan.hash_first;
   // Events that mark the end of one kernel ride on its dispatch (completion signal) instead of a record packet behind it: on the
   // chain every packet is latency.  `x` = that is on and the kernel really is launched.
@@ -833,6 +844,10 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     // the head of the new-key chain (it is the longer one when there are new keys), s*B, the resident walk and finish, then the rest.
     if (hash_first) {  // the dedup beside the hash role; the walk reads the owners it writes (ev_keys: free in this schedule)
       if ((e = hipStreamWaitEvent(kq, c->ev_fork2, 0)) != hipSuccess) return (int)e;
+      // The previous launch's key-pipeline tail (hash table cleared, cache committed) may sit on ANOTHER stream than kq: a tiny call, a cold
+      // or a non-split launch leave it on side2.  Without this wait the dedup raced it on d_hash / owner_of / the cache.
+      // A no-op packet when the tail was on kq itself (split launch after split launch: the usual case).
+      if ((e = hipStreamWaitEvent(kq, c->ev_hash_clean, 0)) != hipSuccess) return (int)e;
       if ((rc = launch_ed_dedup(Q, kq, x ? c->ev_keys : nullptr))) return rc;
       if (!x && (e = hipEventRecord(c->ev_keys, kq)) != hipSuccess) return (int)e;
       if ((e = hipStreamWaitEvent(s, c->ev_keys, 0)) != hipSuccess) return (int)e;
@@ -888,6 +903,8 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
     if (!x && (e = hipEventRecord(c->ev_hash, s)) != hipSuccess) return (int)e;
     c->ev_hash_recorded = true;
     if ((e = hipStreamWaitEvent(c->side2, c->ev_fork2, 0)) != hipSuccess) return (int)e;
+    // (the previous launch's tail is on side3 when that launch took the split schedule: side2's own order does not cover it)
+    if ((e = hipStreamWaitEvent(c->side2, c->ev_hash_clean, 0)) != hipSuccess) return (int)e;
     rc = launch_ed_dedup(Q, c->side2, nullptr);
     if (rc) return rc;
   } else {
@@ -1304,12 +1321,16 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     HIPCK(c, hipMalloc(&c->d_live, lanes * 4));
     if (c->knobs.set_cache) {  // 256 validator sets (20 KB each at N = 128, 82 KB at N = 512), a table of 1024 entries
       SetCache& sc = c->setc;
-      sc.cap = 256; sc.tab_mask = 1023; sc.slot_bytes = (setcache_slot_bytes(n, tree_nodes(n)) + 63u) & ~63u;
+      // (TMX_SET_CACHE_SETS: a smaller cache for the eviction tests; the table keeps four entries per slot)
+      const char* v = std::getenv("TMX_SET_CACHE_SETS");
+      const long want = v ? std::atol(v) : 0;
+      sc.cap = want >= 4 && want <= (long)SETC_MAX_SLOTS ? (uint32_t)want : SETC_MAX_SLOTS;
+      sc.tab_mask = 1023; sc.slot_bytes = (setcache_slot_bytes(n, tree_nodes(n)) + 63u) & ~63u;
       HIPCK(c, hipMalloc(reinterpret_cast<void**>(&sc.table), (sc.tab_mask + 1) * 4));
-      HIPCK(c, hipMalloc(reinterpret_cast<void**>(&sc.state), 32));
+      HIPCK(c, hipMalloc(reinterpret_cast<void**>(&sc.state), (SETC_STATE_WORDS + SETC_MAX_SLOTS) * 4));
       HIPCK(c, hipMalloc(reinterpret_cast<void**>(&sc.slots), (size_t)sc.cap * sc.slot_bytes));
       HIPCK(c, hipMemsetAsync(sc.table, 0, (sc.tab_mask + 1) * 4, c->side2));
-      HIPCK(c, hipMemsetAsync(sc.state, 0, 32, c->side2));
+      HIPCK(c, hipMemsetAsync(sc.state, 0, (SETC_STATE_WORDS + SETC_MAX_SLOTS) * 4, c->side2));
     }
     HIPCK(c, hipMalloc(&c->d_dummy_ed, 512));
     HIPCK(c, hipMalloc(&c->d_dummy_in, VR_STRIDE));
@@ -1400,21 +1421,24 @@ int32_t tmx_key_cache_flush(tmx_ctx* c) {
   if (rc) return fail(c, TMX_ERR_HIP, std::string("k_kc_reset launch: ") + hipGetErrorString((hipError_t)rc));
   if (c->setc.table) {  // (the validator-set cache goes with it: "flush" = a context as new)
     HIPCK(c, hipMemsetAsync(c->setc.table, 0, (c->setc.tab_mask + 1) * 4, c->side2));
-    HIPCK(c, hipMemsetAsync(c->setc.state, 0, 32, c->side2));
+    HIPCK(c, hipMemsetAsync(c->setc.state, 0, (SETC_STATE_WORDS + SETC_MAX_SLOTS) * 4, c->side2));
   }
   HIPCK(c, hipStreamSynchronize(c->side2));
   c->h_hint[0] = 0; c->h_hint[1] = 0;  // an empty cache: the next enqueue takes the cold schedule, as the first call of a context does
   return TMX_OK;
 }
 
-int32_t tmx_set_cache_stats(tmx_ctx* c, uint32_t out[4]) {
+int32_t tmx_set_cache_stats(tmx_ctx* c, uint32_t out[8]) {
   if (!c || !out) return TMX_ERR_BAD_ARG;
-  out[0] = out[1] = out[2] = out[3] = 0;
+  std::memset(out, 0, 8 * sizeof(uint32_t));
   if (!c->setc.table) return TMX_OK;
   int32_t q = quiesce(c);
   if (q) return q;
-  HIPCK(c, hipMemcpy(out, c->setc.state, 16, hipMemcpyDeviceToHost));
-  if (out[0] > c->setc.cap) out[0] = c->setc.cap;
+  uint32_t st[SETC_STATE_WORDS];
+  HIPCK(c, hipMemcpy(st, c->setc.state, sizeof st, hipMemcpyDeviceToHost));
+  const uint32_t hi = st[0] > c->setc.cap ? c->setc.cap : st[0], fr = (int32_t)st[4] > 0 ? st[4] : 0u;
+  out[0] = hi - (fr > hi ? hi : fr);  // resident = slots ever used - slots on the free list
+  out[1] = st[1]; out[2] = st[2]; out[3] = st[3]; out[4] = st[6]; out[5] = c->setc.cap;
   return TMX_OK;
 }
 
@@ -2361,6 +2385,8 @@ struct Rccl {
   int (*GetUniqueId)(RcclId*) = nullptr;
   int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommAbort)(void*) = nullptr;               // optional (every NCCL >= 2.4 / RCCL has both): without them an abort is a destroy
+  int (*CommGetAsyncError)(void*, int*) = nullptr;
   int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
@@ -2409,6 +2435,8 @@ std::string rccl_load() {
   T.GetUniqueId = reinterpret_cast<decltype(T.GetUniqueId)>(sym("ncclGetUniqueId"));
   T.CommInitRank = reinterpret_cast<decltype(T.CommInitRank)>(sym("ncclCommInitRank"));
   T.CommDestroy = reinterpret_cast<decltype(T.CommDestroy)>(sym("ncclCommDestroy"));
+  T.CommAbort = reinterpret_cast<decltype(T.CommAbort)>(sym("ncclCommAbort"));
+  T.CommGetAsyncError = reinterpret_cast<decltype(T.CommGetAsyncError)>(sym("ncclCommGetAsyncError"));
   T.Broadcast = reinterpret_cast<decltype(T.Broadcast)>(sym("ncclBroadcast"));
   T.AllGather = reinterpret_cast<decltype(T.AllGather)>(sym("ncclAllGather"));
   T.GroupStart = reinterpret_cast<decltype(T.GroupStart)>(sym("ncclGroupStart"));
@@ -2426,6 +2454,33 @@ std::string rccl_load() {
 int32_t rccl_fail(tmx_ctx* c, const char* what, int rc) {
   return fail(c, TMX_ERR_RCCL, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
 }
+// A collective is entered by every rank or by none.  A rank that fails LOCALLY between the start of a sharded call and its exchange (its shard
+// exceeds its context's max_batch, a launch fails) would leave the others waiting in the collective for ever: it aborts the communicator
+// instead (ncclCommAbort: its peers' pending operations fail), and so does a rank whose collective reports an error.  Either way the call
+// returns TMX_ERR_RCCL, the context refuses further sharded calls, and every rank makes a new communicator (tmx_comm_create).
+void comm_abort(tmx_ctx* c) {
+  if (!c->comm) return;
+  if (c->have_streams) (void)hipSetDevice(c->cfg.device);
+  if (g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm);
+  else if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  c->comm = nullptr;
+  c->comm_aborted = true;
+}
+int32_t shard_fail(tmx_ctx* c, int32_t st) {
+  if (st == TMX_OK || !c->comm) return st;
+  const std::string local = c->err;
+  comm_abort(c);
+  return fail(c, TMX_ERR_RCCL, "local failure in front of a collective (" + std::string(tmx_status_str(st)) + (local.empty() ? "" : ": " + local) +
+                                   "): communicator aborted so that no peer waits for this rank; tmx_comm_create again on every rank");
+}
+int32_t comm_usable(tmx_ctx* c) {
+  return c->comm_aborted ? fail(c, TMX_ERR_RCCL, "the communicator of this context was aborted: tmx_comm_create again on every rank") : TMX_OK;
+}
+int32_t rccl_fail_abort(tmx_ctx* c, const char* what, int rc) {
+  const int32_t st = rccl_fail(c, what, rc);
+  comm_abort(c);
+  return st;
+}
 constexpr int RCCL_UINT8 = 1;  // ncclUint8
 // every rank's slice [lo_r, hi_r) of `n_items` records of `rec_bytes` becomes resident on every rank: one exchange, in place.
 // Equal slices (n_items a multiple of the world: 256 proofs or 512 lanes over 2 / 4 / 8 ranks, BASELINE configs[3] / [4]) are ONE
@@ -2438,21 +2493,21 @@ int32_t exchange_slices(tmx_ctx* c, void* d_buf, uint64_t n_items, size_t rec_by
     const size_t per = (size_t)(n_items / c->comm_world) * rec_bytes;
     uint8_t* base = reinterpret_cast<uint8_t*>(d_buf);
     rc = g_rccl.AllGather(base + (size_t)c->comm_rank * per, base, per, RCCL_UINT8, c->comm, s);
-    if (rc) return rccl_fail(c, "ncclAllGather", rc);
+    if (rc) return rccl_fail_abort(c, "ncclAllGather", rc);
     return TMX_OK;
   }
   rc = g_rccl.GroupStart();
-  if (rc) return rccl_fail(c, "ncclGroupStart", rc);
+  if (rc) return rccl_fail_abort(c, "ncclGroupStart", rc);
   for (uint32_t r = 0; r < c->comm_world; r++) {
     uint64_t lo, hi;
     tmx_shard_range(n_items, r, c->comm_world, &lo, &hi);
     if (hi == lo) continue;
     uint8_t* p = reinterpret_cast<uint8_t*>(d_buf) + lo * rec_bytes;
     rc = g_rccl.Broadcast(p, p, (size_t)(hi - lo) * rec_bytes, RCCL_UINT8, (int)r, c->comm, s);
-    if (rc) { (void)g_rccl.GroupEnd(); return rccl_fail(c, "ncclBroadcast", rc); }
+    if (rc) { (void)g_rccl.GroupEnd(); return rccl_fail_abort(c, "ncclBroadcast", rc); }
   }
   rc = g_rccl.GroupEnd();
-  if (rc) return rccl_fail(c, "ncclGroupEnd", rc);
+  if (rc) return rccl_fail_abort(c, "ncclGroupEnd", rc);
   return TMX_OK;
 }
 }  // namespace
@@ -2486,6 +2541,7 @@ int32_t tmx_comm_create(tmx_ctx* c, const uint8_t* unique_id, uint32_t rank, uin
   if (unique_id && c->cfg.device < 0) return TMX_ERR_BAD_ARG;
   int32_t st = tmx_comm_destroy(c);
   if (st) return st;
+  c->comm_aborted = false;
   if (world == 1 && !unique_id) { c->comm_rank = 0; c->comm_world = 1; return TMX_OK; }  // nothing to exchange, nothing to load
   // (world == 1 WITH an id makes a real one-rank communicator: the exchange then runs through RCCL -- a broadcast to itself -- which is
   // how the 1-GPU boxes exercise this path)
@@ -2500,6 +2556,7 @@ int32_t tmx_comm_create(tmx_ctx* c, const uint8_t* unique_id, uint32_t rank, uin
   const int rc = g_rccl.CommInitRank(&comm, (int)world, id, (int)rank);
   if (rc) return rccl_fail(c, "ncclCommInitRank", rc);
   c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+  c->comm_aborted = false;
   return TMX_OK;
 }
 
@@ -2522,6 +2579,39 @@ int32_t tmx_comm_info(const tmx_ctx* c, uint32_t* rank, uint32_t* world) {
   return TMX_OK;
 }
 
+int32_t tmx_comm_abort(tmx_ctx* c) {
+  if (!c) return TMX_ERR_BAD_ARG;
+  comm_abort(c);
+  return TMX_OK;
+}
+
+int32_t tmx_comm_sync(tmx_ctx* c, void* hip_stream, uint32_t timeout_ms) {
+  if (!c) return TMX_ERR_BAD_ARG;
+  if (c->comm_aborted) return comm_usable(c);
+  HIPCK(c, hipSetDevice(c->cfg.device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spin = 0;; spin++) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return TMX_OK;
+    if (q != hipErrorNotReady) { (void)hipGetLastError(); comm_abort(c); return fail(c, TMX_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q)); }
+    (void)hipGetLastError();
+    if (c->comm && g_rccl.CommGetAsyncError && (spin & 15) == 0) {
+      int async_rc = 0;
+      const int rc = g_rccl.CommGetAsyncError(c->comm, &async_rc);
+      if (rc || async_rc) return rccl_fail_abort(c, "asynchronous error of the communicator (a peer aborted or died)", rc ? rc : async_rc);
+    }
+    if (timeout_ms) {
+      const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (ms >= (long long)timeout_ms) {
+        comm_abort(c);
+        return fail(c, TMX_ERR_RCCL, "tmx_comm_sync: the stream did not drain within " + std::to_string(timeout_ms) + " ms: communicator aborted");
+      }
+    }
+    if (spin > 200) std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
 int32_t tmx_witness_batch_sharded_device(tmx_ctx* c, int32_t kind, uint32_t n_total, const void* d_proofs, const void* d_targets,
                                          const void* d_trusteds, void* d_out_elems, void* d_reports, uint32_t gather, void* hip_stream) {
   int32_t st = check_batch_args(c, kind, 0, d_proofs, d_targets, d_trusteds);
@@ -2531,7 +2621,9 @@ int32_t tmx_witness_batch_sharded_device(tmx_ctx* c, int32_t kind, uint32_t n_to
   if (gather && (c->comm || c->comm_world > 1) && (!d_out_elems || !d_reports)) return fail(c, TMX_ERR_BAD_ARG, "gather needs the row and report buffers");
   uint64_t lo, hi;
   tmx_shard_range(n_total, c->comm_rank, c->comm_world, &lo, &hi);
-  if (hi - lo > c->cfg.max_batch) return fail(c, TMX_ERR_CAPACITY, "this rank's shard exceeds the context's max_batch");
+  if (gather && (st = comm_usable(c))) return st;
+  // (from here on a failure is LOCAL -- this rank's shard, this rank's context -- while the peers go on to the exchange: shard_fail)
+  if (hi - lo > c->cfg.max_batch) { st = fail(c, TMX_ERR_CAPACITY, "this rank's shard exceeds the context's max_batch"); return gather ? shard_fail(c, st) : st; }
   const uint32_t n = c->cfg.n_max;
   const size_t row_bytes = (size_t)tmx_elem_stride(kind, n) * 8;
   auto at = [](const void* p, size_t off) { return p ? reinterpret_cast<const uint8_t*>(p) + off : nullptr; };
@@ -2539,7 +2631,7 @@ int32_t tmx_witness_batch_sharded_device(tmx_ctx* c, int32_t kind, uint32_t n_to
     st = tmx_witness_batch_device(c, kind, (uint32_t)(hi - lo), at(d_proofs, lo * PR_STRIDE), at(d_targets, lo * n * VR_STRIDE),
                                   at(d_trusteds, lo * n * HR_STRIDE), const_cast<uint8_t*>(at(d_out_elems, lo * row_bytes)),
                                   const_cast<uint8_t*>(at(d_reports, lo * sizeof(tmx_report))), hip_stream);
-    if (st) return st;
+    if (st) return gather ? shard_fail(c, st) : st;
   }
   if (!gather) return TMX_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
@@ -2552,13 +2644,14 @@ int32_t tmx_witness_validator_sharded_device(tmx_ctx* c, int32_t kind, uint32_t 
   int32_t st = check_batch_args(c, kind, n_proofs, d_proofs, d_targets, d_trusteds);
   if (st) return st;
   if (n_proofs == 0) return TMX_OK;
+  if ((st = comm_usable(c))) return st;
   const uint64_t lanes = (uint64_t)n_proofs * c->cfg.n_max;
   uint64_t lo, hi;
   tmx_shard_range(lanes, c->comm_rank, c->comm_world, &lo, &hi);
   uint8_t* ed = reinterpret_cast<uint8_t*>(c->d_ed);
   if (hi > lo) {
     st = tmx_eddsa_lanes_device(c, (uint32_t)(hi - lo), reinterpret_cast<const uint8_t*>(d_targets) + lo * VR_STRIDE, ed + lo * ED_STRIDE, hip_stream);
-    if (st) return st;
+    if (st) return shard_fail(c, st);
   }
   if ((st = exchange_slices(c, ed, lanes, ED_STRIDE, reinterpret_cast<hipStream_t>(hip_stream)))) return st;
   return tmx_finish_batch_device(c, kind, n_proofs, d_proofs, d_targets, d_trusteds, ed, d_out_elems, d_reports, hip_stream);
@@ -2575,10 +2668,11 @@ int32_t tmx_trace_rows_sharded_device(tmx_ctx* c, int32_t kind, uint32_t n_total
   const uint32_t n = c->cfg.n_max;
   const size_t row_bytes = (size_t)trace_elems((uint32_t)kind, n) * 8;
   auto at = [](const void* p, size_t off) { return p ? reinterpret_cast<const uint8_t*>(p) + off : nullptr; };
+  if (gather) { const int32_t su = comm_usable(c); if (su) return su; }
   if (hi > lo) {  // the Level-1 records this reads are those of the rank's own shard: tmx_witness_batch_sharded_device of the same n_total came first
     int32_t st = tmx_trace_rows_device(c, kind, (uint32_t)(hi - lo), at(d_targets, lo * n * VR_STRIDE), at(d_trusteds, lo * n * HR_STRIDE),
                                        const_cast<uint8_t*>(at(d_trace_out, lo * row_bytes)), sections, hip_stream);
-    if (st) return st;
+    if (st) return gather ? shard_fail(c, st) : st;
   }
   if (!gather) return TMX_OK;
   return exchange_slices(c, d_trace_out, n_total, row_bytes, reinterpret_cast<hipStream_t>(hip_stream));
@@ -2593,8 +2687,11 @@ int32_t tmx_trace_rows_validator_sharded_device(tmx_ctx* c, int32_t kind, uint32
   uint64_t lo, hi;
   tmx_shard_range(lanes, c->comm_rank, c->comm_world, &lo, &hi);
   // the per-lane sections (ladders: 266 KB per lane, SHA-512: 23 KB) for this rank's lanes; the small per-proof sections on every rank
-  int32_t st = trace_rows_impl(c, kind, n_proofs, d_targets, d_trusteds, d_trace_out, sections, hip_stream, (uint32_t)lo, (uint32_t)(hi - lo));
-  if (st || !c->comm) return st;
+  int32_t st = comm_usable(c);
+  if (st) return st;
+  st = trace_rows_impl(c, kind, n_proofs, d_targets, d_trusteds, d_trace_out, sections, hip_stream, (uint32_t)lo, (uint32_t)(hi - lo));
+  if (st) return shard_fail(c, st);
+  if (!c->comm) return st;
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
   uint8_t* out = reinterpret_cast<uint8_t*>(d_trace_out);
   const size_t row_bytes = (size_t)trace_elems((uint32_t)kind, n) * 8;
@@ -2609,7 +2706,7 @@ int32_t tmx_trace_rows_validator_sharded_device(tmx_ctx* c, int32_t kind, uint32
     }
     // several proofs: a rank's lanes are one run per proof it touches; every run is broadcast by its owner, grouped
     int rc = g_rccl.GroupStart(), in_group = 0;
-    if (rc) return rccl_fail(c, "ncclGroupStart", rc);
+    if (rc) return rccl_fail_abort(c, "ncclGroupStart", rc);
     for (uint32_t r = 0; r < c->comm_world; r++) {
       uint64_t rlo, rhi;
       tmx_shard_range(lanes, r, c->comm_world, &rlo, &rhi);
@@ -2618,15 +2715,15 @@ int32_t tmx_trace_rows_validator_sharded_device(tmx_ctx* c, int32_t kind, uint32
         if (b <= a) continue;
         uint8_t* ptr = out + p * row_bytes + sc.off + (a - p * n) * sc.per_lane;
         rc = g_rccl.Broadcast(ptr, ptr, (size_t)(b - a) * sc.per_lane, RCCL_UINT8, (int)r, c->comm, s);
-        if (rc) { (void)g_rccl.GroupEnd(); return rccl_fail(c, "ncclBroadcast", rc); }
+        if (rc) { (void)g_rccl.GroupEnd(); return rccl_fail_abort(c, "ncclBroadcast", rc); }
         if (++in_group == 32) {  // (bounded groups: a group is one fused launch, and a thousand-entry group helps nobody)
-          if ((rc = g_rccl.GroupEnd())) return rccl_fail(c, "ncclGroupEnd", rc);
-          if ((rc = g_rccl.GroupStart())) return rccl_fail(c, "ncclGroupStart", rc);
+          if ((rc = g_rccl.GroupEnd())) return rccl_fail_abort(c, "ncclGroupEnd", rc);
+          if ((rc = g_rccl.GroupStart())) return rccl_fail_abort(c, "ncclGroupStart", rc);
           in_group = 0;
         }
       }
     }
-    if ((rc = g_rccl.GroupEnd())) return rccl_fail(c, "ncclGroupEnd", rc);
+    if ((rc = g_rccl.GroupEnd())) return rccl_fail_abort(c, "ncclGroupEnd", rc);
   }
   return TMX_OK;
 }
@@ -2708,9 +2805,11 @@ int32_t tmx_trace_commit_sharded_device(tmx_ctx* c, int32_t kind, uint32_t n_tot
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
   uint64_t* mine = d_caps + (size_t)c->comm_rank * (cap_bytes / 8);
   if (hi > lo) {
-    int32_t st = tmx_trace_commit_device(c, kind, (uint32_t)(hi - lo), section, log_blowup, cap_height, reinterpret_cast<const uint8_t*>(d_trace_rows) + lo * row_bytes,
-                                         mine, hip_stream);
+    int32_t st = comm_usable(c);
     if (st) return st;
+    st = tmx_trace_commit_device(c, kind, (uint32_t)(hi - lo), section, log_blowup, cap_height, reinterpret_cast<const uint8_t*>(d_trace_rows) + lo * row_bytes,
+                                 mine, hip_stream);
+    if (st) return shard_fail(c, st);
   } else {
     HIPCK(c, hipMemsetAsync(mine, 0, cap_bytes, s));  // an empty shard commits to nothing: a zero cap
   }

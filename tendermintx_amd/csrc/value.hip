@@ -38,8 +38,9 @@ namespace {
 __device__ __forceinline__ uint4 ld16(const uint8_t* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ uint32_t ld4(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
 
-__global__ __launch_bounds__(256) void k_pack_value(const ValueLayout L, const ValueSources S, const uint16_t* __restrict__ fixed_lut, uint8_t* __restrict__ out) {
-  const uint32_t proof = blockIdx.y;
+__global__ __launch_bounds__(256) void k_pack_value(const ValueLayout L, const ValueSources S, const uint16_t* __restrict__ fixed_lut, uint8_t* __restrict__ out,
+                                                    const uint32_t proof0) {
+  const uint32_t proof = proof0 + blockIdx.y;
   const uint32_t byte = (blockIdx.x * 256u + threadIdx.x) * 16u;
   if (byte >= L.off[VP_COUNT]) return;
   uint32_t part = 0;
@@ -136,9 +137,15 @@ __global__ __launch_bounds__(256) void k_pack_value(const ValueLayout L, const V
 int launch_pack_value(const ValueLayout& L, const ValueSources& src, const void* d_fixed_lut, uint32_t n_proofs, void* d_out, void* stream) {
   if (n_proofs == 0) return 0;
   const uint32_t chunks = L.off[VP_COUNT] / 16;
-  hipLaunchKernelGGL(k_pack_value, dim3((chunks + 255) / 256, n_proofs), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), L, src,
-                     reinterpret_cast<const uint16_t*>(d_fixed_lut), reinterpret_cast<uint8_t*>(d_out));
-  return (int)hipGetLastError();
+  // (grid.y holds at most 65535: a context with a small n_max can have a larger max_batch -- chunked over proofs like k_serialize)
+  for (uint32_t proof0 = 0; proof0 < n_proofs; proof0 += 65535u) {
+    const uint32_t np = n_proofs - proof0 < 65535u ? n_proofs - proof0 : 65535u;
+    hipLaunchKernelGGL(k_pack_value, dim3((chunks + 255) / 256, np), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), L, src,
+                       reinterpret_cast<const uint16_t*>(d_fixed_lut), reinterpret_cast<uint8_t*>(d_out), proof0);
+    const int e = (int)hipGetLastError();
+    if (e) return e;
+  }
+  return 0;
 }
 
 }  // namespace tmx

@@ -5,7 +5,7 @@
  * ncclBroadcast for ragged ones; the shard arithmetic; the in-place slices) would first execute on somebody's 8-GPU node.
  *
  * Selected with TMX_RCCL_LIB=<this .so> (libtmx binds RCCL with dlopen; an explicit TMX_RCCL_LIB wins over a librccl the process has
- * already loaded).  It implements exactly the eight symbols libtmx binds, with NCCL's signatures and semantics as far as libtmx uses
+ * already loaded).  It implements exactly the ten symbols libtmx binds (ncclCommAbort / ncclCommGetAsyncError since round 6), with NCCL's signatures and semantics as far as libtmx uses
  * them: byte counts, in-place operation, group calls executed at ncclGroupEnd in issue order.  Data moves through a file-backed shared
  * mapping (the "wire"): the owner of a slice copies it device -> wire, everybody meets at a barrier in the mapping, the others copy
  * wire -> device.  Every call is synchronous with respect to the host (it synchronises the stream it was given first), which is a legal
@@ -154,6 +154,19 @@ int ncclCommDestroy(ncclComm_t c) {
   if (c->rank == 0) unlink(c->path);   /* the mapping stays valid for the ranks that still hold it */
   munmap(c->sh, sizeof(shared_t) + WIRE_BYTES);
   free(c);
+  return 0;
+}
+
+/* ncclCommAbort: this rank leaves for good; every barrier of the communicator fails from now on (what a peer of an aborted NCCL
+ * communicator sees as ncclRemoteError / ncclSystemError).  ncclCommGetAsyncError: that same flag, without entering a collective. */
+int ncclCommAbort(ncclComm_t c) {
+  if (!c) return 4;
+  atomic_store(&c->sh->failed, 1);
+  return ncclCommDestroy(c);
+}
+int ncclCommGetAsyncError(ncclComm_t c, int* async_error) {
+  if (!c || !async_error) return 4;
+  *async_error = atomic_load(&c->sh->failed) ? 6 : 0;
   return 0;
 }
 

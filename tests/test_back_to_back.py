@@ -49,3 +49,63 @@ def test_back_to_back_calls_give_the_bits_of_a_call_alone(built_lib, P, n, round
             for j, vi in enumerate(order):
                 assert torch.equal(outs[j][1], want[vi][1]), f"reports of call {j} of round {it} (variant {vi}, order {order})"
                 assert torch.equal(outs[j][0], want[vi][0]), f"rows of call {j} of round {it} (variant {vi}, order {order})"
+
+
+@pytest.mark.parametrize("n", [128, 64])
+def test_mixed_sizes_back_to_back(built_lib, n):
+    """The transitions that CHANGE which side stream owns the key pipeline's tail, without a synchronize between the calls: a tiny
+    call (<= 512 lanes: tail on side2) -> a split hash-first batch (dedup on side3) -> a large split batch (dedup on s, tail on side3) -> a tiny
+    call again -> a non-batch eddsa_lanes call, with and without new keys and with cache flushes (cold schedule: tail on side2).  One context,
+    one stream, max_batch = the largest; every call's rows and reports equal the same call made alone behind a synchronize."""
+    import numpy as np
+    import torch
+    from tendermintx_amd import Context, KIND_SKIP
+    from tendermintx_amd.synth import Workload, bench_workload
+    dev = torch.device("cuda:0")
+    up = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    sizes = [1, 2, 24, 256, 3, 40, 130]
+    Pmax = max(sizes)
+    base = bench_workload("survey8d", n, Pmax, seed=77 + n)
+    fresh = [Workload(0, n, 3, min(n, 90), chain_id=b"celestia", seed=8100 + 17 * k + n, signed_permille=950, n_sets=3) for k in range(2)]
+
+    def variant(P, f):   # the first P proofs of the base batch; f: proofs over validator sets the cache has not seen in front (new keys)
+        pr, tg, tr = base.proofs[:2336 * P], base.targets[:256 * n * P], base.trusteds[:48 * n * P]
+        if f is not None:
+            k = min(3, P)
+            pr, tg, tr = f.proofs[:2336 * k] + pr[2336 * k:], f.targets[:256 * n * k] + tg[256 * n * k:], f.trusteds[:48 * n * k] + tr[48 * n * k:]
+        return tuple(up(b) for b in (pr, tg, tr))
+
+    calls = [(P, variant(P, f)) for P in sizes for f in (None, fresh[0], fresh[1])]
+    st = torch.cuda.Stream(dev)
+    with Context(n, b"celestia", 100800, device=0, max_batch=Pmax) as ctx:
+        stride = ctx.elem_stride(KIND_SKIP)
+
+        def buffers(P):
+            o, r = torch.empty(P * stride, dtype=torch.int64, device=dev), torch.zeros(P * 64, dtype=torch.uint8, device=dev)
+            return o, r
+
+        def call(P, v, o, r):
+            ctx.witness_batch_device(KIND_SKIP, P, v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), o.data_ptr(), r.data_ptr(), st.cuda_stream)
+
+        want = []
+        for P, v in calls:
+            o, r = buffers(P)
+            torch.cuda.synchronize(dev)
+            call(P, v, o, r)
+            torch.cuda.synchronize(dev)
+            want.append((o, r))
+        rng = np.random.default_rng(5 + n)
+        for it in range(40):
+            seq = [int(x) for x in rng.integers(0, len(calls), 6)]
+            if it % 4 == 0:   # the transitions named above, in order: tiny -> hash-first split -> large split -> tiny -> hash-first split
+                seq = [sizes.index(1) * 3, sizes.index(24) * 3 + (it // 4) % 3, sizes.index(256) * 3, sizes.index(2) * 3 + 1, sizes.index(40) * 3, sizes.index(130) * 3 + 2]
+            outs = [buffers(calls[i][0]) for i in seq]
+            torch.cuda.synchronize(dev)
+            if it % 5 == 2:
+                ctx.key_cache_flush()
+            for i, (o, r) in zip(seq, outs):
+                call(calls[i][0], calls[i][1], o, r)
+            torch.cuda.synchronize(dev)
+            for j, (i, (o, r)) in enumerate(zip(seq, outs)):
+                assert torch.equal(r, want[i][1]), f"reports of call {j} of round {it} (sizes {[calls[k][0] for k in seq]})"
+                assert torch.equal(o, want[i][0]), f"rows of call {j} of round {it} (sizes {[calls[k][0] for k in seq]})"

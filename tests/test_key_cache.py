@@ -248,8 +248,56 @@ def test_validator_set_cache(tmx, oracle, monkeypatch):
         want3, _ = oracle.witness_batch(0, P, wl.proofs, bytes(t2), wl.trusteds, n, b"celestia", 100800, n_threads=8)
         assert np.array_equal(e3, want3)
         ctx.key_cache_flush()
-        assert ctx.set_cache_stats() == {"resident": 0, "served": 0, "computed": 0, "inserted": 0}
+        assert ctx.set_cache_stats() == {"resident": 0, "served": 0, "computed": 0, "inserted": 0, "evicted": 0, "capacity": 256}
     monkeypatch.setenv("TMX_SET_CACHE", "0")
     with tmx.Context(n, b"celestia", max_batch=P) as ctx:
         e4, _ = ctx.witness_batch(0, wl.proofs, wl.targets, wl.trusteds)
         assert ctx.set_cache_stats()["computed"] == 0 and np.array_equal(e4, want)
+
+
+@pytest.mark.gpu
+def test_validator_set_cache_evicts_least_recently_used(tmx, oracle, monkeypatch):
+    """A prover process lives for months (reference bin/tendermintx.rs:171) and sees more than 256 validator sets: the set cache evicts the
+    least recently used ones at launch granularity (layout.h SetCache; the last workgroup of a k_proof launch keeps an eighth of the slots
+    free).  300 distinct target sets go through the 256-slot cache in twelve batches of 25 proofs (a set = the base set with one voting
+    power changed: every byte of a set is its key); then the LAST 200 are served from the cache -- nothing recomputed --, the oldest are
+    gone, and every row of every call equals the oracle's.  A 16-slot cache (TMX_SET_CACHE_SETS) thrashes and still gives the same bits."""
+    from tendermintx_amd.synth import Workload
+    n, P, B = 128, 25, 12
+    wl = Workload(0, n, P, 100, chain_id=b"celestia", seed=9100, signed_permille=900, n_sets=1)
+
+    def batch(j):   # proof q of batch j: its own target set (one power word differs in lane q)
+        t = bytearray(wl.targets)
+        for q in range(P):
+            off = (q * n + q) * 256 + 224
+            t[off:off + 4] = (int.from_bytes(t[off:off + 4], "little") ^ (1 + j * P + q)).to_bytes(4, "little")
+        return bytes(t)
+
+    targets = [batch(j) for j in range(B)]
+    want = [oracle.witness_batch(0, P, wl.proofs, t, wl.trusteds, n, b"celestia", 100800, n_threads=8)[0] for t in targets]
+    for sets, expect_all_served in ((None, True), ("16", False)):
+        if sets:
+            monkeypatch.setenv("TMX_SET_CACHE_SETS", sets)
+        with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+            cap = ctx.set_cache_stats()["capacity"]
+            assert cap == (int(sets) if sets else 256)
+            for j in range(B):
+                e, _ = ctx.witness_batch(0, wl.proofs, targets[j], wl.trusteds)
+                assert np.array_equal(e, want[j]), (sets, j)
+            s = ctx.set_cache_stats()
+            assert s["computed"] >= B * P and s["evicted"] > 0 and s["resident"] == s["inserted"] - s["evicted"] <= cap - cap // 8
+            if expect_all_served:
+                assert s["inserted"] == B * P + 1          # 300 target sets + the one trusted set: nothing was refused for want of room
+            for j in range(B - 8, B):                      # the last 200 sets again
+                before = ctx.set_cache_stats()
+                e, _ = ctx.witness_batch(0, wl.proofs, targets[j], wl.trusteds)
+                assert np.array_equal(e, want[j]), (sets, "again", j)
+                after = ctx.set_cache_stats()
+                if expect_all_served:
+                    assert after["computed"] == before["computed"] and after["served"] == before["served"] + 2 * P, j
+                    assert after["evicted"] == before["evicted"] and after["resident"] == before["resident"]
+            if expect_all_served:                          # the oldest sets are gone: batch 0 is recomputed (and inserted again)
+                before = ctx.set_cache_stats()
+                e, _ = ctx.witness_batch(0, wl.proofs, targets[0], wl.trusteds)
+                after = ctx.set_cache_stats()
+                assert np.array_equal(e, want[0]) and after["computed"] == before["computed"] + P

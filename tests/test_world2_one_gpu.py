@@ -29,7 +29,8 @@ def fake_rccl(tmp_path_factory):
 def test_fake_rccl_builds_and_exports_what_libtmx_binds(fake_rccl):
     """(CPU) the stand-in has exactly the symbols rccl_load (api.cpp) resolves"""
     syms = subprocess.check_output(["nm", "-D", "--defined-only", fake_rccl]).decode()
-    for s in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclBroadcast", "ncclAllGather", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
+    for s in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclBroadcast", "ncclAllGather", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString",
+              "ncclCommAbort", "ncclCommGetAsyncError"):
         assert f" T {s}" in syms, s
 
 
@@ -52,16 +53,14 @@ def test_unloadable_rccl_is_an_error_not_a_crash(built_lib):
     assert st == "-7" and "librccl not loadable" in msg and "/nonexistent/librccl.so" in msg
 
 
-@pytest.mark.gpu
-def test_sharded_entry_points_at_world_2_on_one_gpu(built_lib, oracle, fake_rccl, tmp_path):
+def _run_ranks(worker, fake_rccl, tmp_path, world=2, timeout=900):
     env = dict(os.environ, TMX_RCCL_LIB=fake_rccl, FAKE_RCCL_DIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    world = 2
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "rank_worker.py"), str(r), str(world), str(tmp_path)], env=env,
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, worker), str(r), str(world), str(tmp_path)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
         try:
-            outs.append(p.communicate(timeout=900)[0])
+            outs.append(p.communicate(timeout=timeout)[0])
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -73,5 +72,59 @@ def test_sharded_entry_points_at_world_2_on_one_gpu(built_lib, oracle, fake_rccl
     for r, res in enumerate(results):
         assert res.startswith("ok"), f"rank {r}:\n{res}\n--- output ---\n{outs[r][-3000:]}"
         print(f"rank {r}: " + " | ".join(res.split("\n")[1:]))
+    return results
+
+
+@pytest.mark.gpu
+def test_a_local_failure_aborts_the_collective_instead_of_deadlocking(built_lib, oracle, fake_rccl, tmp_path):
+    """include/tmx.h "FAILURE CONTRACT" (VERDICT r5 weak #11): rank 1 is handed a shard that exceeds ITS context's max_batch in front of a
+    gathered exchange; it aborts its communicator and returns TMX_ERR_RCCL, rank 0 -- already in the collective -- returns TMX_ERR_RCCL within
+    the timeout instead of waiting for ever, the contexts refuse sharded calls until tmx_comm_create runs again, and then a batch that fits is
+    sharded, gathered and bit-exact on both ranks (tests/fake_rccl/abort_worker.py)."""
+    _run_ranks("abort_worker.py", fake_rccl, tmp_path, timeout=300)
+
+
+@pytest.mark.gpu
+def test_sharded_entry_points_at_world_2_on_one_gpu(built_lib, oracle, fake_rccl, tmp_path):
+    world = 2
+    results = _run_ranks("rank_worker.py", fake_rccl, tmp_path, world)
     # both ranks went through the same sequence
     assert results[0].split("\n")[1:] != [] and len(results[0].split("\n")) == len(results[1].split("\n"))
+
+
+@pytest.mark.gpu
+def test_bench_py_at_world_2_on_one_gpu(built_lib, fake_rccl, tmp_path):
+    """bench.py's own world > 1 code (VERDICT r5 missing #6) -- `both_scalings` / `other_scaling` (strong scaling through
+    tmx_witness_batch_sharded_device without and with the row exchange, the sharded Level-2 rows), `gather_rows`, `--mode c5` -- executed as the
+    driver launches it (torch.distributed.run, two ranks) before a real 8-GPU node does: TMX_BENCH_SHARE_GPU=1 puts both ranks on cuda:0 with
+    gloo as the control backend, TMX_RCCL_LIB=<fake> gives libtmx a two-rank communicator.  Timings mean nothing (the line says so); the
+    record line must parse, stay under the cap and carry libtmx_comm_world == 2."""
+    import json
+    import socket
+    env = dict(os.environ, TMX_RCCL_LIB=fake_rccl, FAKE_RCCL_DIR=str(tmp_path), TMX_BENCH_SHARE_GPU="1", TMX_BENCH_NO_PMC="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def run(*extra):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--proofs", "16", "--no-cpu-baseline", *extra]
+        r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        line = r.stdout.strip().split("\n")[-1]
+        assert len(line) < 8192, len(line)
+        rec = json.loads(line)
+        assert rec["n_gpus"] == 2 and rec["debug_shared_gpu"] and rec["rccl"]["libtmx_comm_world"] == 2 and rec["all_proofs_ok"], line
+        assert rec["roofline"]["frac"] > 0 and rec["ms_per_step"] > 0
+        return rec
+
+    weak = run()                                   # the driver's command shape: weak scaling + the other scaling of the same record
+    assert weak["scaling"] == "weak" and weak["config"]["proofs_total"] == 32
+    o = weak["other_scaling"]
+    assert o["strong"]["libtmx_comm_world"] == 2 and o["strong"]["proofs_per_gpu"] == 8 and o["strong_with_row_exchange"]["ms_per_step"] > 0
+    assert "error" not in o.get("level2_trace_rows", {}) and o["level2_trace_rows_with_exchange"]["ms_per_step"] > 0
+    strong = run("--scaling", "strong", "--gather")  # BASELINE configs[3] as written, the row exchange inside the step
+    assert strong["scaling"] == "strong" and strong["config"]["proofs_per_gpu"] == 8 and strong["gather_rows"]["bytes_per_rank_out"] > 0
+    assert strong["other_scaling"]["weak"]["proofs_total"] == 32
+    c5 = run("--mode", "c5", "--n-max", "128")     # BASELINE configs[4]'s code path (one proof, lanes sharded), at a size that is quick
+    assert c5["scaling"] == "strong" and "validator-sharded x2" in c5["config"]["parallelism"]
