@@ -279,6 +279,8 @@ struct Knobs {
   bool set_cache = true;     // TMX_SET_CACHE=0: k_proof computes the leaves and the tree of every validator set of every proof (round 4)
   bool epi_late = true;      // TMX_EPI_LATE=0: the cache epilogue of a split warm batch in front of the input sections on side3 (the first round-5 form)
   bool ser_lanes = true;     // TMX_SER_LANES=0: no scalar-lane path for the spans that lie inside one lane of a per-lane section (serialize_span)
+  int fused_base = -1, fused_walk = -1;  // TMX_FUSED_ROWS=<b>[,<w>]: input-only row spans a wave of s*B / of the resident walk takes per table addition
+                                         // (fused rows, layout.h FusedRows); 0,0 = off: the sections as capped launches of their own (round 5); default: see run_batch
   int few_wgs = 0;           // TMX_FEW_WGS=<n>: workgroups of the serializer launches beside the chain (A/B; 0: 1024, 1536 from 131072 lanes)
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
@@ -303,6 +305,13 @@ static Knobs read_knobs() {
   k.set_cache = !((v = std::getenv("TMX_SET_CACHE")) && v[0] == '0');
   k.epi_late = !((v = std::getenv("TMX_EPI_LATE")) && v[0] == '0');
   if ((v = std::getenv("TMX_FEW_WGS"))) k.few_wgs = std::atoi(v);
+  if ((v = std::getenv("TMX_FUSED_ROWS"))) {
+    k.fused_base = std::atoi(v);
+    const char* comma = std::strpbrk(v, ",:");
+    k.fused_walk = comma ? std::atoi(comma + 1) : 0;
+    if (k.fused_base < 0) k.fused_base = 0;
+    if (k.fused_walk < 0) k.fused_walk = 0;
+  }
   if ((v = std::getenv("TMX_SER_LANES"))) k.ser_lanes = std::atoi(v) != 0;
   return k;
 }
@@ -322,6 +331,11 @@ struct tmx_ctx {
   bool fin_done_attached = false;
   void* fin_done = nullptr;  // set by run_batch around the EdDSA producer: the event k_ed_fin signals
   RowOut row = {};           // set by run_batch around the EdDSA producer: where the finish writes D.1b into the rows (or null)
+  FusedRows fused = {};      // set by run_batch around the EdDSA producer: the input-only row spans its throughput kernels carry (ctr null: none)
+  SerializeProgram fused_prog = {};
+  uint32_t* d_span_ctr = nullptr;  // two claim counters (a fused launch uses one, its sweeper zeroes the other for the next)
+  uint32_t span_parity = 0;
+  bool span_ctr_dirty = false;     // a fused launch failed half-way: both counters are zeroed before the next one
   hipEvent_t ev_direct = nullptr;  // the table-free lanes of a launch are done (side2)
   volatile uint32_t* h_hint = nullptr;  // page-locked, written by k_kc_epilogue: [0] launches committed, [1] new keys of the last one
   hipEvent_t ev_part[4] = {};
@@ -425,6 +439,10 @@ static ProofParams proof_params(const tmx_ctx* c, int32_t kind, bool leaves_done
   return P;
 }
 
+#ifndef TMX_FUSED_BASE_DEFAULT
+#define TMX_FUSED_BASE_DEFAULT 0  // (spans per table addition of s*B / of the resident walk; set by measurement: docs/experiments.md round 6)
+#define TMX_FUSED_WALK_DEFAULT 0
+#endif
 #ifndef TMX_HASH_FIRST_MAX
 #define TMX_HASH_FIRST_MAX 16384u  // measured: 64 / 128 proofs at N = 128 -3 %, 256 +2 %, 1024 +6 % (the dedup beside the hash role on a full chip)
 #endif
@@ -526,9 +544,40 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // (the split warm schedule puts the new-key pipeline on side3 IN FRONT of these sections -- usually three empty launches; with new keys
   // the pipeline must not queue behind 200 us of trickling stores -- so the sections are enqueued behind the EdDSA stage then)
   c->plan = eddsa_writes_rows ? ed_plan(c, (uint32_t)lanes_all, true) : tmx_ctx::EdPlan{};
+  // Fused rows (round 6; layout.h FusedRows): in the split warm schedule above 16384 lanes -- s*B and the resident walk are launches of their
+  // own there, throughput-bound and on the chip from ~40 us on -- the input-only sections are not a launch that queues beside the chain but
+  // work items the waves of those kernels claim between their table additions; the capped launch on side3 sweeps up what they leave.
+  FusedRows fused = {};
+  {
+    const uint32_t in_mask = prog.mask_inputs & (((c->sections & TMX_SEC_HINT) ? prog.mask_hint : 0u) | ((c->sections & TMX_SEC_DERIVED) ? prog.mask_derived : 0u));
+    const int fb = K.fused_base >= 0 ? K.fused_base : TMX_FUSED_BASE_DEFAULT, fw = K.fused_walk >= 0 ? K.fused_walk : TMX_FUSED_WALK_DEFAULT;
+    if (c->plan.split && !c->plan.sb_with_hash && K.ser_split && d_out_elems && in_mask && (fb | fw) && c->d_span_ctr) {
+      uint32_t lo = 0xffffffffu, hi = 0;
+      for (uint32_t k = 0; k < prog.sp.n_sections; k++) {
+        if (!((in_mask >> k) & 1u)) continue;
+        const Section& sc = prog.sp.sec[k];
+        lo = std::min(lo, sc.elem_start);
+        hi = std::max(hi, sc.elem_start + sc.lane_elems * sc.n_lanes);
+      }
+      const uint32_t first = lo / prog.sp.span, last = (hi + prog.sp.span - 1) / prog.sp.span;
+      if (prog.sp.span == 256 && last > first && (uint64_t)(last - first) * n_proofs < 0x7fffffffull) {
+        if (c->span_ctr_dirty) { HIPCK(c, hipMemsetAsync(c->d_span_ctr, 0, 256, s)); c->span_ctr_dirty = false; }
+        fused.ctr = c->d_span_ctr + 32 * c->span_parity;  // (the two counters on lines of their own)
+        fused.lut = reinterpret_cast<const uint32_t*>(c->d_lut[kind]); fused.wave_sec = reinterpret_cast<const uint8_t*>(c->d_wave_sec[kind]);
+        fused.out = reinterpret_cast<uint64_t*>(d_out_elems); fused.sec_mask = in_mask; fused.first_span = first; fused.n_spans = last - first;
+        fused.n_proofs = n_proofs; fused.per_base = (uint32_t)fb; fused.per_walk = (uint32_t)fw;
+        c->fused_prog = resolve_serialize_program(prog.sp, src);
+      }
+    }
+  }
   auto side3_inputs = [&]() -> int32_t {
     HIPCK(c, hipStreamWaitEvent(c->side3, ev[0], 0));
-    if (K.ser_split && (st0 = serialize(prog.mask_inputs, c->side3, beside_chain_wgs))) return st0;
+    if (fused.ctr) {
+      int r = launch_serialize_claim(c->fused_prog, fused, c->d_span_ctr + 32 * (c->span_parity ^ 1u), c->side3, beside_chain_wgs);
+      if (r) c->span_ctr_dirty = true;
+      if (r) return fail(c, TMX_ERR_HIP, std::string("k_serialize_claim launch: ") + hipGetErrorString((hipError_t)r));
+      c->span_parity ^= 1u;
+    } else if (K.ser_split && (st0 = serialize(prog.mask_inputs, c->side3, beside_chain_wgs))) return st0;
     if (leaves_first) {
       HIPCK(c, hipStreamWaitEvent(c->side3, c->ev_leaves, 0));
       if ((st0 = serialize(prog.mask_leaves, c->side3, beside_chain_wgs))) return st0;
@@ -552,7 +601,10 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   }
   const uint32_t mask_final = row.rows ? 0u : prog.mask_final;
   c->row = row;
+  c->fused = fused;
   int32_t st = ed_producer(s);
+  c->fused = FusedRows{};
+  if (fused.ctr && st) c->span_ctr_dirty = true;  // (the sweeper that zeroes the next counter was never enqueued)
   const bool fin_split = c->plan.split;  // (the lanes of new keys are finished on side2: whatever reads every lane's verdict on s waits for ev_direct)
   c->plan.valid = false;
   c->fin_done = nullptr;
@@ -793,6 +845,7 @@ static int run_eddsa(tmx_ctx* c, uint32_t n_lanes, const void* d_lanes, void* d_
   Q.kc = c->kc; Q.mode = K.dedup_mode;
   Q.fin_done = c->fin_done; c->fin_done = nullptr;
   Q.row = c->row;
+  Q.fused = c->fused; Q.fused_prog = c->fused_prog;
   c->last_lanes = n_lanes;
   Q.d_cnt = reinterpret_cast<uint32_t*>(c->d_cnt) + 8 * c->parity;
   Q.d_cnt_next = reinterpret_cast<uint32_t*>(c->d_cnt) + 8 * (c->parity ^ 1);
@@ -1192,7 +1245,7 @@ void tmx_ctx_destroy(tmx_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipDeviceSynchronize();
   }
-  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_live, c->d_dummy_ed, c->d_dummy_in, c->setc.table, c->setc.state, c->setc.slots, c->d_owner_of, c->d_slot_of_owner, c->d_slot_of_uid, c->d_owners, c->d_keyrec,
+  void* bufs[] = {c->d_lut[0], c->d_lut[1], c->d_wave_sec[0], c->d_wave_sec[1], c->d_seams[0], c->d_seams[1], c->d_table, c->d_qtable, c->d_pre, c->d_mulout, c->d_hash, c->d_cnt, c->d_live, c->d_dummy_ed, c->d_dummy_in, c->setc.table, c->setc.state, c->setc.slots, c->d_span_ctr, c->d_owner_of, c->d_slot_of_owner, c->d_slot_of_uid, c->d_owners, c->d_keyrec,
                   c->d_anchors, c->d_keytab, c->kc.d_hash, c->kc.d_pk, c->kc.d_used, c->kc.d_free, c->kc.d_state, c->d_ed, c->d_tl, c->d_lr, c->d_pf, c->d_nodes_t, c->d_nodes_r,
                   c->d_reports, c->d_in_proofs, c->d_in_targets, c->d_in_trusteds, c->d_out, c->d_pack, c->d_trace_tmp, c->d_tiny, c->d_shadow, c->d_commit,
                   c->d_val_lut[0], c->d_val_lut[1], c->d_value};
@@ -1316,6 +1369,8 @@ int32_t tmx_ctx_create(const tmx_config* cfg, tmx_ctx** out) {
     c->hash_mask = (uint32_t)(cap - 1);
     HIPCK(c, hipMalloc(&c->d_hash, (size_t)cap * 4));
     HIPCK(c, hipMalloc(&c->d_cnt, 64));
+    HIPCK(c, hipMalloc(reinterpret_cast<void**>(&c->d_span_ctr), 256));
+    HIPCK(c, hipMemsetAsync(c->d_span_ctr, 0, 256, c->side2));
     HIPCK(c, hipMemsetAsync(c->d_hash, 0xff, (size_t)cap * 4, c->side2));
     HIPCK(c, hipMemsetAsync(c->d_cnt, 0, 64, c->side2));
     HIPCK(c, hipMalloc(&c->d_live, lanes * 4));

@@ -53,6 +53,9 @@ struct EdQuad {
   uint32_t compact = 0;
   void* d_live = nullptr;
   const void* d_dummy_ed = nullptr;
+  // Fused rows (layout.h FusedRows): the input-only row spans carried by k_ed_base / the resident k_ed_mul_tab; fused.ctr == null: off
+  FusedRows fused = {};
+  SerializeProgram fused_prog = {};  // the program resolved for this batch (resolve_serialize_program)
 };
 size_t quad_table_bytes();
 size_t pre_bytes_per_lane();
@@ -93,6 +96,9 @@ int launch_verdict(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_e
 int launch_verdict_tail(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_ed, uint32_t ed_stride, void* d_pf, void* d_reports, const RowOut& row,
                         const SerializeProgram& S, const SerializeSources& src, const void* d_lut, const void* d_seam_waves, uint32_t n_seams, void* d_out,
                         uint32_t sec_mask, void* stream, void* started = nullptr, void* done = nullptr);
+SerializeProgram resolve_serialize_program(const SerializeProgram& S, const SerializeSources& src);
+// the sweeper of the fused rows: at most max_wgs workgroups claim the spans the carriers have not taken; zeroes *d_zero_ctr (the other parity's counter)
+int launch_serialize_claim(const SerializeProgram& S_resolved, const FusedRows& F, void* d_zero_ctr, void* stream, uint32_t max_wgs);
 // sec_mask: bit s = section s, bit 31 = waves straddling a section boundary / the row end
 int launch_serialize(const SerializeProgram& S, const SerializeSources& src, const void* d_lut, const void* d_wave_sec, const void* d_seam_waves,
                      uint32_t n_seams, uint32_t n_proofs, void* d_out, uint32_t sec_mask, void* stream, uint32_t max_wgs = 0, uint32_t proof0 = 0);

@@ -89,6 +89,18 @@ struct SerializeProgram {
   uint32_t lane_fast;    // 1: a span that lies inside ONE lane of a per-lane section takes the scalar-lane path (serialize_span; TMX_SER_LANES=0: never)
   uint32_t span;         // elements one wave serializes (128, 256 or 512): SPAN/128 coalesced 16-byte stores per thread, all loads in flight together
 };
+// Fused rows (round 6): the row spans that only expand input records (H.2, H.4: 42 % of a skip row) are work items of ONE claim counter; the
+// throughput-bound EdDSA kernels (s*B, the table walk) take `per_base` / `per_walk` of them per table addition -- their stores ride between the
+// additions of waves that are on the chip anyway -- and a capped sweeper launch on the low-priority stream takes whatever is left.  Every span is
+// written by exactly one claimer; which one decides nothing but the schedule.  ctr == null: off.
+struct FusedRows {
+  uint32_t* ctr;           // this launch's claim counter: item w = span (first_span + w % n_spans) of proof (w / n_spans)
+  const uint32_t* lut;
+  const uint8_t* wave_sec;
+  uint64_t* out;
+  uint32_t sec_mask, first_span, n_spans, n_proofs;
+  uint32_t per_base, per_walk, pad0, pad1;
+};
 struct SerializeSources {
   const uint8_t* base[SRC_COUNT];
   const uint8_t* nodes_t;
