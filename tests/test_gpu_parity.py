@@ -667,6 +667,31 @@ def test_schedule_knobs_give_the_same_bits(tmx, oracle, monkeypatch, knobs):
             assert [r["first_bad_sig"] for r in reps] == ([lane] if p0 == 0 else [-1]) + [-1] * (p1 - p0 - 1)
 
 
+@pytest.mark.parametrize("fused", ["0:0", "4:0", "0:3", "8:4", "40:40"])
+def test_fused_rows_give_the_same_bits(tmx, oracle, monkeypatch, fused):
+    """TMX_FUSED_ROWS=<b>:<w> (layout.h FusedRows): the input-only row spans of a warm batch above 16384 lanes as work items that
+    the waves of s*B (b per table addition) and of the resident walk (w) claim between their additions, a capped claiming launch sweeping up
+    the rest.  Whoever writes a span writes the same bytes: 140 proofs x 128 lanes (one failing signature), cold, warm, warm again with three
+    proofs over new validator sets (new keys: the new-key walk does not carry) and warm once more -- all rows and reports vs the oracle.
+    40:40 = the carriers claim more than there is.  (Measured slower than the launches of their own at 256 / 512 / 768 proofs: off by default,
+    docs/experiments.md round 6.)"""
+    from tendermintx_amd.synth import Workload
+    monkeypatch.setenv("TMX_FUSED_ROWS", fused)
+    n, P = 128, 140
+    wl = Workload(0, n, P, 100, chain_id=b"celestia", seed=6161, signed_permille=880, n_sets=3)
+    targets = bytearray(wl.targets)
+    lane = next(l for l in range(n) if targets[l * 256 + 223] & 1)
+    targets[lane * 256 + 40] ^= 0x10
+    fresh = Workload(0, n, 3, 90, chain_id=b"celestia", seed=6262, signed_permille=950, n_sets=3)
+    mix = (fresh.proofs + wl.proofs[3 * 2336:], fresh.targets + bytes(targets[3 * n * 256:]), fresh.trusteds + wl.trusteds[3 * n * 48:])
+    with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+        for _ in range(2):
+            _, reps = _check_vs_oracle(tmx, oracle, 0, n, wl.proofs, bytes(targets), wl.trusteds, b"celestia", ctx=ctx)
+            assert reps[0]["first_bad_sig"] == lane and all(r["first_bad_sig"] == -1 for r in reps[1:])
+        _check_vs_oracle(tmx, oracle, 0, n, *mix, b"celestia", ctx=ctx)
+        _check_vs_oracle(tmx, oracle, 0, n, wl.proofs, bytes(targets), wl.trusteds, b"celestia", ctx=ctx, repeat=2)
+
+
 @pytest.mark.parametrize("permille", [0, 1000, 500])
 def test_compacted_launch_edges(tmx, oracle, monkeypatch, permille):
     """The dense list of lanes that signed (k_ed_dedup, kernels.h EdQuad.compact) at its edges: NOBODY signed in the whole batch (an empty
