@@ -281,6 +281,7 @@ struct Knobs {
   bool ser_lanes = true;     // TMX_SER_LANES=0: no scalar-lane path for the spans that lie inside one lane of a per-lane section (serialize_span)
   int fused_base = -1, fused_walk = -1;  // TMX_FUSED_ROWS=<b>[,<w>]: input-only row spans a wave of s*B / of the resident walk takes per table addition
                                          // (fused rows, layout.h FusedRows); 0,0 = off: the sections as capped launches of their own (round 5); default: see run_batch
+  int tail_aside_min = -1;   // TMX_TAIL_ASIDE_MIN=<lanes>: from how many lanes on the verdict + its sections leave the caller's stream (default 10240)
   int few_wgs = 0;           // TMX_FEW_WGS=<n>: workgroups of the serializer launches beside the chain (A/B; 0: 1024, 1536 from 131072 lanes)
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
@@ -305,6 +306,7 @@ static Knobs read_knobs() {
   k.set_cache = !((v = std::getenv("TMX_SET_CACHE")) && v[0] == '0');
   k.epi_late = !((v = std::getenv("TMX_EPI_LATE")) && v[0] == '0');
   if ((v = std::getenv("TMX_FEW_WGS"))) k.few_wgs = std::atoi(v);
+  if ((v = std::getenv("TMX_TAIL_ASIDE_MIN"))) k.tail_aside_min = std::atoi(v);
   if ((v = std::getenv("TMX_FUSED_ROWS"))) {
     k.fused_base = std::atoi(v);
     const char* comma = std::strpbrk(v, ",:");
@@ -630,7 +632,9 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
   }
   // (a small batch is pure latency: its tail stays on s, two cross-stream hops cost more than the overlap gains)
-  const bool tail_aside = K.ser_split && (uint64_t)n_proofs * n >= 4096;
+  // (round 6: the threshold moved from 4096 to 10240 lanes -- 32 / 48 / 64 proofs x 128: 0.210 -> 0.199, 0.222 -> 0.214, 0.259 -> 0.252 ms with the
+  // one-launch tail on s; 96 proofs: 0.2625 aside vs 0.2715 on s.  profiles/r06_small_tail_ab.txt)
+  const bool tail_aside = K.ser_split && (uint64_t)n_proofs * n >= (K.tail_aside_min >= 0 ? (uint64_t)K.tail_aside_min : 10240u);
   const bool small_tail = K.ser_split && !tail_aside;  // D.1a goes into the SAME launch as k_proof's sections (one launch, behind the hash event)
   if (small_tail && !leaves_first) {
     if (!c->ev_hash_recorded) HIPCK(c, hipEventRecord(c->ev_hash, s));  // (a producer without a phase-1 event: everything it enqueued)
