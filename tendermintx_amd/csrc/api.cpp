@@ -282,7 +282,7 @@ struct Knobs {
   int fused_base = -1, fused_walk = -1;  // TMX_FUSED_ROWS=<b>[,<w>]: input-only row spans a wave of s*B / of the resident walk takes per table addition
                                          // (fused rows, layout.h FusedRows); 0,0 = off: the sections as capped launches of their own (round 5); default: see run_batch
   int tail_aside_min = -1;   // TMX_TAIL_ASIDE_MIN=<lanes>: from how many lanes on the verdict + its sections leave the caller's stream (default 10240)
-  int few_wgs = 0;           // TMX_FEW_WGS=<n>: workgroups of the serializer launches beside the chain (A/B; 0: 1024, 1536 from 131072 lanes)
+  int few_wgs = 0;           // TMX_FEW_WGS=<n>: workgroups of the serializer launches beside the chain (A/B; 0: by size, run_batch)
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
 static Knobs read_knobs() {
@@ -508,7 +508,10 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // 256 proofs 0.377 - 0.387 vs 0.395 - 0.410 ms with 1024; 512 / 768: 0.455 / 0.432; 3072 / 4096 / 8192: 0.385 / 0.381 / 0.393; no difference
   // at 64, 128, 512 and 1024 proofs)
   const uint64_t lanes_bc = (uint64_t)n_proofs * n;
-  const uint32_t beside_chain_wgs = K.few_wgs > 0 ? (uint32_t)K.few_wgs : (lanes_bc >= 131072 ? 1536u : (lanes_bc > 16384 && lanes_bc < 65536 ? 2048u : 1024u));  // (warm key cache, 256 proofs: 2048 / 4096 / uncapped +10 / +4 / +2 %)
+  // (round 6, profiles/r06_writer_cap_sweep.txt: from 1024 proofs on -- where the leaves go first and the step is the sum of a VALU-bound chain
+  // and an HBM-bound tail -- 8192 workgroups: 1024 / 1280 / 1536 proofs 1.557 -> 1.455, 2.008 -> 1.890, 2.358 -> 2.145 ms, 2048 proofs flat;
+  // 512 to 1023 proofs 1536 instead of 1024: 640 / 768 / 896 proofs 1.11 -> 0.98, 1.164 -> 1.116, 1.332 -> 1.315 ms, 512 proofs unchanged)
+  const uint32_t beside_chain_wgs = K.few_wgs > 0 ? (uint32_t)K.few_wgs : (lanes_bc >= 131072 ? 8192u : (lanes_bc >= 65536 ? 1536u : (lanes_bc > 16384 ? 2048u : 1024u)));  // (warm key cache, 256 proofs: 2048 / 4096 / uncapped +10 / +4 / +2 %)
   // Leaves first (TMX_LEAVES=1|0, default by size): marshalled validators + leaf hashes as a 10-us launch of their own in front of k_proof,
   // so that the byte fields of the two per-lane derived sections (D.2a: the leaves; D.1a: the leaves + phase 1 -- 42 % of a skip row) are
   // written by the low-priority stream behind the input sections instead of behind k_proof (which ends at ~300 us inside a step) / k_ed_fin.
