@@ -281,6 +281,8 @@ struct Knobs {
   bool ser_lanes = true;     // TMX_SER_LANES=0: no scalar-lane path for the spans that lie inside one lane of a per-lane section (serialize_span)
   int fused_base = -1, fused_walk = -1;  // TMX_FUSED_ROWS=<b>[,<w>]: input-only row spans a wave of s*B / of the resident walk takes per table addition
                                          // (fused rows, layout.h FusedRows); 0,0 = off: the sections as capped launches of their own (round 5); default: see run_batch
+  long inputs_first_min = -1; // TMX_INPUTS_FIRST=<lanes>: from that many lanes on the split warm schedule enqueues the input sections IN FRONT of the new-key pipeline on the low-priority stream (0: never)
+  int writer_prio = -1;      // TMX_WRITER_PRIO=<0..3>: s_setprio of the row-writer waves (default: by size, run_batch)
   int tail_aside_min = -1;   // TMX_TAIL_ASIDE_MIN=<lanes>: from how many lanes on the verdict + its sections leave the caller's stream (default 10240)
   int few_wgs = 0;           // TMX_FEW_WGS=<n>: workgroups of the serializer launches beside the chain (A/B; 0: by size, run_batch)
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
@@ -307,6 +309,8 @@ static Knobs read_knobs() {
   k.epi_late = !((v = std::getenv("TMX_EPI_LATE")) && v[0] == '0');
   if ((v = std::getenv("TMX_FEW_WGS"))) k.few_wgs = std::atoi(v);
   if ((v = std::getenv("TMX_TAIL_ASIDE_MIN"))) k.tail_aside_min = std::atoi(v);
+  if ((v = std::getenv("TMX_WRITER_PRIO"))) k.writer_prio = std::atoi(v);
+  if ((v = std::getenv("TMX_INPUTS_FIRST"))) k.inputs_first_min = std::atol(v);
   if ((v = std::getenv("TMX_FUSED_ROWS"))) {
     k.fused_base = std::atoi(v);
     const char* comma = std::strpbrk(v, ",:");
@@ -485,7 +489,14 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   src.base[SRC_TARGET] = (const uint8_t*)d_targets; src.base[SRC_TRUSTED] = (const uint8_t*)d_trusteds;
   src.base[SRC_TL] = tl; src.base[SRC_LR] = (const uint8_t*)c->d_lr; src.base[SRC_PF] = (const uint8_t*)c->d_pf;
   src.nodes_t = (const uint8_t*)c->d_nodes_t; src.nodes_r = (const uint8_t*)c->d_nodes_r;
-  const Program& prog = c->prog[kind];
+  Program& prog = c->prog[kind];
+  // Throughput regime (round 6, profiles/r06_throughput_regime_ab.txt): from 512 proofs x 128 on a step is a VALU-bound chain plus an HBM-bound tail
+  // that overlap badly -- whatever shortens one lengthens the other.  What moves the sum: the row writers' short waves at wave priority 3 (they
+  // issue a dozen instructions between memory round trips: first in line they keep the store path fed, and the walk loses < 10 % of its slots) and,
+  // from 1024 proofs on, the input sections in front of the new-key pipeline so that the stores start with the step: 512 / 1024 / 2048 proofs
+  // 0.764 -> 0.741, 1.479 -> 1.422, 3.12 -> 2.81 ms.  (256 proofs: +1 % / +4.6 %: the latency regime keeps the round-5 form.)
+  const uint64_t lanes_w = (uint64_t)n_proofs * c->cfg.n_max;
+  prog.sp.wave_prio = K.writer_prio >= 0 ? (uint32_t)K.writer_prio : (lanes_w >= 65536 ? 3u : 0u);
   auto serialize = [&](uint32_t mask, hipStream_t on, uint32_t max_wgs = 0) -> int32_t {
     if (!d_out_elems) return TMX_OK;
     // (sections the caller did not ask for are not written; the seam spans are few and always written)
@@ -590,7 +601,8 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
     return TMX_OK;
   };
-  const bool defer3 = c->plan.split;
+  const bool inputs_first = K.inputs_first_min >= 0 ? (K.inputs_first_min > 0 && lanes_bc >= (uint64_t)K.inputs_first_min) : lanes_bc >= 131072;
+  const bool defer3 = c->plan.split && !inputs_first;
   if (!defer3 && (st0 = side3_inputs())) return st0;
 
   // ev[1] rides on the k_ed_fin dispatch itself (TMX_EXT_EVENTS=0: a record packet behind it)
