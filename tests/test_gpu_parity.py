@@ -638,7 +638,12 @@ KNOBS = [
     # the cache epilogue in front of / behind the input sections of the low-priority stream; no validator-set cache
     {"TMX_EPI_LATE": "0", "TMX_SCHEDULE": "warm"}, {"TMX_SET_CACHE": "0"}, {"TMX_SET_CACHE": "0", "TMX_SCHEDULE": "warm", "TMX_TINY": "0"},
     # per-lane sections of the row span by span (k_serialize) instead of lane by lane (k_serialize_lanes, the default above 8 proofs)
-    {"TMX_SER_LANES": "0"}, {"TMX_SER_LANES": "0", "TMX_SER_SPLIT": "0"}, {"TMX_SER_SPLIT": "0"}]
+    {"TMX_SER_LANES": "0"}, {"TMX_SER_LANES": "0", "TMX_SER_SPLIT": "0"}, {"TMX_SER_SPLIT": "0"},
+    # round 6: the throughput regime's settings forced on a small batch (row-writer wave priority, input sections in front of the new-key
+    # pipeline, the writers' workgroup cap), the verdict's tail on / off the caller's stream, the fused rows at this size (no carrier: the sweeper alone)
+    {"TMX_WRITER_PRIO": "3"}, {"TMX_INPUTS_FIRST": "1"}, {"TMX_INPUTS_FIRST": "1", "TMX_WRITER_PRIO": "3", "TMX_FEW_WGS": "8192"},
+    {"TMX_INPUTS_FIRST": "1", "TMX_SCHEDULE": "warm", "TMX_TINY": "0"}, {"TMX_TAIL_ASIDE_MIN": "0"}, {"TMX_TAIL_ASIDE_MIN": "1000000"},
+    {"TMX_FUSED_ROWS": "4:2", "TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0"}]
 
 
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
@@ -763,6 +768,42 @@ def test_key_dedup_paths(tmx, oracle):
         # the same batch again must not see stale keys / tables from the previous launches
         _, reps2 = _check_vs_oracle(tmx, oracle, 0, n, same.proofs, same.targets, same.trusteds, b"celestia", ctx=ctx)
         assert ctx.last_dedup() == (16, True)
+
+
+@pytest.mark.parametrize("P", [640, 1024])
+def test_throughput_regime_all_rows(tmx, oracle, P):
+    """The schedule of the throughput regime (round 6: from 512 proofs x 128 the row writers run at wave priority 3 with 1536 workgroups beside the
+    chain; from 1024 proofs the input sections go in front of the new-key pipeline, 8192 workgroups, the leaves first): the bench workload at 640
+    and 1024 proofs, cold, warm and warm with new keys in front -- EVERY row and report vs the oracle (4.4 GB of rows at 1024 proofs, compared
+    128 proofs at a time)."""
+    import torch
+    from tendermintx_amd.synth import Workload, bench_workload
+    n = 128
+    wl = bench_workload("survey8d", n, P, seed=0x544D58 + P)
+    fresh = Workload(0, n, 2, 90, chain_id=b"celestia", seed=31337 + P, signed_permille=950, n_sets=2)
+    mixed = (fresh.proofs + wl.proofs[2 * 2336:], fresh.targets + wl.targets[2 * n * 256:], fresh.trusteds + wl.trusteds[2 * n * 48:])
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev)
+    with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+        stride, count = ctx.elem_stride(0), ctx.elem_count(0)
+        out = torch.empty((P, stride), dtype=torch.int64, device=dev)
+        rep = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
+        for run, (pr, tg, tr) in enumerate(((wl.proofs, wl.targets, wl.trusteds),) * 2 + (mixed, (wl.proofs, wl.targets, wl.trusteds))):
+            d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) for b in (pr, tg, tr)]
+            out.fill_(-1)
+            rep.zero_()
+            torch.cuda.synchronize(dev)
+            ctx.witness_batch_device(0, P, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), out.data_ptr(), rep.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            reps = np.frombuffer(rep.cpu().numpy().tobytes(), dtype=np.uint32).reshape(P, 16)
+            for p0 in range(0, P, 128):
+                p1 = min(P, p0 + 128)
+                want, oreps = oracle.witness_batch(0, p1 - p0, pr[p0 * 2336:p1 * 2336], tg[p0 * n * 256:p1 * n * 256], tr[p0 * n * 48:p1 * n * 48], n,
+                                                   b"celestia", 100800, n_threads=os.cpu_count() or 8)
+                got = out[p0:p1, :count].cpu().numpy().view(np.uint64)
+                assert np.array_equal(got, want), (run, p0, np.argwhere(got != want)[:8].tolist())
+                assert [int(r[8]) for r in reps[p0:p1]] == [int(o["all_ok"]) for o in oreps], (run, p0)
+            assert int(out[:, count:].abs().sum().item()) == 0
 
 
 def test_timed_workload_all_rows(tmx, oracle):
