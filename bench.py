@@ -535,6 +535,35 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
         "distinct_keys": uo, "per_key_tables": to,
         "all_proofs_ok": ok_o, "note": "same context, 30 steps after 10 warm-up, host clock around the enqueue + synchronize"}
 
+    # ---- other batch sizes through the same entry point (warm key cache, rows resident, host clock around 20 pipelined steps): the latency regime
+    # (32 ... 128 proofs) and the throughput regime (512 / 1024 proofs: chain + tail)
+    try:
+        sizes = {}
+        for Pb in (32, 64, 128, 512, 1024):
+            wb = bench_workload(args.workload, n, Pb, seed=0x544D58)
+            cb = ctx if Pb <= P else Context(n, b"celestia", 100800, device=dev.index, max_batch=Pb)
+            bb = tuple(dev_bytes(b) for b in (wb.proofs, wb.targets, wb.trusteds))
+            ob = d_out if Pb <= P else torch.empty((Pb, stride), dtype=torch.int64, device=dev)
+            rb = d_rep if Pb <= P else torch.zeros(Pb * 64, dtype=torch.uint8, device=dev)
+
+            def go(k):
+                for _ in range(k):
+                    cb.witness_batch_device(KIND_SKIP, Pb, bb[0].data_ptr(), bb[1].data_ptr(), bb[2].data_ptr(), ob.data_ptr(), rb.data_ptr(), stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+            go(6)
+            a = time.perf_counter()
+            go(20)
+            ms = 1e3 * (time.perf_counter() - a) / 20
+            ok_b = int(rb.cpu().numpy().reshape(-1, 64)[:Pb, 32:36].copy().view(np.uint32).sum()) == Pb
+            sizes[str(Pb)] = round(ms, 4) if ok_b else None
+            if cb is not ctx:
+                cb.close()
+            del bb
+        result["batch_sizes_ms"] = sizes
+        run(ctx, 3)   # (the timed batch resident again)
+    except Exception as e:
+        result["batch_sizes_ms"] = {"error": repr(e)[:200]}
+
     # ---- BASELINE configs[2]: ONE proof.  Device-resident latency (host clock around one call) and host-to-host (host buffers in,
     # witness row in page-locked host memory out: SURVEY 8(d)'s metric definition)
     lat_cold = cold_ms(None, 1, reps=20)

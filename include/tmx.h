@@ -429,7 +429,7 @@ int32_t tmx_key_cache_config(tmx_ctx* ctx, uint32_t enabled, uint32_t max_keys);
  * the number of enabled lanes -- not on the proof, and a light client re-verifies the same slowly changing sets.  A batch's k_proof looks both
  * sets of a proof up by a 64-bit fingerprint, compares EVERY key byte, and copies the cached values instead of hashing (15 SHA-256
  * compressions off its chain); sets it had to compute are inserted.  256 sets per context, least-recently-used eviction at launch granularity
- * (round 6): a hit or an insert stamps the set with the launch's number, and the last workgroup of a launch keeps an eighth of the slots free by
+ * (round 6): a hit or an insert stamps the set with the launch's number, and a one-workgroup kernel behind every k_proof launch keeps an eighth of the slots free by
  * evicting the sets used longest ago -- a prover that lives for months (reference bin/tendermintx.rs:171) keeps the sets it is verifying now, not
  * the first 256 it ever saw.  tmx_key_cache_flush empties it too; TMX_SET_CACHE=0 disables; TMX_SET_CACHE_SETS=<4..256> = capacity (tests).
  * Bit-identical by construction.  out: [0] sets resident [1] sets served from the cache [2] sets computed [3] sets inserted [4] sets evicted

@@ -657,6 +657,9 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   }
   st0 = K.ser_split ? serialize(prog.mask_proof | (leaves_first ? 0u : prog.mask_leaves) | (small_tail && !leaves_first ? prog.mask_p1 : 0u), c->side) : TMX_OK;
   if (st0) return st0;
+  // the validator-set cache's LRU: one workgroup behind k_proof and its sections on this stream (the next k_proof is behind it), off every chain
+  if (!roles && c->setc.table && (rc = launch_setc_evict(c->setc, c->setc_epoch, c->side)))
+    return fail(c, TMX_ERR_HIP, std::string("k_setc_evict launch: ") + hipGetErrorString((hipError_t)rc));
   // D.1a (the byte fields of the per-target-lane derived values: a quarter of the row) needs k_proof and phase 1, not k_ed_fin: behind
   // k_proof's sections on the side stream, i.e. while the table walk and the finish run.  Measured (round 2): -6.3 % step at 1024
   // proofs x 128; +-0.5 % at 256 and 64, +1 ... +2 % at 512 proofs (and +7 % at 256 with a warm key cache): on from 131072 lanes

@@ -96,6 +96,8 @@ int launch_verdict(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_e
 int launch_verdict_tail(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_ed, uint32_t ed_stride, void* d_pf, void* d_reports, const RowOut& row,
                         const SerializeProgram& S, const SerializeSources& src, const void* d_lut, const void* d_seam_waves, uint32_t n_seams, void* d_out,
                         uint32_t sec_mask, void* stream, void* started = nullptr, void* done = nullptr);
+// LRU eviction of the validator-set cache (layout.h SetCache): one workgroup behind a k_proof launch on its stream
+int launch_setc_evict(const SetCache& SC, uint32_t epoch, void* stream);
 SerializeProgram resolve_serialize_program(const SerializeProgram& S, const SerializeSources& src);
 // the sweeper of the fused rows: at most max_wgs workgroups claim the spans the carriers have not taken; zeroes *d_zero_ctr (the other parity's counter)
 int launch_serialize_claim(const SerializeProgram& S_resolved, const FusedRows& F, void* d_zero_ctr, void* stream, uint32_t max_wgs);

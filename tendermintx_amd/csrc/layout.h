@@ -128,14 +128,14 @@ constexpr uint32_t TR_LADDER_ROW = 65, TR_LADDER_ROWS = 256, TR_SHA512_ROW = 18,
 // addressed like the key cache: a 64-bit fingerprint finds a slot, ALL key bytes are compared before its values are used.
 //   table[tab_mask + 1]   0 = empty, (slot + 1) = valid, (slot + 1) | SETC_PENDING = claimed and being written
 //   state[8]              [0] next never-used slot  [1] sets served from the cache  [2] sets computed  [3] sets inserted
-//                         [4] entries on the free list (signed: a pop that finds none takes it below zero for a moment)  [5] workgroups of the
-//                         running k_proof launch that are done with the cache  [6] sets evicted  [7] free
+//                         [4] entries on the free list (signed: a pop that finds none takes it below zero for a moment)  [5] free
+//                         [6] sets evicted  [7] free
 //   freelist[cap]         slots given back by an eviction (behind state[]: same allocation)
 //   slot                  u64 fingerprint | u32 nb | u32 varint-msb failures | u32 epoch of the last launch that used it (0: free) | pad to 32 |
 //                         root[32] | keys n x 48 B (pubkey, power, vlen) | per-lane values n x 80 B (marshalled validator 48, leaf hash 32) |
 //                         tree nodes tree_nodes x 32 B
-// LRU at launch granularity (round 6; like the key cache's): a hit or an insert stamps the slot with the launch's epoch; the LAST workgroup of a
-// k_proof launch to finish (ticket state[5]; k_proof launches of a context run in order on one stream, so nobody else touches the cache then)
+// LRU at launch granularity (round 6; like the key cache's): a hit or an insert stamps the slot with the launch's epoch; k_setc_evict -- one
+// workgroup enqueued behind every k_proof launch on its stream, so nobody else touches the cache while it runs --
 // keeps an eighth of the slots free: it evicts the least recently used, rebuilds the table from the surviving slots' fingerprints and puts the
 // evicted slots on the free list.  Within a launch slots are never rewritten.  tmx_key_cache_flush empties the cache.
 constexpr uint32_t SETC_PENDING = 0x80000000u, SETC_HDR = 64, SETC_KEY = 48, SETC_VAL = 80, SETC_OFF_EPOCH = 16, SETC_STATE_WORDS = 8, SETC_MAX_SLOTS = 256;

@@ -7,7 +7,9 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+python bench.py > "$OUT/bench.out" 2> "$OUT/bench.err"
+tail -1 "$OUT/bench.out" > "$OUT/bench.json"                       # the record line, byte for byte (what the driver parses)
+cp bench_extras.json "$OUT/bench_extras.json" 2>/dev/null           # the full record
 tools/microbench/valu_isa > "$OUT/valu_isa.txt" 2>&1
 TMX_BENCH_NO_PMC=1 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- python bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
 rocprofv3 --kernel-trace -d "$OUT/trace_step" -o step -- python tools/profile_step.py > "$OUT/step_trace.log" 2>&1
