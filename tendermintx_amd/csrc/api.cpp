@@ -238,7 +238,7 @@ Program build_program(int kind, uint32_t n) {
   P.sp.n = n;
   P.sp.tree_nodes = tn;
   P.lut = std::move(L.v);
-  const uint32_t span = 256;  // elements per wave: 128 and 512 measured slower on MI355X (round 1)
+  const uint32_t span = SER_SPAN_ELEMS;  // elements per wave (layout.h TMX_SER_SPAN): 128 and 512 measured slower on MI355X (round 1; round 6: docs/experiments.md)
   P.sp.span = span;
   for (uint32_t w = 0; w * span < P.sp.elem_stride; w++) {
     const uint32_t first = w * span, last = first + span - 1;
@@ -576,7 +576,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
         hi = std::max(hi, sc.elem_start + sc.lane_elems * sc.n_lanes);
       }
       const uint32_t first = lo / prog.sp.span, last = (hi + prog.sp.span - 1) / prog.sp.span;
-      if (prog.sp.span == 256 && last > first && (uint64_t)(last - first) * n_proofs < 0x7fffffffull) {
+      if (prog.sp.span == SER_SPAN_ELEMS && last > first && (uint64_t)(last - first) * n_proofs < 0x7fffffffull) {
         if (c->span_ctr_dirty) { HIPCK(c, hipMemsetAsync(c->d_span_ctr, 0, 256, s)); c->span_ctr_dirty = false; }
         fused.ctr = c->d_span_ctr + 32 * c->span_parity;  // (the two counters on lines of their own)
         fused.lut = reinterpret_cast<const uint32_t*>(c->d_lut[kind]); fused.wave_sec = reinterpret_cast<const uint8_t*>(c->d_wave_sec[kind]);

@@ -78,6 +78,10 @@ struct Section {
   uint32_t pad;
   const uint8_t* base;  // source buffer
 };
+#ifndef TMX_SER_SPAN
+#define TMX_SER_SPAN 256  // elements one serializer wave expands (SerializeProgram::span): TMX_SER_SPAN / 128 coalesced 16-byte stores per thread
+#endif
+constexpr uint32_t SER_SPAN_ELEMS = TMX_SER_SPAN;
 constexpr int MAX_SECTIONS = 12;
 struct SerializeProgram {
   Section sec[MAX_SECTIONS];

@@ -931,7 +931,7 @@ __global__ __launch_bounds__(TINY_THREADS) void k_tiny(TinyEd E, TinyProof PA, T
     const uint32_t r = b - E.n_lanes - proof_blocks;
     const uint32_t per = 2 * SA.n_blocks, proof = r / per, k = r - proof * per;
     const uint32_t span = __builtin_amdgcn_readfirstlane(SA.first_block * 4 + 2 * k + (threadIdx.x >> 6));
-    serialize_span<256>(SA.S, SA.lut, SA.wave_sec, SA.out, SA.mask, proof, span);
+    serialize_span<SER_SPAN_ELEMS>(SA.S, SA.lut, SA.wave_sec, SA.out, SA.mask, proof, span);
   }
 }
 
@@ -947,7 +947,7 @@ __global__ __launch_bounds__(TINY_TAIL_THREADS) void k_tiny_tail(TinyProof PA, T
     const uint32_t per = (SA.n_blocks + 3) / 4;  // workgroups per proof: sixteen spans = four span blocks each
     const uint32_t r = b - 2 * PA.n_proofs, proof = r / per, k = r - proof * per;
     const uint32_t span = __builtin_amdgcn_readfirstlane(SA.first_block * 4 + k * 16 + (threadIdx.x >> 6));
-    if (span < (SA.first_block + SA.n_blocks) * 4 && span < SA.tail_first_span) serialize_span<256>(S, SA.lut, SA.wave_sec, SA.out, SA.mask, proof, span);
+    if (span < (SA.first_block + SA.n_blocks) * 4 && span < SA.tail_first_span) serialize_span<SER_SPAN_ELEMS>(S, SA.lut, SA.wave_sec, SA.out, SA.mask, proof, span);
     return;
   }
   if (b >= PA.n_proofs) {  // seam spans in front of the dependent tail
