@@ -109,3 +109,59 @@ def test_mixed_sizes_back_to_back(built_lib, n):
             for j, (i, (o, r)) in enumerate(zip(seq, outs)):
                 assert torch.equal(r, want[i][1]), f"reports of call {j} of round {it} (sizes {[calls[k][0] for k in seq]})"
                 assert torch.equal(o, want[i][0]), f"rows of call {j} of round {it} (sizes {[calls[k][0] for k in seq]})"
+
+
+def test_two_contexts_on_one_device(built_lib):
+    """Two or three contexts of one device, each on a caller stream of its own, batches alternating without a synchronize (a host with a context
+    per worker thread): they share the device's three internal streams and nothing else -- rows and reports of every call equal the same batch
+    computed alone, and a context destroyed in between leaves the others intact.  (Correctness only: five streams on the runtime's four hardware
+    queues cost time -- 0.49 - 0.64 instead of 0.38 ms per 256-proof step, with or without making the contexts take turns by event:
+    profiles/r06_two_ctx_and_proof_chunk_ab.txt -- so INTEGRATION.md recommends one context per process and GPU.)"""
+    import torch
+    from tendermintx_amd import Context, KIND_SKIP
+    from tendermintx_amd.synth import bench_workload
+    dev = torch.device("cuda:0")
+    up = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    n = 128
+    shapes = [(130, 31), (24, 32), (256, 33)]     # (proofs, seed) per context: a split batch, a hash-first batch, the bench shape
+    ctxs, want = [], []
+    for P, seed in shapes:
+        w = bench_workload("survey8d", n, P, seed=seed)
+        c = Context(n, b"celestia", 100800, device=0, max_batch=P)
+        st = torch.cuda.Stream(dev)
+        d = tuple(up(b) for b in (w.proofs, w.targets, w.trusteds))
+        stride = c.elem_stride(KIND_SKIP)
+        ctxs.append((c, st, d, P, stride))
+    try:
+        def call(k, o, r):
+            c, st, d, P, _ = ctxs[k]
+            c.witness_batch_device(KIND_SKIP, P, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), o.data_ptr(), r.data_ptr(), st.cuda_stream)
+
+        def buffers(k):
+            _, _, _, P, stride = ctxs[k]
+            return torch.empty(P * stride, dtype=torch.int64, device=dev), torch.zeros(P * 64, dtype=torch.uint8, device=dev)
+
+        for k in range(len(ctxs)):     # every batch alone (twice: cold, warm), behind a synchronize
+            for _ in range(2):
+                o, r = buffers(k)
+                torch.cuda.synchronize(dev)
+                call(k, o, r)
+                torch.cuda.synchronize(dev)
+            want.append((o, r))
+        for it in range(12):
+            order = [(it + j) % len(ctxs) for j in range(6)]
+            outs = [buffers(k) for k in order]
+            torch.cuda.synchronize(dev)
+            for k, (o, r) in zip(order, outs):
+                call(k, o, r)
+            torch.cuda.synchronize(dev)
+            for j, (k, (o, r)) in enumerate(zip(order, outs)):
+                assert torch.equal(r, want[k][1]) and torch.equal(o, want[k][0]), f"call {j} of round {it} (context {k}, order {order})"
+            if it == 7:                # the context that enqueued last goes away
+                ctxs[order[-1]][0].close()
+                gone = order[-1]
+                ctxs = [x for i, x in enumerate(ctxs) if i != gone]
+                want = [x for i, x in enumerate(want) if i != gone]
+    finally:
+        for c, *_ in ctxs:
+            c.close()
