@@ -282,6 +282,7 @@ struct Knobs {
   int fused_base = -1, fused_walk = -1;  // TMX_FUSED_ROWS=<b>[,<w>]: input-only row spans a wave of s*B / of the resident walk takes per table addition
                                          // (fused rows, layout.h FusedRows); 0,0 = off: the sections as capped launches of their own (round 5); default: see run_batch
   long inputs_first_min = -1; // TMX_INPUTS_FIRST=<lanes>: from that many lanes on the split warm schedule enqueues the input sections IN FRONT of the new-key pipeline on the low-priority stream (0: never)
+  bool ser_rows = true;      // TMX_SER_ROWS=0: the capped row-writer launches grid-stride over (proof, block) (k_serialize_few, round 5) instead of proof-major (k_serialize_rows)
   int writer_prio = -1;      // TMX_WRITER_PRIO=<0..3>: s_setprio of the row-writer waves (default: by size, run_batch)
   int tail_aside_min = -1;   // TMX_TAIL_ASIDE_MIN=<lanes>: from how many lanes on the verdict + its sections leave the caller's stream (default 10240)
   int few_wgs = 0;           // TMX_FEW_WGS=<n>: workgroups of the serializer launches beside the chain (A/B; 0: by size, run_batch)
@@ -310,6 +311,7 @@ static Knobs read_knobs() {
   if ((v = std::getenv("TMX_FEW_WGS"))) k.few_wgs = std::atoi(v);
   if ((v = std::getenv("TMX_TAIL_ASIDE_MIN"))) k.tail_aside_min = std::atoi(v);
   if ((v = std::getenv("TMX_WRITER_PRIO"))) k.writer_prio = std::atoi(v);
+  k.ser_rows = !((v = std::getenv("TMX_SER_ROWS")) && v[0] == '0');
   if ((v = std::getenv("TMX_INPUTS_FIRST"))) k.inputs_first_min = std::atol(v);
   if ((v = std::getenv("TMX_FUSED_ROWS"))) {
     k.fused_base = std::atoi(v);
@@ -497,6 +499,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // 0.764 -> 0.741, 1.479 -> 1.422, 3.12 -> 2.81 ms.  (256 proofs: +1 % / +4.6 %: the latency regime keeps the round-5 form.)
   const uint64_t lanes_w = (uint64_t)n_proofs * c->cfg.n_max;
   prog.sp.wave_prio = K.writer_prio >= 0 ? (uint32_t)K.writer_prio : (lanes_w >= 65536 ? 3u : 0u);
+  prog.sp.rows_major = K.ser_rows ? 1u : 0u;
   auto serialize = [&](uint32_t mask, hipStream_t on, uint32_t max_wgs = 0) -> int32_t {
     if (!d_out_elems) return TMX_OK;
     // (sections the caller did not ask for are not written; the seam spans are few and always written)

@@ -643,7 +643,9 @@ KNOBS = [
     # pipeline, the writers' workgroup cap), the verdict's tail on / off the caller's stream, the fused rows at this size (no carrier: the sweeper alone)
     {"TMX_WRITER_PRIO": "3"}, {"TMX_INPUTS_FIRST": "1"}, {"TMX_INPUTS_FIRST": "1", "TMX_WRITER_PRIO": "3", "TMX_FEW_WGS": "8192"},
     {"TMX_INPUTS_FIRST": "1", "TMX_SCHEDULE": "warm", "TMX_TINY": "0"}, {"TMX_TAIL_ASIDE_MIN": "0"}, {"TMX_TAIL_ASIDE_MIN": "1000000"},
-    {"TMX_FUSED_ROWS": "4:2", "TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0"}]
+    {"TMX_FUSED_ROWS": "4:2", "TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0"},
+    # the capped row-writer launches grid-striding over (proof, block) as in round 5 instead of proof-major with the LUT words loaded once
+    {"TMX_SER_ROWS": "0"}, {"TMX_SER_ROWS": "0", "TMX_FEW_WGS": "100"}, {"TMX_FEW_WGS": "100"}, {"TMX_FEW_WGS": "700", "TMX_INPUTS_FIRST": "1"}]
 
 
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
