@@ -301,3 +301,34 @@ def test_validator_set_cache_evicts_least_recently_used(tmx, oracle, monkeypatch
                 e, _ = ctx.witness_batch(0, wl.proofs, targets[0], wl.trusteds)
                 after = ctx.set_cache_stats()
                 assert np.array_equal(e, want[0]) and after["computed"] == before["computed"] + P
+
+
+@pytest.mark.gpu
+def test_validator_set_cache_random_stream_through_a_tiny_cache(tmx, oracle, monkeypatch):
+    """LRU under churn: an 8-slot set cache (TMX_SET_CACHE_SETS) and 150 calls of 20 proofs drawn at random from 48 proofs over 48 different
+    target sets (and one trusted set): every call hits, misses, inserts, is refused and evicts in some mix -- every row of every call equals
+    the oracle's row of that proof (rows are per proof, so the oracle runs once per variant), and the counters stay consistent."""
+    from tendermintx_amd.synth import Workload
+    monkeypatch.setenv("TMX_SET_CACHE_SETS", "8")
+    n, V, P = 128, 48, 20
+    wl = Workload(0, n, V, 100, chain_id=b"celestia", seed=9200, signed_permille=900, n_sets=1)
+    t = bytearray(wl.targets)
+    for q in range(V):          # proof q: its own target set (one power word differs in lane q % 100)
+        off = (q * n + q % 100) * 256 + 224
+        t[off:off + 4] = (int.from_bytes(t[off:off + 4], "little") ^ (0x100 + q)).to_bytes(4, "little")
+    targets = bytes(t)
+    want, oreps = oracle.witness_batch(0, V, wl.proofs, targets, wl.trusteds, n, b"celestia", 100800, n_threads=8)
+    rng = np.random.default_rng(77)
+    with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+        for call in range(150):
+            hot = rng.integers(0, V, 3)                       # a few hot sets + a random rest: hits and misses in every call
+            pick = [int(hot[i % 3]) if rng.random() < 0.5 else int(rng.integers(0, V)) for i in range(P)]
+            pr = b"".join(wl.proofs[2336 * q:2336 * (q + 1)] for q in pick)
+            tg = b"".join(targets[256 * n * q:256 * n * (q + 1)] for q in pick)
+            tr = b"".join(wl.trusteds[48 * n * q:48 * n * (q + 1)] for q in pick)
+            e, reps = ctx.witness_batch(0, pr, tg, tr)
+            assert np.array_equal(e, want[pick]), (call, pick)
+            assert [r["all_ok"] for r in reps] == [oreps[q]["all_ok"] for q in pick]
+        s = ctx.set_cache_stats()
+        assert s["capacity"] == 8 and s["resident"] <= 8 and s["resident"] == s["inserted"] - s["evicted"] and s["evicted"] > 50
+        assert s["served"] > 0 and s["computed"] > 0
