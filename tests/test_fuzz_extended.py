@@ -212,4 +212,6 @@ def test_big_mutated_batch(tmx, oracle, n_proofs):
     proofs = b"".join(p[0] for p in parts)[:n_proofs * 2336]
     targets = b"".join(p[1] for p in parts)[:n_proofs * n * 256]
     trusteds = b"".join(p[2] for p in parts)[:n_proofs * n * 48]
-    _check_vs_oracle(tmx, oracle, kind0, n, proofs, targets, trusteds, b"celestia", threads=16)
+    # (cold, then warm on the same context: the split schedule, the proof-major capped row writer and -- from 512 proofs on -- the throughput
+    # regime's settings see the hostile inputs as well)
+    _check_vs_oracle(tmx, oracle, kind0, n, proofs, targets, trusteds, b"celestia", threads=16, repeat=int(os.environ.get("TMX_FUZZ_BIG_REPEAT", "2")))
