@@ -56,6 +56,11 @@ def parse_args(argv=None):
     ap.add_argument("--workload", choices=("survey8d", "one_set"), default="survey8d")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (profiling runs)")
+    ap.add_argument("--other-scaling", action="store_true",
+                    help="more than one GPU: after the timed region also run the scaling mode the command line did not ask for (strong: one batch sharded "
+                         "through tmx_witness_batch_sharded_device without / with the row exchange, the sharded Level-2 rows).  Off by default: these are "
+                         "collective calls that have only run through the stand-in RCCL (tests/test_world2_one_gpu.py), and the scaling record of the "
+                         "driver's run must not depend on them")
     return ap.parse_args(argv)
 
 
@@ -203,7 +208,22 @@ def main():
     d_out = torch.empty((rows_buf, stride), dtype=torch.int64, device=dev)
     d_rep = torch.zeros(rows_buf * 64, dtype=torch.uint8, device=dev)
     gather = args.gather and world > 1
-    comm_world = sharding.connect(ctx)[1] if (use_dist and (not share_gpu or share_gpu_comm)) else 1
+    comm_world, comm_error = 1, None
+    need_comm = args.scaling == "strong" or args.other_scaling   # (weak scaling alone has no data-path collective: no libtmx communicator at all)
+    if use_dist and need_comm and (not share_gpu or share_gpu_comm):
+        try:
+            comm_world = sharding.connect(ctx)[1]
+        except Exception as e:   # (weak scaling has no data-path collective: a communicator that cannot be made must not cost the scaling record)
+            if args.scaling == "strong":
+                raise
+            comm_error = repr(e)[:200]
+        # every rank must agree on whether the communicator exists (the strong-scaling extras below are collective calls)
+        flag = torch.tensor([0 if comm_error else 1], device="cpu" if share_gpu else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and comm_error is None:
+            comm_error = "another rank could not create its communicator"
+        if comm_error:
+            comm_world = 1
 
     def run(c, k, bufs=None, n_proofs=None):
         dp, dt, dr = bufs or (d_proofs, d_targets, d_trusteds)
@@ -302,14 +322,14 @@ def main():
                             "nothing on this path is a dense contraction (no MFMA)"}
         result["roofline"] = roofline
 
-        result["rccl"] = {"torch_world": world, "libtmx_comm_world": comm_world,
+        result["rccl"] = {"torch_world": world, "libtmx_comm_world": comm_world, **({"comm_error": comm_error} if comm_error else {}),
                           "note": "the data-path exchange (strong scaling with --gather, --mode c5) is RCCL inside libtmx (tmx_comm_create); torch.distributed "
                                   "carries the unique id, the barriers and the max over ranks"}
         if not args.no_extras and world == 1:
             extras(args, result, roofline, ctx, run, wl_all, n, P, stride, count, dev, stream, d_out, d_rep, dev_bytes, kms, ms_per_step, alg_bytes)
     # ---- more than one GPU: the OTHER scaling of the same record (a SCALE run of the default command then carries both the weak-scaled value
     # and BASELINE configs[3] as written: 256 proofs sharded over the ranks, without and with the row exchange)
-    if world > 1 and not args.no_extras and (not share_gpu or share_gpu_comm):
+    if world > 1 and args.other_scaling and not args.no_extras and (not share_gpu or share_gpu_comm) and comm_error is None:
         other = both_scalings(args, ctx if args.scaling == "strong" else None, n, world, rank, local_rank, dev, stream, dev_bytes, barrier, max_over_ranks)
         if rank == 0:
             result["other_scaling"] = other

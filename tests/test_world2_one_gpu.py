@@ -114,16 +114,19 @@ def test_bench_py_at_world_2_on_one_gpu(built_lib, fake_rccl, tmp_path):
         line = r.stdout.strip().split("\n")[-1]
         assert len(line) < 8192, len(line)
         rec = json.loads(line)
-        assert rec["n_gpus"] == 2 and rec["debug_shared_gpu"] and rec["rccl"]["libtmx_comm_world"] == 2 and rec["all_proofs_ok"], line
+        assert rec["n_gpus"] == 2 and rec["debug_shared_gpu"] and rec["all_proofs_ok"], line
+        assert rec["rccl"]["libtmx_comm_world"] == (2 if ("--other-scaling" in extra or "--mode" in extra or "strong" in extra) else 1), line
         assert rec["roofline"]["frac"] > 0 and rec["ms_per_step"] > 0
         return rec
 
-    weak = run()                                   # the driver's command shape: weak scaling + the other scaling of the same record
+    plain = run()                                  # the driver's command shape: weak scaling, no data-path collective, nothing else
+    assert plain["scaling"] == "weak" and "other_scaling" not in plain and plain["config"]["proofs_total"] == 32
+    weak = run("--other-scaling")                  # + the other scaling of the same record
     assert weak["scaling"] == "weak" and weak["config"]["proofs_total"] == 32
     o = weak["other_scaling"]
     assert o["strong"]["libtmx_comm_world"] == 2 and o["strong"]["proofs_per_gpu"] == 8 and o["strong_with_row_exchange"]["ms_per_step"] > 0
     assert "error" not in o.get("level2_trace_rows", {}) and o["level2_trace_rows_with_exchange"]["ms_per_step"] > 0
-    strong = run("--scaling", "strong", "--gather")  # BASELINE configs[3] as written, the row exchange inside the step
+    strong = run("--scaling", "strong", "--gather", "--other-scaling")  # BASELINE configs[3] as written, the row exchange inside the step
     assert strong["scaling"] == "strong" and strong["config"]["proofs_per_gpu"] == 8 and strong["gather_rows"]["bytes_per_rank_out"] > 0
     assert strong["other_scaling"]["weak"]["proofs_total"] == 32
     c5 = run("--mode", "c5", "--n-max", "128")     # BASELINE configs[4]'s code path (one proof, lanes sharded), at a size that is quick
