@@ -258,6 +258,7 @@ Program build_program(int kind, uint32_t n) {
 
 // ------------------------------------------------------------------------------------------------ context
 constexpr int EV_RING_DECL = 128;
+constexpr uint64_t THROUGHPUT_LANES = 98304;  // proofs x validators from which run_batch schedules for throughput (see beside_chain_wgs)
 // Schedule knobs, read ONCE at context creation (getenv is not safe against a concurrent setenv, and the enqueue path is
 // latency-critical).  Each selects a schedule, never a value (tests/test_gpu_parity.py::test_schedule_knobs_give_the_same_bits); the A/B
 // harness that measured the alternatives no longer in the product lives in tools/ (DESIGN.md appendix "measured and dropped").
@@ -525,13 +526,19 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // (round 6, profiles/r06_writer_cap_sweep.txt: from 1024 proofs on -- where the leaves go first and the step is the sum of a VALU-bound chain
   // and an HBM-bound tail -- 8192 workgroups: 1024 / 1280 / 1536 proofs 1.557 -> 1.455, 2.008 -> 1.890, 2.358 -> 2.145 ms, 2048 proofs flat;
   // 512 to 1023 proofs 1536 instead of 1024: 640 / 768 / 896 proofs 1.11 -> 0.98, 1.164 -> 1.116, 1.332 -> 1.315 ms, 512 proofs unchanged)
-  const uint32_t beside_chain_wgs = K.few_wgs > 0 ? (uint32_t)K.few_wgs : (lanes_bc >= 131072 ? 8192u : (lanes_bc >= 65536 ? 1536u : (lanes_bc > 16384 ? 2048u : 1024u)));  // (warm key cache, 256 proofs: 2048 / 4096 / uncapped +10 / +4 / +2 %)
+  // (round 6, with the proof-major writer k_serialize_rows, profiles/r06_writer_cap_sweep2.txt: persistent writers hold their wave slots for
+  // the whole launch and the chain's kernels wait for a slot; 32768 short-lived workgroups instead of 8192: 1024 / 1536 / 2048 proofs
+  // 1.42 -> 1.28, 2.06 -> 1.91, 2.81 -> 2.59 ms; 65536: the same; 131072 and uncapped: +6 ... +10 %.  The whole throughput regime -- this cap,
+  // the input sections first, the leaves first, D.1a early -- from THROUGHPUT_LANES = 98304 on: 768 / 896 proofs 1.08 -> 1.05, 1.25 -> 1.20 ms;
+  // 512 / 640 proofs within +-2 % either way and left as they were)
+  const bool throughput = lanes_bc >= THROUGHPUT_LANES;
+  const uint32_t beside_chain_wgs = K.few_wgs > 0 ? (uint32_t)K.few_wgs : (throughput ? 32768u : (lanes_bc >= 65536 ? 1536u : (lanes_bc > 16384 ? 2048u : 1024u)));  // (warm key cache, 256 proofs: 2048 / 4096 / uncapped +10 / +4 / +2 %)
   // Leaves first (TMX_LEAVES=1|0, default by size): marshalled validators + leaf hashes as a 10-us launch of their own in front of k_proof,
   // so that the byte fields of the two per-lane derived sections (D.2a: the leaves; D.1a: the leaves + phase 1 -- 42 % of a skip row) are
   // written by the low-priority stream behind the input sections instead of behind k_proof (which ends at ~300 us inside a step) / k_ed_fin.
   // Measured at N = 128: -5 % step at 1024 proofs (on top of the -6 % of D.1a behind k_proof's sections), but +1.5 % at 256, +4.5 % at 512,
   // +8 % at 64: below ~1000 proofs every extra concurrent launch stretches the EdDSA chain by more than the tail it removes.
-  const bool leaves_first = K.ser_split && d_out_elems && (K.leaves >= 0 ? K.leaves != 0 : (uint64_t)n_proofs * n >= 131072);
+  const bool leaves_first = K.ser_split && d_out_elems && (K.leaves >= 0 ? K.leaves != 0 : throughput);
   // side: k_proof first -- for a single proof it IS the critical path, and every API call in front of its launch is latency --, its two
   // timing events on the dispatch itself; then the sections that only need its results
   const bool xp = K.ext_events && !leaves_first;
@@ -604,7 +611,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     HIPCK(c, hipEventRecord(c->ev_join3, c->side3));
     return TMX_OK;
   };
-  const bool inputs_first = K.inputs_first_min >= 0 ? (K.inputs_first_min > 0 && lanes_bc >= (uint64_t)K.inputs_first_min) : lanes_bc >= 131072;
+  const bool inputs_first = K.inputs_first_min >= 0 ? (K.inputs_first_min > 0 && lanes_bc >= (uint64_t)K.inputs_first_min) : throughput;
   const bool defer3 = c->plan.split && !inputs_first;
   if (!defer3 && (st0 = side3_inputs())) return st0;
 
@@ -667,7 +674,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // k_proof's sections on the side stream, i.e. while the table walk and the finish run.  Measured (round 2): -6.3 % step at 1024
   // proofs x 128; +-0.5 % at 256 and 64, +1 ... +2 % at 512 proofs (and +7 % at 256 with a warm key cache): on from 131072 lanes
   const bool p1_early = leaves_first || small_tail ||
-                        (K.ser_split && c->ev_hash_recorded && (K.p1_early >= 0 ? K.p1_early != 0 : (uint64_t)n_proofs * n >= 131072));
+                        (K.ser_split && c->ev_hash_recorded && (K.p1_early >= 0 ? K.p1_early != 0 : throughput));
   if (p1_early && !leaves_first && !small_tail) {
     HIPCK(c, hipStreamWaitEvent(c->side, c->ev_hash, 0));
     if ((st0 = serialize(prog.mask_p1, c->side, K.p1_early == 2 ? 0u : beside_chain_wgs))) return st0;

@@ -772,7 +772,7 @@ def test_key_dedup_paths(tmx, oracle):
         assert ctx.last_dedup() == (16, True)
 
 
-@pytest.mark.parametrize("P", [640, 1024])
+@pytest.mark.parametrize("P", [640, 768, 1024])
 def test_throughput_regime_all_rows(tmx, oracle, P):
     """The schedule of the throughput regime (round 6: from 512 proofs x 128 the row writers run at wave priority 3 with 1536 workgroups beside the
     chain; from 1024 proofs the input sections go in front of the new-key pipeline, 8192 workgroups, the leaves first): the bench workload at 640
