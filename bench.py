@@ -105,6 +105,7 @@ def main():
     # ... together with TMX_RCCL_LIB=<tests/fake_rccl>: libtmx's own communicator is made at world > 1 too (real RCCL refuses two ranks on one
     # device), so that the strong-scaling / row-exchange / --mode c5 code of this file runs before a real node runs it (tests/test_world2_one_gpu.py)
     share_gpu_comm = share_gpu and bool(os.environ.get("TMX_RCCL_LIB"))
+    control_cpu = share_gpu  # the control plane's tensors live on the CPU (gloo)
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -116,7 +117,22 @@ def main():
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # the control plane (barriers, max over ranks, the unique id) over RCCL; its first collective runs HERE so that a broken RCCL
+            # shows as an exception in front of the timed region -- the control plane then falls back to gloo (no data-path collective is
+            # part of the weak-scaled step; the line's rccl.control_backend says which one carried the barriers)
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize(dev)
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all_reduce over {world} ranks gave {probe.item()}")
+            except Exception as e:  # noqa: BLE001
+                print(f"warning: rank {rank}: RCCL control plane failed ({type(e).__name__}: {str(e)[:200]}); falling back to gloo", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                control_cpu = True
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
@@ -133,7 +149,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cpu" if share_gpu else dev)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if control_cpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -218,7 +234,7 @@ def main():
                 raise
             comm_error = repr(e)[:200]
         # every rank must agree on whether the communicator exists (the strong-scaling extras below are collective calls)
-        flag = torch.tensor([0 if comm_error else 1], device="cpu" if share_gpu else dev)
+        flag = torch.tensor([0 if comm_error else 1], device="cpu" if control_cpu else dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0 and comm_error is None:
             comm_error = "another rank could not create its communicator"
@@ -265,7 +281,7 @@ def main():
     row0 = lo if (args.scaling == "strong" and comm_world > 1) else 0   # (strong: this rank's rows sit at their place in the full-size buffer)
     rep = d_rep.cpu().numpy().reshape(-1, 64)[row0:row0 + P]
     all_ok = int(rep[:, 32:36].copy().view(np.uint32).sum())
-    ok_flag = torch.tensor([1 if all_ok == P else 0], device="cpu" if share_gpu else dev)
+    ok_flag = torch.tensor([1 if all_ok == P else 0], device="cpu" if control_cpu else dev)
     if world > 1:
         dist.all_reduce(ok_flag, op=dist.ReduceOp.MIN)
 
@@ -323,6 +339,7 @@ def main():
         result["roofline"] = roofline
 
         result["rccl"] = {"torch_world": world, "libtmx_comm_world": comm_world, **({"comm_error": comm_error} if comm_error else {}),
+                          "control_backend": (dist.get_backend() if use_dist and dist.is_initialized() else None),
                           "note": "the data-path exchange (strong scaling with --gather, --mode c5) is RCCL inside libtmx (tmx_comm_create); torch.distributed "
                                   "carries the unique id, the barriers and the max over ranks"}
         if not args.no_extras and world == 1:
@@ -423,7 +440,7 @@ def compact_line(full):
                                     "lde_frac_1r1w": v.get("lde_stage", {}).get("frac_1r1w"), "gperm_per_s": v.get("merkle_stage", {}).get("gperm_per_s")}
                                 for k, v in cp.items() if k in ("sha512", "ladders")}
     if "rccl" in full:
-        c["rccl"] = pick(full["rccl"], "torch_world", "libtmx_comm_world", "backend")
+        c["rccl"] = pick(full["rccl"], "torch_world", "libtmx_comm_world", "backend", "control_backend", "comm_error")
     if "gather_rows" in full:
         c["gather_rows"] = pick(full["gather_rows"], "ms", "bytes_per_rank_out")
     if "other_scaling" in full:
