@@ -416,6 +416,8 @@ def compact_line(full):
         c["memoized"] = {"lanes_that_did_not_sign": full["memoized"].get("lanes_that_did_not_sign"), "set_cache": full["memoized"]["validator_set_cache"]}
     if "batch_sizes_ms" in full:
         c["batch_sizes_ms"] = full["batch_sizes_ms"]
+    if "batch_sizes_frac" in full:
+        c["batch_sizes_frac"] = full["batch_sizes_frac"]
     if "single_proof" in full:
         c["single_proof"] = pick(full["single_proof"], "device_ms", "device_ms_cold", "host_to_host_ms", "host_to_host_typed_value_ms")
     if "typed_value" in full and "batch" in full["typed_value"]:
@@ -448,7 +450,7 @@ def compact_line(full):
                               for k, v in full["other_scaling"].items() if k != "note"}
     c["extras"] = "bench_extras.json"
     # never over the cap: shed the secondary objects, least important first
-    for k in ("commit_pipeline", "best_case", "survey8d", "memoized", "kernels_ms", "other_scaling", "level2", "typed_value", "batch_sizes_ms", "single_proof"):
+    for k in ("commit_pipeline", "best_case", "survey8d", "memoized", "kernels_ms", "other_scaling", "level2", "typed_value", "batch_sizes_frac", "batch_sizes_ms", "single_proof"):
         if len(json.dumps(c)) <= LINE_CAP:
             break
         c.pop(k, None)
@@ -597,6 +599,8 @@ def extras(args, result, roofline, ctx, run, wl, n, P, stride, count, dev, strea
                 cb.close()
             del bb
         result["batch_sizes_ms"] = sizes
+        # the same sizes as fractions of the HBM roof (SURVEY 8d bytes of that many proofs / host clock / 8 TB/s): the throughput regime's figure
+        result["batch_sizes_frac"] = {k: (round(gbs(alg_bytes * int(k) // P, v) / HBM_PEAK_GBS, 4) if v else None) for k, v in sizes.items()}
         run(ctx, 3)   # (the timed batch resident again)
     except Exception as e:
         result["batch_sizes_ms"] = {"error": repr(e)[:200]}
