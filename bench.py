@@ -114,13 +114,16 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
-        if share_gpu:
+        fail_control = os.environ.get("TMX_BENCH_FAIL_RCCL_CONTROL") == "1"  # (test hook: the fallback below on a 1-GPU box)
+        if share_gpu and not fail_control:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             # the control plane (barriers, max over ranks, the unique id) over RCCL; its first collective runs HERE so that a broken RCCL
             # shows as an exception in front of the timed region -- the control plane then falls back to gloo (no data-path collective is
             # part of the weak-scaled step; the line's rccl.control_backend says which one carried the barriers)
             try:
+                if fail_control:
+                    raise RuntimeError("TMX_BENCH_FAIL_RCCL_CONTROL=1")
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
                 probe = torch.ones(1, device=dev)
                 dist.all_reduce(probe)

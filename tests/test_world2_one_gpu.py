@@ -103,14 +103,16 @@ def test_bench_py_at_world_2_on_one_gpu(built_lib, fake_rccl, tmp_path):
     import socket
     env = dict(os.environ, TMX_RCCL_LIB=fake_rccl, FAKE_RCCL_DIR=str(tmp_path), TMX_BENCH_SHARE_GPU="1", TMX_BENCH_NO_PMC="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
 
-    def run(*extra):
+    def run(*extra, more_env=None):
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--proofs", "16", "--no-cpu-baseline", *extra]
-        r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+        r = subprocess.run(cmd, env=dict(env, **(more_env or {})), cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        if more_env:
+            assert "falling back to gloo" in r.stderr, r.stderr[-2000:]
         line = r.stdout.strip().split("\n")[-1]
         assert len(line) < 8192, len(line)
         rec = json.loads(line)
@@ -121,6 +123,9 @@ def test_bench_py_at_world_2_on_one_gpu(built_lib, fake_rccl, tmp_path):
 
     plain = run()                                  # the driver's command shape: weak scaling, no data-path collective, nothing else
     assert plain["scaling"] == "weak" and "other_scaling" not in plain and plain["config"]["proofs_total"] == 32
+    assert plain["rccl"]["control_backend"] == "gloo"
+    fb = run(more_env={"TMX_BENCH_FAIL_RCCL_CONTROL": "1"})  # the control plane's RCCL fails in front of the timed region: gloo carries the barriers
+    assert fb["rccl"]["control_backend"] == "gloo" and fb["scaling"] == "weak" and fb["config"]["proofs_total"] == 32
     weak = run("--other-scaling")                  # + the other scaling of the same record
     assert weak["scaling"] == "weak" and weak["config"]["proofs_total"] == 32
     o = weak["other_scaling"]
