@@ -3,6 +3,8 @@ same batch computed alone: the schedule's cross-stream joins (four streams, the 
 resident lanes, the dedup beside the hash role of small batches) order every kernel against the NEXT call's kernels too.  Batches with and
 without new keys alternate, the key cache is flushed now and then; rows and reports are compared bit for bit.  (The batches themselves are
 checked against the oracle in test_gpu_parity.py / test_key_cache.py; this test is about ordering.)"""
+import os
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -63,7 +65,8 @@ def test_mixed_sizes_back_to_back(built_lib, n):
     from tendermintx_amd.synth import Workload, bench_workload
     dev = torch.device("cuda:0")
     up = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
-    sizes = [1, 2, 24, 256, 3, 40, 130]
+    sizes = [1, 2, 24, 256, 3, 40, 130] + ([800] if n == 128 else [])   # (800 x 128 lanes: the throughput regime's schedule, api.cpp THROUGHPUT_LANES)
+    rounds = int(os.environ.get("TMX_SOAK_ROUNDS", "40"))                # (a soak: TMX_SOAK_ROUNDS=3000)
     Pmax = max(sizes)
     base = bench_workload("survey8d", n, Pmax, seed=77 + n)
     fresh = [Workload(0, n, 3, min(n, 90), chain_id=b"celestia", seed=8100 + 17 * k + n, signed_permille=950, n_sets=3) for k in range(2)]
@@ -95,8 +98,10 @@ def test_mixed_sizes_back_to_back(built_lib, n):
             torch.cuda.synchronize(dev)
             want.append((o, r))
         rng = np.random.default_rng(5 + n)
-        for it in range(40):
+        for it in range(rounds):
             seq = [int(x) for x in rng.integers(0, len(calls), 6)]
+            if it % 8 == 4 and 800 in sizes:   # across the regime boundary and back: large split -> throughput regime -> tiny -> throughput regime -> hash-first split
+                seq = [sizes.index(256) * 3, sizes.index(800) * 3 + (it // 8) % 3, sizes.index(1) * 3, sizes.index(800) * 3, sizes.index(40) * 3 + 1, sizes.index(800) * 3 + 2]
             if it % 4 == 0:   # the transitions named above, in order: tiny -> hash-first split -> large split -> tiny -> hash-first split
                 seq = [sizes.index(1) * 3, sizes.index(24) * 3 + (it // 4) % 3, sizes.index(256) * 3, sizes.index(2) * 3 + 1, sizes.index(40) * 3, sizes.index(130) * 3 + 2]
             outs = [buffers(calls[i][0]) for i in seq]
