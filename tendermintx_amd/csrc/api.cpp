@@ -273,6 +273,7 @@ struct Knobs {
   int warm_schedule = -1;    // TMX_SCHEDULE=warm|cold: the EdDSA schedule for resident / new keys (default: by what the last launch saw)
   int phase1_max = -1;       // TMX_PHASE1_MAX=<lanes>: up to that many lanes the warm schedule runs s*B as a role of the hash launch (default 16384: 128 proofs at N = 128)
   bool proof_roles = true;   // TMX_PROOF_ROLES=0: k_proof as one workgroup per proof (the round-3 kernel) instead of four role workgroups
+  int tail_wide = 1;         // TMX_TAIL_WIDE=0: k_verdict -> D.5 -> the seam spans as three launches (rounds 2 - 5) instead of ONE launch of independent workgroups (k_verdict_tail_wide)
   int p1_early = -1;         // TMX_P1_EARLY=0|1|2: D.1a behind k_proof's sections on the side stream (1: on a capped grid, 2: full grid) instead of behind k_ed_fin (default: capped, from 131072 lanes)
   int hash_first = -1;       // TMX_HASH_FIRST=0|1: warm schedule with the hash role in front of the dedup (which moves to side2); default: see run_eddsa
   bool walk_split = true;    // TMX_WALK_SPLIT=0: the warm schedule's table walk as ONE launch behind the table build (the round-4 form) instead of resident lanes at once + new-key lanes behind the build
@@ -305,6 +306,7 @@ static Knobs read_knobs() {
   k.proof_roles = !((v = std::getenv("TMX_PROOF_ROLES")) && v[0] == '0');
   if ((v = std::getenv("TMX_PHASE1_MAX"))) k.phase1_max = std::atoi(v);
   k.hash_first = (v = std::getenv("TMX_HASH_FIRST")) ? (v[0] != '0' ? 1 : 0) : -1;
+  if ((v = std::getenv("TMX_TAIL_WIDE"))) k.tail_wide = v[0] != '0' ? 1 : 0;
   k.p1_early = (v = std::getenv("TMX_P1_EARLY")) && v[0] >= '0' && v[0] <= '2' ? v[0] - '0' : -1;
   k.compact = !((v = std::getenv("TMX_COMPACT")) && v[0] == '0');
   k.set_cache = !((v = std::getenv("TMX_SET_CACHE")) && v[0] == '0');
@@ -679,6 +681,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     HIPCK(c, hipStreamWaitEvent(c->side, c->ev_hash, 0));
     if ((st0 = serialize(prog.mask_p1, c->side, K.p1_early == 2 ? 0u : beside_chain_wgs))) return st0;
   }
+
   HIPCK(c, hipStreamWaitEvent(c->side, c->ev_join3, 0));  // ev_join = both low-priority streams done
   HIPCK(c, hipEventRecord(c->ev_join, c->side));
   if (!c->fin_done_attached) HIPCK(c, hipEventRecord(ev[1], s));
@@ -702,11 +705,22 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     // between k_ed_fin and the serializer is latency on the critical path.)
     HIPCK(c, hipStreamWaitEvent(c->side2, ev[1], 0));
     HIPCK(c, hipStreamWaitEvent(c->side2, evs[1], 0));  // k_proof itself, not the serializer launches queued behind it
+    if (K.tail_wide && n_proofs) {
+      const bool xv = K.ext_events;
+      if (!xv) HIPCK(c, hipEventRecord(evs[2], c->side2));
+      const uint32_t tail_mask = prog.mask_tail & (((c->sections & TMX_SEC_HINT) ? prog.mask_hint : 0u) | ((c->sections & TMX_SEC_DERIVED) ? prog.mask_derived : 0u) | (1u << 31));
+      rc = launch_verdict_tail_wide((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, row, prog.sp, src, c->d_lut[kind], c->d_wave_sec[kind],
+                                    c->d_seams[kind], (uint32_t)prog.seam_waves.size(), d_out_elems, tail_mask, prog.tail_dep_elem, c->side2,
+                                    xv ? evs[2] : nullptr, xv ? evs[3] : nullptr);
+      if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict_tail_wide launch: ") + hipGetErrorString((hipError_t)rc));
+      if (!xv) HIPCK(c, hipEventRecord(evs[3], c->side2));
+    } else {
     HIPCK(c, hipEventRecord(evs[2], c->side2));
     rc = launch_verdict((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, row, c->side2);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict launch: ") + hipGetErrorString((hipError_t)rc));
     HIPCK(c, hipEventRecord(evs[3], c->side2));
     if ((st0 = serialize(prog.mask_tail, c->side2))) return st0;
+    }
     HIPCK(c, hipStreamWaitEvent(c->side2, c->ev_join, 0));  // ev_tail = every side stream done
     HIPCK(c, hipEventRecord(c->ev_tail, c->side2));
     if (mask_final | (p1_early ? 0u : prog.mask_p1)) {

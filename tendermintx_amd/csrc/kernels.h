@@ -96,6 +96,12 @@ int launch_verdict(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_e
 int launch_verdict_tail(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_ed, uint32_t ed_stride, void* d_pf, void* d_reports, const RowOut& row,
                         const SerializeProgram& S, const SerializeSources& src, const void* d_lut, const void* d_seam_waves, uint32_t n_seams, void* d_out,
                         uint32_t sec_mask, void* stream, void* started = nullptr, void* done = nullptr);
+// any batch size: k_verdict, the spans of the sections in sec_mask in front of the first element that depends on the verdict, the seam spans and
+// the dependent end of the row in ONE launch of independent workgroups (k_verdict_tail_wide)
+int launch_verdict_tail_wide(uint32_t kind, uint32_t n, uint32_t n_proofs, const void* d_ed, uint32_t ed_stride, void* d_pf, void* d_reports,
+                             const RowOut& row, const SerializeProgram& S, const SerializeSources& src, const void* d_lut, const void* d_wave_sec,
+                             const void* d_seam_waves, uint32_t n_seams, void* d_out, uint32_t sec_mask, uint32_t tail_dep_elem, void* stream,
+                             void* started = nullptr, void* done = nullptr);
 // LRU eviction of the validator-set cache (layout.h SetCache): one workgroup behind a k_proof launch on its stream
 int launch_setc_evict(const SetCache& SC, uint32_t epoch, void* stream);
 SerializeProgram resolve_serialize_program(const SerializeProgram& S, const SerializeSources& src);

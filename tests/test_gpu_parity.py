@@ -645,7 +645,11 @@ KNOBS = [
     {"TMX_INPUTS_FIRST": "1", "TMX_SCHEDULE": "warm", "TMX_TINY": "0"}, {"TMX_TAIL_ASIDE_MIN": "0"}, {"TMX_TAIL_ASIDE_MIN": "1000000"},
     {"TMX_FUSED_ROWS": "4:2", "TMX_SCHEDULE": "warm", "TMX_PHASE1_MAX": "0"},
     # the capped row-writer launches grid-striding over (proof, block) as in round 5 instead of proof-major with the LUT words loaded once
-    {"TMX_SER_ROWS": "0"}, {"TMX_SER_ROWS": "0", "TMX_FEW_WGS": "100"}, {"TMX_FEW_WGS": "100"}, {"TMX_FEW_WGS": "700", "TMX_INPUTS_FIRST": "1"}]
+    {"TMX_SER_ROWS": "0"}, {"TMX_SER_ROWS": "0", "TMX_FEW_WGS": "100"}, {"TMX_FEW_WGS": "100"}, {"TMX_FEW_WGS": "700", "TMX_INPUTS_FIRST": "1"},
+    # verdict + D.5 + the seam spans as one launch of independent workgroups (k_verdict_tail_wide) / as three launches, alone and with D.1a
+    # early / the tail never on the caller's stream
+    {"TMX_TAIL_WIDE": "1"}, {"TMX_TAIL_WIDE": "0"}, {"TMX_TAIL_WIDE": "1", "TMX_P1_EARLY": "2"}, {"TMX_TAIL_WIDE": "0", "TMX_TAIL_ASIDE_MIN": "0", "TMX_TINY": "0"},
+    {"TMX_TAIL_WIDE": "1", "TMX_TAIL_ASIDE_MIN": "0", "TMX_TINY": "0"}]
 
 
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
