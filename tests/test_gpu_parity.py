@@ -549,6 +549,39 @@ def test_section_selection_and_u32_transfer_format(tmx, oracle):
                 ctx.witness_batch_opts(kind, wl.proofs, wl.targets, wl.trusteds, 4, "u64")
 
 
+@pytest.mark.parametrize("kind, n, P", [(0, 128, 96), (1, 64, 200)])
+def test_section_selection_on_the_large_path(tmx, oracle, kind, n, P):
+    """The device entry point with a section selection above the small-tail threshold (> 10 240 lanes: the tail is k_verdict_tail_wide on the
+    high-priority stream): the selected section equals the full row's, the other one keeps the caller's fill except for the seam spans (whole
+    spans of 256 elements that straddle a section boundary or the row end: always written, with the right values)."""
+    import torch
+    from tendermintx_amd import _lib
+    from tendermintx_amd.synth import Workload
+    wl = Workload(kind, n, P, max(1, n - 5), chain_id=b"celestia", seed=4100 + n, signed_permille=930, n_sets=3)
+    want, oreps = oracle.witness_batch(kind, P, wl.proofs, wl.targets, wl.trusteds, n, b"celestia", 100800, n_threads=16)
+    dev = torch.device("cuda", 0)
+    d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) if b else None for b in (wl.proofs, wl.targets, wl.trusteds)]
+    with tmx.Context(n, b"celestia", max_batch=P) as ctx:
+        hint, count, stride = ctx.hint_elem_count(kind), ctx.elem_count(kind), ctx.elem_stride(kind)
+        for sections, lo, hi in ((_lib.SEC_HINT, 0, hint), (_lib.SEC_DERIVED, hint, count), (_lib.SEC_ALL, 0, count)):
+            out = torch.full((P, stride), -1, dtype=torch.int64, device=dev)
+            rep = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
+            for _ in range(2):  # (cold, then warm: both schedules)
+                ctx.witness_batch_device_sections(kind, P, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr() if d[2] is not None else None,
+                                                  out.data_ptr(), rep.data_ptr(), sections, 0)
+            torch.cuda.synchronize(dev)
+            o = out.cpu().numpy()
+            assert np.array_equal(o[:, lo:hi].view(np.uint64), want[:, lo:hi]), (kind, n, sections)
+            other = np.ones(count, dtype=bool)
+            other[lo:hi] = False
+            written = (o[:, :count] != -1) & other[None, :]
+            # whatever was written outside the selection has the row's value, and it is a small share (seam spans only)
+            assert np.array_equal(o[:, :count].view(np.uint64)[written], want[written]), (kind, n, sections)
+            assert sections == _lib.SEC_ALL or written.mean() < 0.05, (kind, n, sections, float(written.mean()))
+            reps = np.frombuffer(rep.cpu().numpy().tobytes(), dtype=np.uint32).reshape(P, 16)
+            assert [int(r[8]) for r in reps] == [int(bool(x["all_ok"])) for x in oreps]
+
+
 def test_device_path_flags_nb_above_n(tmx, oracle):
     """The device entry points cannot refuse nb > N before enqueueing (the records are in HBM): tmx_report.precond carries the host
     assert of input/mod.rs:439-444 / 338-342 instead, and the values follow the circuit (every lane enabled)."""
