@@ -273,7 +273,7 @@ struct Knobs {
   int warm_schedule = -1;    // TMX_SCHEDULE=warm|cold: the EdDSA schedule for resident / new keys (default: by what the last launch saw)
   int phase1_max = -1;       // TMX_PHASE1_MAX=<lanes>: up to that many lanes the warm schedule runs s*B as a role of the hash launch (default 16384: 128 proofs at N = 128)
   bool proof_roles = true;   // TMX_PROOF_ROLES=0: k_proof as one workgroup per proof (the round-3 kernel) instead of four role workgroups
-  int tail_wide = 1;         // TMX_TAIL_WIDE=0: k_verdict -> D.5 -> the seam spans as three launches (rounds 2 - 5) instead of ONE launch of independent workgroups (k_verdict_tail_wide)
+  int tail_wide = 1;         // TMX_TAIL_WIDE=0: k_verdict -> D.5 -> the seam spans as three launches / one workgroup per proof (rounds 2 - 5) instead of ONE launch of independent workgroups (k_verdict_tail_wide)
   int p1_early = -1;         // TMX_P1_EARLY=0|1|2: D.1a behind k_proof's sections on the side stream (1: on a capped grid, 2: full grid) instead of behind k_ed_fin (default: capped, from 131072 lanes)
   int hash_first = -1;       // TMX_HASH_FIRST=0|1: warm schedule with the hash role in front of the dedup (which moves to side2); default: see run_eddsa
   bool walk_split = true;    // TMX_WALK_SPLIT=0: the warm schedule's table walk as ONE launch behind the table build (the round-4 form) instead of resident lanes at once + new-key lanes behind the build
@@ -286,7 +286,7 @@ struct Knobs {
   long inputs_first_min = -1; // TMX_INPUTS_FIRST=<lanes>: from that many lanes on the split warm schedule enqueues the input sections IN FRONT of the new-key pipeline on the low-priority stream (0: never)
   bool ser_rows = true;      // TMX_SER_ROWS=0: the capped row-writer launches grid-stride over (proof, block) (k_serialize_few, round 5) instead of proof-major (k_serialize_rows)
   int writer_prio = -1;      // TMX_WRITER_PRIO=<0..3>: s_setprio of the row-writer waves (default: by size, run_batch)
-  int tail_aside_min = -1;   // TMX_TAIL_ASIDE_MIN=<lanes>: from how many lanes on the verdict + its sections leave the caller's stream (default 10240)
+  int tail_aside_min = -1;   // TMX_TAIL_ASIDE_MIN=<lanes>: from how many lanes on the verdict + its sections leave the caller's stream (default 28672)
   int few_wgs = 0;           // TMX_FEW_WGS=<n>: workgroups of the serializer launches beside the chain (A/B; 0: by size, run_batch)
   int tiny = -1;             // TMX_TINY=0|1: never / always (also under a forced TMX_SCHEDULE) take the two-launch small path for <= TINY_MAX_LANES lanes
 };
@@ -661,7 +661,10 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // (a small batch is pure latency: its tail stays on s, two cross-stream hops cost more than the overlap gains)
   // (round 6: the threshold moved from 4096 to 10240 lanes -- 32 / 48 / 64 proofs x 128: 0.210 -> 0.199, 0.222 -> 0.214, 0.259 -> 0.252 ms with the
   // one-launch tail on s; 96 proofs: 0.2625 aside vs 0.2715 on s.  profiles/r06_small_tail_ab.txt)
-  const bool tail_aside = K.ser_split && (uint64_t)n_proofs * n >= (K.tail_aside_min >= 0 ? (uint64_t)K.tail_aside_min : 10240u);
+  // (round 6, with k_verdict_tail_wide as the one launch -- profiles/r06_tail_wide_ab.txt: 32 / 48 / 64 proofs 0.209 -> 0.204, 0.233 -> 0.224, 0.244 -> 0.225;
+  // the one-launch form on s up to 28 672 lanes instead of 10 240: 80 / 96 / 160 / 208 proofs x 128 0.269 -> 0.257, 0.284 -> 0.273, 0.309 -> 0.300, 0.326 -> 0.318,
+  // 224 / 240 level, 256 +1.4 %; N = 32: 512 / 768 proofs -3.7 / -1.8 %, 1024 +5 %; N = 512: 48 proofs -4 %, 32 / 64 level)
+  const bool tail_aside = K.ser_split && (uint64_t)n_proofs * n >= (K.tail_aside_min >= 0 ? (uint64_t)K.tail_aside_min : 28672u);
   const bool small_tail = K.ser_split && !tail_aside;  // D.1a goes into the SAME launch as k_proof's sections (one launch, behind the hash event)
   if (small_tail && !leaves_first) {
     if (!c->ev_hash_recorded) HIPCK(c, hipEventRecord(c->ev_hash, s));  // (a producer without a phase-1 event: everything it enqueued)
@@ -694,6 +697,11 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     if (!xv) HIPCK(c, hipEventRecord(evs[2], s));
     const bool with_rows = d_out_elems != nullptr;
     uint32_t tail_mask = (mask_final | prog.mask_tail) & (((c->sections & TMX_SEC_HINT) ? prog.mask_hint : 0u) | ((c->sections & TMX_SEC_DERIVED) ? prog.mask_derived : 0u) | (1u << 31));
+    if (K.tail_wide && !(tail_mask & mask_final))  // (k_verdict_tail: one 1024-thread workgroup per proof expands D.5 and the seam spans element by element -- 21 us at 32 proofs, 82 at 256)
+      rc = launch_verdict_tail_wide((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, row, prog.sp, src, c->d_lut[kind], c->d_wave_sec[kind],
+                                    c->d_seams[kind], (uint32_t)prog.seam_waves.size(), with_rows ? d_out_elems : nullptr, tail_mask, prog.tail_dep_elem, s,
+                                    xv ? evs[2] : nullptr, xv ? evs[3] : nullptr);
+    else
     rc = launch_verdict_tail((uint32_t)kind, n, n_proofs, tl + TL_OFF_ED, TL_STRIDE, c->d_pf, reports, row, prog.sp, src, c->d_lut[kind], c->d_seams[kind],
                              (uint32_t)prog.seam_waves.size(), with_rows ? d_out_elems : nullptr, tail_mask, s, xv ? evs[2] : nullptr, xv ? evs[3] : nullptr);
     if (rc) return fail(c, TMX_ERR_HIP, std::string("k_verdict_tail launch: ") + hipGetErrorString((hipError_t)rc));

@@ -549,10 +549,10 @@ def test_section_selection_and_u32_transfer_format(tmx, oracle):
                 ctx.witness_batch_opts(kind, wl.proofs, wl.targets, wl.trusteds, 4, "u64")
 
 
-@pytest.mark.parametrize("kind, n, P", [(0, 128, 96), (1, 64, 200)])
+@pytest.mark.parametrize("kind, n, P", [(0, 128, 240), (0, 128, 96), (1, 64, 200)])
 def test_section_selection_on_the_large_path(tmx, oracle, kind, n, P):
-    """The device entry point with a section selection above the small-tail threshold (> 10 240 lanes: the tail is k_verdict_tail_wide on the
-    high-priority stream): the selected section equals the full row's, the other one keeps the caller's fill except for the seam spans (whole
+    """The device entry point with a section selection on both forms of the one-launch tail (k_verdict_tail_wide: from 28 672 lanes on the
+    high-priority stream beside D.1a, below on the caller's stream behind it): the selected section equals the full row's, the other one keeps the caller's fill except for the seam spans (whole
     spans of 256 elements that straddle a section boundary or the row end: always written, with the right values)."""
     import torch
     from tendermintx_amd import _lib
