@@ -272,6 +272,7 @@ struct Knobs {
   bool ext_events = true;    // TMX_EXT_EVENTS=0: record packets instead of completion signals on the chain kernels
   int warm_schedule = -1;    // TMX_SCHEDULE=warm|cold: the EdDSA schedule for resident / new keys (default: by what the last launch saw)
   int phase1_max = -1;       // TMX_PHASE1_MAX=<lanes>: up to that many lanes the warm schedule runs s*B as a role of the hash launch (default 16384: 128 proofs at N = 128)
+  int one_launch_max = -1;   // TMX_SER_ONE_LAUNCH=<proofs>: up to that many proofs the uncapped serializer calls are one launch each (default 8)
   bool proof_roles = true;   // TMX_PROOF_ROLES=0: k_proof as one workgroup per proof (the round-3 kernel) instead of four role workgroups
   int tail_wide = 1;         // TMX_TAIL_WIDE=0: k_verdict -> D.5 -> the seam spans as three launches / one workgroup per proof (rounds 2 - 5) instead of ONE launch of independent workgroups (k_verdict_tail_wide)
   int p1_early = -1;         // TMX_P1_EARLY=0|1|2: D.1a behind k_proof's sections on the side stream (1: on a capped grid, 2: full grid) instead of behind k_ed_fin (default: capped, from 131072 lanes)
@@ -304,6 +305,7 @@ static Knobs read_knobs() {
   k.tiny = (v = std::getenv("TMX_TINY")) ? (v[0] != '0' ? 1 : 0) : -1;
   k.walk_split = !((v = std::getenv("TMX_WALK_SPLIT")) && v[0] == '0');
   k.proof_roles = !((v = std::getenv("TMX_PROOF_ROLES")) && v[0] == '0');
+  if ((v = std::getenv("TMX_SER_ONE_LAUNCH"))) k.one_launch_max = std::atoi(v);
   if ((v = std::getenv("TMX_PHASE1_MAX"))) k.phase1_max = std::atoi(v);
   k.hash_first = (v = std::getenv("TMX_HASH_FIRST")) ? (v[0] != '0' ? 1 : 0) : -1;
   if ((v = std::getenv("TMX_TAIL_WIDE"))) k.tail_wide = v[0] != '0' ? 1 : 0;
@@ -503,6 +505,10 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   const uint64_t lanes_w = (uint64_t)n_proofs * c->cfg.n_max;
   prog.sp.wave_prio = K.writer_prio >= 0 ? (uint32_t)K.writer_prio : (lanes_w >= 65536 ? 3u : 0u);
   prog.sp.rows_major = K.ser_rows ? 1u : 0u;
+  // (round 6: in the small form of the tail -- below 28 672 lanes, see tail_aside -- k_proof's sections + D.1a are ONE launch instead of four: 80 / 128 /
+  // 208 proofs x 128 -1.6 / -4.5 / -2.6 %, N = 512 x 32 proofs -5.6 %, 20 ... 48 proofs level; at 256 proofs +2 %: profiles/r06_one_launch_ab.txt)
+  const bool tail_aside_early = K.ser_split && (uint64_t)n_proofs * n >= (K.tail_aside_min >= 0 ? (uint64_t)K.tail_aside_min : 28672u);
+  prog.sp.one_launch_max = K.one_launch_max >= 0 ? (uint32_t)K.one_launch_max : (tail_aside_early ? 8u : n_proofs);
   auto serialize = [&](uint32_t mask, hipStream_t on, uint32_t max_wgs = 0) -> int32_t {
     if (!d_out_elems) return TMX_OK;
     // (sections the caller did not ask for are not written; the seam spans are few and always written)
@@ -664,7 +670,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // (round 6, with k_verdict_tail_wide as the one launch -- profiles/r06_tail_wide_ab.txt: 32 / 48 / 64 proofs 0.209 -> 0.204, 0.233 -> 0.224, 0.244 -> 0.225;
   // the one-launch form on s up to 28 672 lanes instead of 10 240: 80 / 96 / 160 / 208 proofs x 128 0.269 -> 0.257, 0.284 -> 0.273, 0.309 -> 0.300, 0.326 -> 0.318,
   // 224 / 240 level, 256 +1.4 %; N = 32: 512 / 768 proofs -3.7 / -1.8 %, 1024 +5 %; N = 512: 48 proofs -4 %, 32 / 64 level)
-  const bool tail_aside = K.ser_split && (uint64_t)n_proofs * n >= (K.tail_aside_min >= 0 ? (uint64_t)K.tail_aside_min : 28672u);
+  const bool tail_aside = tail_aside_early;
   const bool small_tail = K.ser_split && !tail_aside;  // D.1a goes into the SAME launch as k_proof's sections (one launch, behind the hash event)
   if (small_tail && !leaves_first) {
     if (!c->ev_hash_recorded) HIPCK(c, hipEventRecord(c->ev_hash, s));  // (a producer without a phase-1 event: everything it enqueued)

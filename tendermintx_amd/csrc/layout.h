@@ -94,6 +94,7 @@ struct SerializeProgram {
   uint32_t span;         // elements one wave serializes (128, 256 or 512): SPAN/128 coalesced 16-byte stores per thread, all loads in flight together
   uint32_t wave_prio;    // s_setprio of the row-writer waves (0: none)
   uint32_t rows_major;   // 1: capped launches walk the proofs per span block with the position's LUT words loaded once (k_serialize_rows); 0: k_serialize_few (TMX_SER_ROWS=0)
+  uint32_t one_launch_max;  // up to that many proofs an uncapped launch_serialize is ONE launch from the first to the last selected section (the blocks of unselected sections in between exit at once) instead of one per run of adjacent sections
 };
 // Fused rows (round 6): the row spans that only expand input records (H.2, H.4: 42 % of a skip row) are work items of ONE claim counter; the
 // throughput-bound EdDSA kernels (s*B, the table walk) take `per_base` / `per_walk` of them per table addition -- their stores ride between the

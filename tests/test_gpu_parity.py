@@ -682,7 +682,9 @@ KNOBS = [
     # verdict + D.5 + the seam spans as one launch of independent workgroups (k_verdict_tail_wide) / as three launches, alone and with D.1a
     # early / the tail never on the caller's stream
     {"TMX_TAIL_WIDE": "1"}, {"TMX_TAIL_WIDE": "0"}, {"TMX_TAIL_WIDE": "1", "TMX_P1_EARLY": "2"}, {"TMX_TAIL_WIDE": "0", "TMX_TAIL_ASIDE_MIN": "0", "TMX_TINY": "0"},
-    {"TMX_TAIL_WIDE": "1", "TMX_TAIL_ASIDE_MIN": "0", "TMX_TINY": "0"}]
+    {"TMX_TAIL_WIDE": "1", "TMX_TAIL_ASIDE_MIN": "0", "TMX_TINY": "0"},
+    # the uncapped serializer calls as one launch from the first to the last selected section / one per run of adjacent sections
+    {"TMX_SER_ONE_LAUNCH": "100000", "TMX_TINY": "0"}, {"TMX_SER_ONE_LAUNCH": "0", "TMX_TINY": "0"}, {"TMX_SER_ONE_LAUNCH": "100000", "TMX_TAIL_ASIDE_MIN": "0"}]
 
 
 @pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
