@@ -272,6 +272,7 @@ struct Knobs {
   bool ext_events = true;    // TMX_EXT_EVENTS=0: record packets instead of completion signals on the chain kernels
   int warm_schedule = -1;    // TMX_SCHEDULE=warm|cold: the EdDSA schedule for resident / new keys (default: by what the last launch saw)
   int phase1_max = -1;       // TMX_PHASE1_MAX=<lanes>: up to that many lanes the warm schedule runs s*B as a role of the hash launch (default 16384: 128 proofs at N = 128)
+  long tiny_max = -1;        // TMX_TINY_MAX=<lanes>: the two-launch small path up to that many lanes (default 1536, at most TINY_MAX_LANES = 2048)
   int one_launch_max = -1;   // TMX_SER_ONE_LAUNCH=<proofs>: up to that many proofs the uncapped serializer calls are one launch each (default 8)
   bool proof_roles = true;   // TMX_PROOF_ROLES=0: k_proof as one workgroup per proof (the round-3 kernel) instead of four role workgroups
   int tail_wide = 1;         // TMX_TAIL_WIDE=0: k_verdict -> D.5 -> the seam spans as three launches / one workgroup per proof (rounds 2 - 5) instead of ONE launch of independent workgroups (k_verdict_tail_wide)
@@ -306,6 +307,7 @@ static Knobs read_knobs() {
   k.walk_split = !((v = std::getenv("TMX_WALK_SPLIT")) && v[0] == '0');
   k.proof_roles = !((v = std::getenv("TMX_PROOF_ROLES")) && v[0] == '0');
   if ((v = std::getenv("TMX_SER_ONE_LAUNCH"))) k.one_launch_max = std::atoi(v);
+  if ((v = std::getenv("TMX_TINY_MAX"))) k.tiny_max = std::atol(v);
   if ((v = std::getenv("TMX_PHASE1_MAX"))) k.phase1_max = std::atoi(v);
   k.hash_first = (v = std::getenv("TMX_HASH_FIRST")) ? (v[0] != '0' ? 1 : 0) : -1;
   if ((v = std::getenv("TMX_TAIL_WIDE"))) k.tail_wide = v[0] != '0' ? 1 : 0;
@@ -770,7 +772,12 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
 // leaves, and nothing reads the caller's buffers once the caller's stream is done.  TMX_TINY=0 never takes this path.
 static bool use_tiny(const tmx_ctx* c, uint64_t n_lanes) {
   const Knobs& K = c->knobs;
-  if (K.tiny == 0 || n_lanes == 0 || n_lanes > TINY_MAX_LANES || !c->d_tiny || !c->d_shadow) return false;
+  // (round 6: up to 1536 lanes instead of TINY_MAX_LANES = 2048 -- with the validator-set cache, the one-launch tail and the one-launch sections the
+  // classic graph needs 0.18 - 0.205 ms at 13 ... 16 proofs x 128 where the two launches need 0.207 ... 0.225 (a workgroup per lane: their time grows
+  // with the lanes); N = 64: 28 proofs 0.216 -> 0.201; N = 512: 4 proofs 0.51 -> 0.44; N = 32 loses 3 - 5 % between 1536 and 2048 lanes.
+  // profiles/r06_small_batches_ab.txt)
+  const uint64_t tiny_max = K.tiny_max >= 0 ? std::min<uint64_t>((uint64_t)K.tiny_max, TINY_MAX_LANES) : 1536u;
+  if (K.tiny == 0 || n_lanes == 0 || n_lanes > tiny_max || !c->d_tiny || !c->d_shadow) return false;
   if (c->kc.cap == 0 || K.dedup_mode == 0) return false;  // (TMX_DEDUP=0: no per-key tables at all -- the classic table-free kernels)
   if (K.warm_schedule >= 0 && K.tiny < 0) return false;   // a forced schedule names one of the classic graphs
   return true;

@@ -457,7 +457,7 @@ def test_device_resident_path_with_torch(tmx, oracle):
     """tmx_witness_batch_device on PyTorch-owned HBM buffers and PyTorch's current stream (one HIP runtime per process)"""
     import torch
     from tendermintx_amd.synth import Workload
-    n, P = 128, 16
+    n, P = 128, 12
     wl = Workload(0, n, P, 128, chain_id=b"celestia", seed=31337, signed_permille=900)
     dev = torch.device("cuda", 0)
     d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) for b in (wl.proofs, wl.targets, wl.trusteds)]
@@ -470,7 +470,7 @@ def test_device_resident_path_with_torch(tmx, oracle):
             ctx.witness_batch_device(0, P, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), out.data_ptr(), rep.data_ptr(), s.cuda_stream)
         s.synchronize()
         ms = ctx.kernel_ms_mean(1)
-        # (2048 lanes = a small launch: k_tiny is attributed ONCE, to the EdDSA slot -- the four figures are disjoint intervals of the launch)
+        # (1536 lanes = the largest small launch: k_tiny is attributed ONCE, to the EdDSA slot -- the four figures are disjoint intervals of the launch)
         assert all(v >= 0 for v in ms.values()) and ms["k_eddsa"] > 0 and ms["k_verdict"] > 0 and ms["k_proof"] == 0
     got = out[:, :count].cpu().numpy().view(np.uint64)
     want, oreps = oracle.witness_batch(0, P, wl.proofs, wl.targets, wl.trusteds, n, b"celestia", 100800, n_threads=8)
@@ -653,7 +653,7 @@ KNOBS = [
     {"TMX_LEAVES": "1", "TMX_SER_SPLIT": "0"}, {"TMX_SER_SPLIT": "0"}, {"TMX_SER_SPLIT": "0", "TMX_KEY_CACHE": "0"}, {"TMX_SCHEDULE": "warm"},
     {"TMX_SCHEDULE": "cold"}, {"TMX_SCHEDULE": "warm", "TMX_KEY_CACHE_KEYS": "40"}, {"TMX_SCHEDULE": "warm", "TMX_DEDUP": "0"},
     {"TMX_SCHEDULE": "cold", "TMX_LEAVES": "1", "TMX_WALK_PARTS": "1"},
-    # round 4: the small path (two launches for <= 2048 lanes) and k_proof as role workgroups, off / forced / combined with the others
+    # round 4: the small path (two launches for <= 1536 lanes, TMX_TINY_MAX) and k_proof as role workgroups, off / forced / combined with the others
     {"TMX_TINY": "0"}, {"TMX_PROOF_ROLES": "0"}, {"TMX_TINY": "0", "TMX_PROOF_ROLES": "0"}, {"TMX_TINY": "1", "TMX_SCHEDULE": "cold"},
     {"TMX_TINY": "1", "TMX_KEY_CACHE": "0"}, {"TMX_TINY": "1", "TMX_EXT_EVENTS": "0"}, {"TMX_TINY": "1", "TMX_KEY_CACHE_KEYS": "40"},
     {"TMX_PHASE1_MAX": "0"}, {"TMX_PHASE1_MAX": "1000000", "TMX_TINY": "0"},
@@ -684,6 +684,7 @@ KNOBS = [
     {"TMX_TAIL_WIDE": "1"}, {"TMX_TAIL_WIDE": "0"}, {"TMX_TAIL_WIDE": "1", "TMX_P1_EARLY": "2"}, {"TMX_TAIL_WIDE": "0", "TMX_TAIL_ASIDE_MIN": "0", "TMX_TINY": "0"},
     {"TMX_TAIL_WIDE": "1", "TMX_TAIL_ASIDE_MIN": "0", "TMX_TINY": "0"},
     # the uncapped serializer calls as one launch from the first to the last selected section / one per run of adjacent sections
+    {"TMX_TINY_MAX": "2048"}, {"TMX_TINY_MAX": "256"},
     {"TMX_SER_ONE_LAUNCH": "100000", "TMX_TINY": "0"}, {"TMX_SER_ONE_LAUNCH": "0", "TMX_TINY": "0"}, {"TMX_SER_ONE_LAUNCH": "100000", "TMX_TAIL_ASIDE_MIN": "0"}]
 
 
