@@ -272,6 +272,7 @@ struct Knobs {
   bool ext_events = true;    // TMX_EXT_EVENTS=0: record packets instead of completion signals on the chain kernels
   int warm_schedule = -1;    // TMX_SCHEDULE=warm|cold: the EdDSA schedule for resident / new keys (default: by what the last launch saw)
   int phase1_max = -1;       // TMX_PHASE1_MAX=<lanes>: up to that many lanes the warm schedule runs s*B as a role of the hash launch (default 16384: 128 proofs at N = 128)
+  bool join1 = true;         // TMX_JOIN1=0: the small form's tail behind two wait packets (k_proof, the new-key lanes' finish) instead of one joined on side2
   long tiny_max = -1;        // TMX_TINY_MAX=<lanes>: the two-launch small path up to that many lanes (default 1536, at most TINY_MAX_LANES = 2048)
   int one_launch_max = -1;   // TMX_SER_ONE_LAUNCH=<proofs>: up to that many proofs the uncapped serializer calls are one launch each (default 8)
   bool proof_roles = true;   // TMX_PROOF_ROLES=0: k_proof as one workgroup per proof (the round-3 kernel) instead of four role workgroups
@@ -308,6 +309,7 @@ static Knobs read_knobs() {
   k.proof_roles = !((v = std::getenv("TMX_PROOF_ROLES")) && v[0] == '0');
   if ((v = std::getenv("TMX_SER_ONE_LAUNCH"))) k.one_launch_max = std::atoi(v);
   if ((v = std::getenv("TMX_TINY_MAX"))) k.tiny_max = std::atol(v);
+  if ((v = std::getenv("TMX_JOIN1"))) k.join1 = v[0] != '0';
   if ((v = std::getenv("TMX_PHASE1_MAX"))) k.phase1_max = std::atoi(v);
   k.hash_first = (v = std::getenv("TMX_HASH_FIRST")) ? (v[0] != '0' ? 1 : 0) : -1;
   if ((v = std::getenv("TMX_TAIL_WIDE"))) k.tail_wide = v[0] != '0' ? 1 : 0;
@@ -699,8 +701,16 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   if (small_tail) {
     // D.1a (needs the leaves and the hash role, both long done) goes with k_proof's sections on the side stream; what follows the join of
     // k_proof and the EdDSA finish on s is ONE launch: verdict + the sections that carry it + the seam spans (k_verdict_tail)
-    HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
-    if (fin_split) HIPCK(c, hipStreamWaitEvent(s, c->ev_direct, 0));
+    if (fin_split && K.join1) {
+      // ONE wait packet between the finish and the tail instead of two: side2 -- idle behind the new-key lanes' finish -- waits for k_proof and
+      // records ev_direct again, which then stands for both
+      HIPCK(c, hipStreamWaitEvent(c->side2, evs[1], 0));
+      HIPCK(c, hipEventRecord(c->ev_direct, c->side2));
+      HIPCK(c, hipStreamWaitEvent(s, c->ev_direct, 0));
+    } else {
+      HIPCK(c, hipStreamWaitEvent(s, evs[1], 0));
+      if (fin_split) HIPCK(c, hipStreamWaitEvent(s, c->ev_direct, 0));
+    }
     const bool xv = K.ext_events && n_proofs != 0;  // the verdict's two timing events ride on its dispatch
     if (!xv) HIPCK(c, hipEventRecord(evs[2], s));
     const bool with_rows = d_out_elems != nullptr;
@@ -719,8 +729,14 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
     // tail: the per-lane derived section (a quarter of the row) only needs k_ed_fin + k_proof, so it is written on s while the
     // verdict and the few sections that carry it go through the high-priority side stream.  (ev[2] = ev[1] here: every packet
     // between k_ed_fin and the serializer is latency on the critical path.)
+    // (the wait that is over first goes first: k_proof ends before the finish, and a wait packet behind the finish's is ~5 us of the tail's start)
+    if (K.join1) {
+      HIPCK(c, hipStreamWaitEvent(c->side2, evs[1], 0));  // k_proof itself, not the serializer launches queued behind it
+      HIPCK(c, hipStreamWaitEvent(c->side2, ev[1], 0));
+    } else {
     HIPCK(c, hipStreamWaitEvent(c->side2, ev[1], 0));
     HIPCK(c, hipStreamWaitEvent(c->side2, evs[1], 0));  // k_proof itself, not the serializer launches queued behind it
+    }
     if (K.tail_wide && n_proofs) {
       const bool xv = K.ext_events;
       if (!xv) HIPCK(c, hipEventRecord(evs[2], c->side2));

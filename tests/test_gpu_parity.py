@@ -684,7 +684,7 @@ KNOBS = [
     {"TMX_TAIL_WIDE": "1"}, {"TMX_TAIL_WIDE": "0"}, {"TMX_TAIL_WIDE": "1", "TMX_P1_EARLY": "2"}, {"TMX_TAIL_WIDE": "0", "TMX_TAIL_ASIDE_MIN": "0", "TMX_TINY": "0"},
     {"TMX_TAIL_WIDE": "1", "TMX_TAIL_ASIDE_MIN": "0", "TMX_TINY": "0"},
     # the uncapped serializer calls as one launch from the first to the last selected section / one per run of adjacent sections
-    {"TMX_TINY_MAX": "2048"}, {"TMX_TINY_MAX": "256"},
+    {"TMX_TINY_MAX": "2048"}, {"TMX_TINY_MAX": "256"}, {"TMX_JOIN1": "0"}, {"TMX_JOIN1": "0", "TMX_TAIL_ASIDE_MIN": "0", "TMX_TINY": "0"},
     {"TMX_SER_ONE_LAUNCH": "100000", "TMX_TINY": "0"}, {"TMX_SER_ONE_LAUNCH": "0", "TMX_TINY": "0"}, {"TMX_SER_ONE_LAUNCH": "100000", "TMX_TAIL_ASIDE_MIN": "0"}]
 
 
