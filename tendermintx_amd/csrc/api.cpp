@@ -258,7 +258,7 @@ Program build_program(int kind, uint32_t n) {
 
 // ------------------------------------------------------------------------------------------------ context
 constexpr int EV_RING_DECL = 128;
-constexpr uint64_t THROUGHPUT_LANES = 98304;  // proofs x validators from which run_batch schedules for throughput (see beside_chain_wgs)
+constexpr uint64_t THROUGHPUT_LANES = 81920;  // proofs x validators from which run_batch schedules for throughput (see beside_chain_wgs)
 // Schedule knobs, read ONCE at context creation (getenv is not safe against a concurrent setenv, and the enqueue path is
 // latency-critical).  Each selects a schedule, never a value (tests/test_gpu_parity.py::test_schedule_knobs_give_the_same_bits); the A/B
 // harness that measured the alternatives no longer in the product lives in tools/ (DESIGN.md appendix "measured and dropped").
@@ -541,7 +541,7 @@ static int32_t run_batch(tmx_ctx* c, int32_t kind, uint32_t n_proofs, const void
   // (round 6, with the proof-major writer k_serialize_rows, profiles/r06_writer_cap_sweep2.txt: persistent writers hold their wave slots for
   // the whole launch and the chain's kernels wait for a slot; 32768 short-lived workgroups instead of 8192: 1024 / 1536 / 2048 proofs
   // 1.42 -> 1.28, 2.06 -> 1.91, 2.81 -> 2.59 ms; 65536: the same; 131072 and uncapped: +6 ... +10 %.  The whole throughput regime -- this cap,
-  // the input sections first, the leaves first, D.1a early -- from THROUGHPUT_LANES = 98304 on: 768 / 896 proofs 1.08 -> 1.05, 1.25 -> 1.20 ms;
+  // the input sections first, the leaves first, D.1a early -- from THROUGHPUT_LANES on (first 98304: 768 / 896 proofs 1.08 -> 1.05, 1.25 -> 1.20 ms; then 81920: 672 / 704 / 736 proofs 0.894 -> 0.854, 0.943 -> 0.876, 1.011 -> 0.946, 640 level);
   // 512 / 640 proofs within +-2 % either way and left as they were)
   const bool throughput = lanes_bc >= THROUGHPUT_LANES;
   const uint32_t beside_chain_wgs = K.few_wgs > 0 ? (uint32_t)K.few_wgs : (throughput ? 32768u : (lanes_bc >= 65536 ? 1536u : (lanes_bc > 16384 ? 2048u : 1024u)));  // (warm key cache, 256 proofs: 2048 / 4096 / uncapped +10 / +4 / +2 %)

@@ -65,7 +65,7 @@ def test_mixed_sizes_back_to_back(built_lib, n):
     from tendermintx_amd.synth import Workload, bench_workload
     dev = torch.device("cuda:0")
     up = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
-    sizes = [1, 2, 24, 256, 3, 40, 130] + ([800] if n == 128 else [])   # (800 x 128 lanes: the throughput regime's schedule, api.cpp THROUGHPUT_LANES)
+    sizes = [1, 2, 24, 256, 3, 40, 130] + ([800] if n == 128 else [])   # (800 x 128 lanes: the throughput regime's schedule, api.cpp THROUGHPUT_LANES = 81 920)
     rounds = int(os.environ.get("TMX_SOAK_ROUNDS", "40"))                # (a soak: TMX_SOAK_ROUNDS=3000)
     Pmax = max(sizes)
     base = bench_workload("survey8d", n, Pmax, seed=77 + n)
