@@ -792,7 +792,8 @@ static bool use_tiny(const tmx_ctx* c, uint64_t n_lanes) {
   // classic graph needs 0.18 - 0.205 ms at 13 ... 16 proofs x 128 where the two launches need 0.207 ... 0.225 (a workgroup per lane: their time grows
   // with the lanes); N = 64: 28 proofs 0.216 -> 0.201; N = 512: 4 proofs 0.51 -> 0.44; N = 32 loses 3 - 5 % between 1536 and 2048 lanes.
   // profiles/r06_small_batches_ab.txt)
-  const uint64_t tiny_max = K.tiny_max >= 0 ? std::min<uint64_t>((uint64_t)K.tiny_max, TINY_MAX_LANES) : 1536u;
+  // (small validator sets keep the old bound: N = 32 x 56 / 64 proofs 0.222 / 0.219 on the small path against 0.228 / 0.230)
+  const uint64_t tiny_max = K.tiny_max >= 0 ? std::min<uint64_t>((uint64_t)K.tiny_max, TINY_MAX_LANES) : (c->cfg.n_max <= 32 ? TINY_MAX_LANES : 1536u);
   if (K.tiny == 0 || n_lanes == 0 || n_lanes > tiny_max || !c->d_tiny || !c->d_shadow) return false;
   if (c->kc.cap == 0 || K.dedup_mode == 0) return false;  // (TMX_DEDUP=0: no per-key tables at all -- the classic table-free kernels)
   if (K.warm_schedule >= 0 && K.tiny < 0) return false;   // a forced schedule names one of the classic graphs
